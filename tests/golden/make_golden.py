@@ -1,0 +1,349 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in this directory by running the REFERENCE
+implementation (imported read-only from /root/reference) on small seeded inputs.
+
+Run in the build container only (the GPU box has no /root/reference):
+    python tests/golden/make_golden.py
+
+The reference modules are imported unmodified; packages that are absent here and
+untouched by the hot path (trimesh, cv2, open3d, ...) are stubbed with MagicMock
+exactly as SURVEY.md section 8(c) describes.  A `Trainer` is built with
+`object.__new__` and the attribute set the unmodified `Trainer.sample_points /
+sdf_eval_and_loss / step` methods read.  Every random draw the reference makes
+(`torch.randint/rand/normal/randn`, `np.random.choice`) is recorded so the
+oracle and the HIP path can consume identical draws.
+"""
+import os
+import sys
+import copy
+from unittest import mock
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, REPO)
+REF = "/root/reference"
+
+
+STUB_ROOTS = ["trimesh", "cv2", "imgviz", "torchvision", "open3d", "pyglet", "skimage",
+              "imageio", "git", "urdfpy", "rospy", "sensor_msgs", "geometry_msgs",
+              "orb_slam3_ros_wrapper", "cv_bridge", "message_filters"]
+
+
+class _StubFinder:
+    """meta-path finder: any (sub)module of a package that is absent here
+    resolves to a MagicMock (the hot path never touches them)."""
+
+    def __init__(self, roots):
+        self.roots = set(roots)
+
+    def find_spec(self, fullname, path=None, target=None):
+        import importlib.machinery
+        if fullname.split(".")[0] in self.roots:
+            return importlib.machinery.ModuleSpec(fullname, self, is_package=True)
+        return None
+
+    def create_module(self, spec):
+        m = mock.MagicMock(name=spec.name)
+        m.__path__ = []
+        m.__spec__ = spec
+        m.__name__ = spec.name
+        return m
+
+    def exec_module(self, module):
+        pass
+
+
+def import_reference():
+    import importlib
+    missing = []
+    for name in STUB_ROOTS:
+        try:
+            importlib.import_module(name)
+        except Exception:
+            missing.append(name)
+    sys.meta_path.insert(0, _StubFinder(missing))
+    sys.path.insert(0, REF)
+    from isdf.modules import trainer, sample, embedding, fc_map, loss  # noqa
+    from isdf.geometry import transform  # noqa
+    from isdf.datasets.data_util import FrameData  # noqa
+    return trainer, sample, embedding, fc_map, loss, transform, FrameData
+
+
+class DrawRecorder:
+    """Wraps torch RNG entry points used on the hot path and logs what they return."""
+
+    def __init__(self):
+        self.log = []
+        self._orig = {}
+
+    def __enter__(self):
+        for name in ["randint", "rand", "normal", "randn"]:
+            self._orig[name] = getattr(torch, name)
+
+            def wrap(*a, _n=name, **k):
+                out = self._orig[_n](*a, **k)
+                self.log.append((_n, out.detach().cpu().numpy().copy()))
+                return out
+            setattr(torch, name, wrap)
+        return self
+
+    def __exit__(self, *exc):
+        for name, fn in self._orig.items():
+            setattr(torch, name, fn)
+
+    def pop_step(self, with_noise=True):
+        """randint(h), randint(w), rand(U), normal(N_off)[, randn(noise)]"""
+        names = ["randint", "randint", "rand", "normal"] + (["randn"] if with_noise else [])
+        got = [self.log.pop(0) for _ in names]
+        assert [g[0] for g in got] == names, [g[0] for g in got]
+        return [g[1] for g in got]
+
+
+def synth_frames(rng, F, H, W, fx, fy, cx, cy):
+    """Small posed-depth keyframes: smooth depth 1-4 m, ~4% invalid (0), unit
+    normals with a NaN border + a few NaN pixels (as the reference's normal
+    estimator leaves them)."""
+    v, u = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+    depth = np.empty((F, H, W), np.float32)
+    normal = np.empty((F, H, W, 3), np.float32)
+    T = np.empty((F, 4, 4), np.float32)
+    for f in range(F):
+        depth[f] = (2.5 + 1.2 * np.sin(0.11 * u + f) * np.cos(0.07 * v - 0.5 * f)
+                    + 0.3 * rng.standard_normal((H, W))).astype(np.float32)
+        depth[f][rng.uniform(size=(H, W)) < 0.04] = 0.0
+        n = rng.standard_normal((H, W, 3)).astype(np.float32)
+        n /= np.linalg.norm(n, axis=-1, keepdims=True)
+        n[:2] = np.nan; n[-2:] = np.nan; n[:, :2] = np.nan; n[:, -2:] = np.nan
+        n[rng.uniform(size=(H, W)) < 0.02] = np.nan
+        normal[f] = n
+        a = 0.3 * f
+        Rm = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]])
+        b = 0.1 * f
+        Rx = np.array([[1, 0, 0], [0, np.cos(b), -np.sin(b)], [0, np.sin(b), np.cos(b)]])
+        T[f] = np.eye(4)
+        T[f, :3, :3] = Rm @ Rx
+        T[f, :3, 3] = [0.5 * f - 1.0, 0.1 * f, 0.2 * f]
+    return depth, normal, T
+
+
+def bounds_transform(rng):
+    a, b = 0.4, -0.25
+    Rz = np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1]])
+    Ry = np.array([[np.cos(b), 0, np.sin(b)], [0, 1, 0], [-np.sin(b), 0, np.cos(b)]])
+    T = np.eye(4, dtype=np.float32)
+    T[:3, :3] = (Rz @ Ry).astype(np.float32)
+    T[:3, 3] = [0.3, -0.2, 0.1]
+    return T
+
+
+def build_trainer(mods, cam, net, lossc, samplec, frames_np, params_np, transform_np,
+                  noise_std, window_size=5, incremental=True):
+    trainer, sample, embedding, fc_map, loss, transform, FrameData = mods
+    tr = object.__new__(trainer.Trainer)
+    tr.device = "cpu"
+    tr.incremental = incremental
+    tr.window_size = window_size
+    tr.do_normal = True
+    tr.H, tr.W = cam["H"], cam["W"]
+    tr.n_rays = samplec["n_rays"]
+    tr.dist_behind_surf = samplec["dist_behind_surf"]
+    tr.n_strat_samples = samplec["n_strat"]
+    tr.n_surf_samples = samplec["n_surf"]
+    tr.min_depth = samplec["min_depth"]
+    tr.dirs_C = transform.ray_dirs_C(1, cam["H"], cam["W"], cam["fx"], cam["fy"], cam["cx"],
+                                     cam["cy"], "cpu", depth_type="z")
+    tr.eik_weight = lossc["eik_weight"]
+    tr.grad_weight = lossc["grad_weight"]
+    tr.noise_std = noise_std
+    tr.bounds_method = lossc["bounds_method"]
+    tr.trunc_distance = lossc["trunc_distance"]
+    tr.loss_type = lossc["loss_type"]
+    tr.orien_loss = lossc["orien_loss"]
+    tr.eik_apply_dist = lossc["eik_apply_dist"]
+    tr.trunc_weight = lossc["trunc_weight"]
+    tr.loss_approx_factor = 8
+    tr.frac_time_perception = 1.0
+    tr.tot_step_time = 0.0
+    tr.steps_since_frame = 0
+    tr.cosSim = torch.nn.CosineSimilarity(dim=-1, eps=1e-6)
+    T_t = None if transform_np is None else torch.from_numpy(transform_np)
+    pe = embedding.PostionalEncoding(min_deg=0, max_deg=net["n_freqs"] - 1,
+                                     scale=net["scale_input"], transform=T_t)
+    tr.sdf_map = fc_map.SDFMap(pe, hidden_size=net["H"], hidden_layers_block=net["B"],
+                               scale_output=net["scale_output"])
+    sd = {k: torch.from_numpy(v.copy()) for k, v in params_np.items()}
+    tr.sdf_map.load_state_dict(sd)
+    tr.optimiser = torch.optim.AdamW(tr.sdf_map.parameters(), lr=0.0013, weight_decay=0.012)
+    depth, normal, T = frames_np
+    K = depth.shape[0]
+    tr.frames = FrameData(
+        frame_id=np.arange(K), im_batch=torch.zeros(K, cam["H"], cam["W"], 3),
+        depth_batch=torch.from_numpy(depth.copy()), T_WC_batch=torch.from_numpy(T.copy()),
+        normal_batch=torch.from_numpy(normal.copy()),
+        frame_avg_losses=torch.zeros(K))
+    return tr
+
+
+LOSS_DEFAULT = dict(bounds_method="ray", loss_type="L1", trunc_weight=5.38344020,
+                    trunc_distance=0.29365022, eik_weight=0.268, eik_apply_dist=0.1,
+                    grad_weight=0.018, orien_loss=False)
+SAMPLE_DEFAULT = dict(n_rays=40, n_strat=19, n_surf=8, min_depth=0.07, dist_behind_surf=0.1)
+
+
+def t2n(x):
+    return None if x is None else x.detach().cpu().numpy().copy()
+
+
+def run_eval_case(mods, name, net, lossc, samplec, F, cam, seed, noise_std, full_grads,
+                  transform_on=True):
+    """sample_points + sdf_eval_and_loss + backward on the reference; store everything."""
+    import oracle.isdf_oracle as orc
+    rng = np.random.RandomState(seed)
+    frames_np = synth_frames(rng, F, cam["H"], cam["W"], cam["fx"], cam["fy"], cam["cx"], cam["cy"])
+    params_np = orc.init_params(net["H"], net["B"], net["n_freqs"], np.random.RandomState(seed + 100))
+    Tb = bounds_transform(rng) if transform_on else None
+    tr = build_trainer(mods, cam, net, lossc, samplec, frames_np, params_np, Tb, noise_std)
+    torch.manual_seed(seed)
+    with DrawRecorder() as rec:
+        sp = tr.sample_points(tr.frames.depth_batch, tr.frames.T_WC_batch,
+                              norm_batch=tr.frames.normal_batch)
+        pc_in = sp["pc"].clone()
+        total, losses, loss_approx, frame_avg_loss = tr.sdf_eval_and_loss(sp, do_avg_loss=True)
+        ih, iw, U, N_off, noise = rec.pop_step(with_noise=True)
+    # recompute sdf/sdf_grad with the same noise for storage
+    mods_fc = mods[3]
+    pc = pc_in.clone().requires_grad_()
+    torch.manual_seed(0)
+    raw_sdf = tr.sdf_map(pc, noise_std=None)
+    sdf_nonoise = raw_sdf.detach()
+    sdf_grad = mods_fc.gradient(pc, raw_sdf).detach()
+    total.backward()
+    grads = {k: t2n(p.grad) for k, p in tr.sdf_map.named_parameters()}
+    out = dict(
+        depth_batch=frames_np[0], normal_batch=frames_np[1], T_WC_batch=frames_np[2],
+        cam=np.array([cam["H"], cam["W"], cam["fx"], cam["fy"], cam["cx"], cam["cy"]], np.float64),
+        net=np.array([net["H"], net["B"], net["n_freqs"], net["scale_input"], net["scale_output"]], np.float64),
+        seed=np.array([seed]), noise_std=np.array([noise_std], np.float64),
+        has_transform=np.array([int(transform_on)]),
+        bounds_T=Tb if Tb is not None else np.eye(4, dtype=np.float32),
+        draw_indices_h=ih, draw_indices_w=iw, draw_U=U, draw_N_off=N_off,
+        draw_noise=noise,  # raw N(0,1) draw; scaled by noise_std at use
+        pc=t2n(sp["pc"]), z_vals=t2n(sp["z_vals"]), indices_b=t2n(sp["indices_b"]),
+        indices_h=t2n(sp["indices_h"]), indices_w=t2n(sp["indices_w"]),
+        dirs_C_sample=t2n(sp["dirs_C_sample"]), depth_sample=t2n(sp["depth_sample"]),
+        T_WC_sample=t2n(sp["T_WC_sample"]), norm_sample=t2n(sp["norm_sample"]),
+        sdf_nonoise=t2n(sdf_nonoise), sdf_grad=t2n(sdf_grad),
+        total_loss=np.array([float(total)]),
+        sdf_loss=np.array([losses["sdf_loss"]]),
+        grad_loss=np.array([losses.get("grad_loss", np.nan)]),
+        eikonal_loss=np.array([losses.get("eikonal_loss", np.nan)]),
+        loss_approx=t2n(loss_approx), frame_avg_loss=t2n(frame_avg_loss),
+    )
+    for k, v in lossc.items():
+        out["loss_" + k] = np.array([v]) if not isinstance(v, str) else np.array(v)
+    for k, v in samplec.items():
+        out["sample_" + k] = np.array([v], np.float64)
+    if full_grads:
+        for k, v in params_np.items():
+            out["param/" + k] = v
+        for k, v in grads.items():
+            out["grad/" + k] = v
+    else:
+        prng = np.random.RandomState(1234)
+        for k, v in grads.items():
+            probe = prng.standard_normal(v.shape).astype(np.float64)
+            out["gdig/" + k] = np.array([np.linalg.norm(v.astype(np.float64)),
+                                         float((v.astype(np.float64) * probe).sum())])
+            out["ghead/" + k] = v.reshape(-1)[:64].copy()
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, "R =", out["depth_sample"].shape[0], "total_loss =", float(total),
+          {k: round(float(v), 6) if not torch.is_tensor(v) else float(v) for k, v in losses.items()})
+
+
+def run_step_case(mods, name, net, lossc, samplec, K, cam, seed, noise_std, n_steps, window_size):
+    """Unmodified Trainer.step (incl. select_keyframes when K > window) for n_steps."""
+    import oracle.isdf_oracle as orc
+    rng = np.random.RandomState(seed)
+    frames_np = synth_frames(rng, K, cam["H"], cam["W"], cam["fx"], cam["fy"], cam["cx"], cam["cy"])
+    params_np = orc.init_params(net["H"], net["B"], net["n_freqs"], np.random.RandomState(seed + 100))
+    Tb = bounds_transform(rng)
+    tr = build_trainer(mods, cam, net, lossc, samplec, frames_np, params_np, Tb, noise_std,
+                       window_size=window_size)
+    tr.frames.frame_avg_losses = torch.from_numpy(
+        np.random.RandomState(seed + 5).uniform(0.5, 1.5, K).astype(np.float32))
+    fal0 = t2n(tr.frames.frame_avg_losses)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    out = dict(
+        depth_batch=frames_np[0], normal_batch=frames_np[1], T_WC_batch=frames_np[2],
+        cam=np.array([cam["H"], cam["W"], cam["fx"], cam["fy"], cam["cx"], cam["cy"]], np.float64),
+        net=np.array([net["H"], net["B"], net["n_freqs"], net["scale_input"], net["scale_output"]], np.float64),
+        seed=np.array([seed]), noise_std=np.array([noise_std], np.float64), bounds_T=Tb,
+        frame_avg_losses0=fal0, window_size=np.array([window_size]), n_steps=np.array([n_steps]),
+    )
+    for k, v in lossc.items():
+        out["loss_" + k] = np.array([v]) if not isinstance(v, str) else np.array(v)
+    for k, v in samplec.items():
+        out["sample_" + k] = np.array([v], np.float64)
+    for k, v in params_np.items():
+        out["param/" + k] = v
+    with DrawRecorder() as rec:
+        for s in range(n_steps):
+            losses, _ = tr.step()
+            ih, iw, U, N_off, noise = rec.pop_step(with_noise=True)
+            out["s%d/idxs" % s] = np.asarray(tr.active_idxs, np.int64)
+            out["s%d/draw_indices_h" % s] = ih
+            out["s%d/draw_indices_w" % s] = iw
+            out["s%d/draw_U" % s] = U
+            out["s%d/draw_N_off" % s] = N_off
+            out["s%d/draw_noise" % s] = noise
+            out["s%d/total_loss" % s] = np.array([float(losses["total_loss"])])
+            out["s%d/sdf_loss" % s] = np.array([losses["sdf_loss"]])
+            out["s%d/grad_loss" % s] = np.array([losses["grad_loss"]])
+            out["s%d/eikonal_loss" % s] = np.array([losses["eikonal_loss"]])
+            out["s%d/frame_avg_losses" % s] = t2n(tr.frames.frame_avg_losses)
+            print(name, "step", s, "idxs", list(tr.active_idxs), "total", float(losses["total_loss"]))
+    for k, p in tr.sdf_map.named_parameters():
+        out["param_after/" + k] = t2n(p)
+    st = tr.optimiser.state_dict()["state"]
+    names = [k for k, _ in tr.sdf_map.named_parameters()]
+    for i, k in enumerate(names):
+        out["exp_avg/" + k] = t2n(st[i]["exp_avg"])
+        out["exp_avg_sq/" + k] = t2n(st[i]["exp_avg_sq"])
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path)
+
+
+def main():
+    torch.set_num_threads(4)
+    mods = import_reference()
+    cam_s = dict(H=48, W=64, fx=60.0, fy=60.0, cx=31.5, cy=23.5)
+    small = dict(H=64, B=1, n_freqs=6, scale_input=0.05937489, scale_output=0.14)
+    full = dict(H=256, B=2, n_freqs=6, scale_input=0.05937489, scale_output=0.14)
+    # 1. small net, default loss, noise on, bounds transform on: every tensor + full grads
+    run_eval_case(mods, "eval_small_ray", small, LOSS_DEFAULT, SAMPLE_DEFAULT, 3, cam_s, 11, 0.25, True)
+    # 2. small net, bounds "pc", L2 loss
+    lc = dict(LOSS_DEFAULT, bounds_method="pc", loss_type="L2")
+    run_eval_case(mods, "eval_small_pc_l2", small, lc, SAMPLE_DEFAULT, 3, cam_s, 12, 0.08, True)
+    # 3. small net, no eikonal/normal terms (no input gradient), identity transform
+    lc = dict(LOSS_DEFAULT, eik_weight=0.0, grad_weight=0.0)
+    run_eval_case(mods, "eval_small_nograd", small, lc, SAMPLE_DEFAULT, 2, cam_s, 13, 0.04, True,
+                  transform_on=False)
+    # 4. default-size net (6x256, E=255), digest of grads only (weights regenerate from seed)
+    run_eval_case(mods, "eval_full_ray", full, LOSS_DEFAULT, dict(SAMPLE_DEFAULT, n_rays=24), 5,
+                  cam_s, 14, 0.25, False)
+    # 5. unmodified Trainer.step x3 with K=7 keyframes > window 5 (select_keyframes, quirk q4)
+    run_step_case(mods, "step_small_k7", small, LOSS_DEFAULT, dict(SAMPLE_DEFAULT, n_rays=30), 7,
+                  cam_s, 21, 0.08, 3, 5)
+    # 6. K=3 <= window: all frames every step
+    run_step_case(mods, "step_small_k3", small, LOSS_DEFAULT, dict(SAMPLE_DEFAULT, n_rays=30), 3,
+                  cam_s, 22, 0.04, 2, 5)
+
+
+if __name__ == "__main__":
+    main()

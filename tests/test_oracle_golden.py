@@ -1,0 +1,154 @@
+"""Pin the CPU oracle (oracle/isdf_oracle.py) against fixtures produced by the
+REAL reference (tests/golden/make_golden.py imports /root/reference).  The
+reference ships no tests or golden vectors for this path, so
+these reference-run outputs are what anchors parity."""
+import numpy as np
+import pytest
+
+import oracle.isdf_oracle as orc
+from tests import golden_util as gu
+
+EVAL_CASES = ["eval_small_ray", "eval_small_pc_l2", "eval_small_nograd", "eval_full_ray"]
+
+
+def _sample(g):
+    cam, sc = gu.cam_of(g), gu.sample_of(g)
+    F = g["depth_batch"].shape[0]
+    dirs_C = orc.ray_dirs_C(cam["H"], cam["W"], cam["fx"], cam["fy"], cam["cx"], cam["cy"])
+    ib = orc.sample_pixels_indices_b(sc["n_rays"], F)
+    bd = orc.get_batch_data(g["depth_batch"], g["T_WC_batch"], dirs_C, ib,
+                            g["draw_indices_h"], g["draw_indices_w"], g["normal_batch"])
+    max_depth = bd["depth_sample"] + np.float32(sc["dist_behind_surf"])
+    pc, z = orc.sample_along_rays(bd["T_WC_sample"], sc["min_depth"], max_depth, sc["n_strat"],
+                                  sc["n_surf"], bd["dirs_C_sample"], bd["depth_sample"],
+                                  g["draw_U"], g["draw_N_off"])
+    return bd, pc, z
+
+
+@pytest.mark.parametrize("case", EVAL_CASES)
+def test_sampler_matches_reference(case):
+    g = gu.load(case)
+    bd, pc, z = _sample(g)
+    # index work: bit-exact (compaction order included)
+    for k in ["indices_b", "indices_h", "indices_w"]:
+        assert np.array_equal(bd[k], g[k]), k
+    assert np.array_equal(bd["depth_sample"], g["depth_sample"])
+    assert np.array_equal(bd["norm_sample"], g["norm_sample"])
+    assert np.array_equal(bd["T_WC_sample"], g["T_WC_sample"])
+    np.testing.assert_allclose(bd["dirs_C_sample"], g["dirs_C_sample"], rtol=0, atol=1e-7)
+    np.testing.assert_allclose(z, g["z_vals"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(pc, g["pc"], rtol=0, atol=4e-6)
+
+
+@pytest.mark.parametrize("case", EVAL_CASES)
+def test_forward_and_input_gradient(case):
+    g = gu.load(case)
+    cfg, params = gu.net_of(g), gu.params_of(g)
+    x = g["pc"].reshape(-1, 3)
+    sdf, grad = orc.sdf_forward_grad(params, cfg, x)
+    assert gu.rel_err(sdf, g["sdf_nonoise"].reshape(-1)) < 2e-5
+    assert gu.rel_err(grad, g["sdf_grad"].reshape(-1, 3)) < 5e-5
+    # float64 evaluation of the same formulas agrees with the reference to fp32 round-off
+    cfg64 = gu.net_of(g, np.float64)
+    sdf64, grad64 = orc.sdf_forward_grad(params, cfg64, x.astype(np.float64))
+    assert gu.rel_err(sdf64, g["sdf_nonoise"].reshape(-1)) < 2e-5
+    assert gu.rel_err(grad64, g["sdf_grad"].reshape(-1, 3)) < 5e-5
+
+
+@pytest.mark.parametrize("case", EVAL_CASES)
+def test_losses_and_param_grads(case):
+    g = gu.load(case)
+    cfg, lc, params = gu.net_of(g), gu.loss_of(g), gu.params_of(g)
+    noise = g["draw_noise"].reshape(g["z_vals"].shape) * np.float32(g["noise_std"][0])
+    terms, grads = orc.loss_and_grads(params, cfg, lc, g["pc"], g["z_vals"], g["depth_sample"],
+                                      g["dirs_C_sample"], g["T_WC_sample"], g["norm_sample"],
+                                      noise=noise)
+    assert abs(terms["total_loss"] - g["total_loss"][0]) < 2e-5 * abs(g["total_loss"][0])
+    assert abs(terms["sdf_loss"] - g["sdf_loss"][0]) < 2e-5 * abs(g["sdf_loss"][0])
+    if lc.grad_weight != 0:
+        assert abs(terms["grad_loss"] - g["grad_loss"][0]) < 2e-5 * abs(g["grad_loss"][0])
+    if lc.eik_weight != 0:
+        assert abs(terms["eikonal_loss"] - g["eikonal_loss"][0]) < 5e-5 * abs(g["eikonal_loss"][0])
+    cam = gu.cam_of(g)
+    la, fa = orc.frame_avg(terms["tot_loss_mat"], g["indices_b"], g["indices_h"], g["indices_w"],
+                           g["depth_batch"].shape[0], cam["H"], cam["W"])
+    np.testing.assert_allclose(la, g["loss_approx"], rtol=2e-4, atol=1e-6)
+    np.testing.assert_allclose(fa, g["frame_avg_loss"], rtol=2e-4, atol=1e-6)
+    # parameter gradients (hand-derived double backward vs autograd in the reference)
+    full = any(k.startswith("grad/") for k in g)
+    prng = np.random.RandomState(1234)
+    for k in params:  # reference named_parameters() order (digest probes were drawn in it)
+        if full:
+            ref = g["grad/" + k]
+            assert gu.rel_err(grads[k], ref) < 3e-4, (k, gu.rel_err(grads[k], ref))
+        else:
+            probe = prng.standard_normal(grads[k].shape)
+            nrm, dot = g["gdig/" + k]
+            v = grads[k].astype(np.float64)
+            assert abs(np.linalg.norm(v) - nrm) < 3e-4 * nrm, k
+            assert abs((v * probe).sum() - dot) < 3e-4 * nrm * np.sqrt(v.size), k
+            np.testing.assert_allclose(grads[k].reshape(-1)[:64], g["ghead/" + k],
+                                       rtol=0, atol=3e-4 * np.abs(g["ghead/" + k]).max())
+
+
+def test_double_backward_float64_tight():
+    """The hand derivation evaluated in float64 matches the reference's autograd
+    result to fp32 round-off of the REFERENCE (not of the oracle)."""
+    g = gu.load("eval_small_ray")
+    cfg, lc, params = gu.net_of(g, np.float64), gu.loss_of(g), gu.params_of(g)
+    noise = (g["draw_noise"].reshape(g["z_vals"].shape) * g["noise_std"][0]).astype(np.float64)
+    f64 = lambda a: a.astype(np.float64)
+    terms, grads = orc.loss_and_grads(params, cfg, lc, f64(g["pc"]), f64(g["z_vals"]),
+                                      f64(g["depth_sample"]), f64(g["dirs_C_sample"]),
+                                      f64(g["T_WC_sample"]), f64(g["norm_sample"]), noise=noise)
+    for k in grads:
+        assert gu.rel_err(grads[k], g["grad/" + k]) < 1e-4, (k, gu.rel_err(grads[k], g["grad/" + k]))
+
+
+@pytest.mark.parametrize("case", ["step_small_k7", "step_small_k3"])
+def test_full_steps_match_reference_trainer_step(case):
+    """Unmodified reference `Trainer.step` x n (incl. select_keyframes and the
+    un-windowed normal_batch quirk) vs oracle.train_step."""
+    g = gu.load(case)
+    cfg, lc, params = gu.net_of(g), gu.loss_of(g), gu.params_of(g)
+    cam, sc = gu.cam_of(g), gu.sample_of(g)
+    state = orc.new_adam_state()
+    fal = g["frame_avg_losses0"].copy()
+    for s in range(int(g["n_steps"][0])):
+        idxs = g["s%d/idxs" % s]
+        F = len(idxs)
+        frames = dict(depth_batch=g["depth_batch"][idxs], T_WC_batch=g["T_WC_batch"][idxs],
+                      normal_batch=g["normal_batch"])  # quirk q4: normals NOT windowed
+        noise = g["s%d/draw_noise" % s] * np.float32(g["noise_std"][0])
+        draws = dict(indices_h=g["s%d/draw_indices_h" % s], indices_w=g["s%d/draw_indices_w" % s],
+                     U=g["s%d/draw_U" % s], N_off=g["s%d/draw_N_off" % s], noise=noise)
+        out = orc.train_step(params, state, cfg, lc, frames, cam, sc, draws)
+        fal[idxs] = out["frame_avg_loss"]
+        for k in ["total_loss", "sdf_loss", "grad_loss", "eikonal_loss"]:
+            ref = g["s%d/%s" % (s, k)][0]
+            assert abs(out[k] - ref) < 1e-4 * abs(ref), (s, k, out[k], ref)
+        np.testing.assert_allclose(fal, g["s%d/frame_avg_losses" % s], rtol=5e-4, atol=1e-6)
+    for k in params:
+        assert gu.rel_err(params[k], g["param_after/" + k]) < 2e-4, k
+        assert gu.rel_err(state["exp_avg"][k], g["exp_avg/" + k]) < 2e-3, k
+
+
+def test_select_keyframes_numpy_rng():
+    """`Trainer.select_keyframes` (trainer.py:652-674): the recorded window of the
+    K=7 fixture is what np.random.choice(p=loss_dist) gives for the same seed."""
+    g = gu.load("step_small_k7")
+    np.random.seed(int(g["seed"][0]))
+    fal = g["frame_avg_losses0"]
+    K = fal.shape[0]
+    p = (fal[:-2] / fal[:-2].sum())
+    ints = np.random.choice(np.arange(0, K - 2), size=int(g["window_size"][0]) - 2,
+                            replace=False, p=p)
+    assert list(ints) + [K - 2, K - 1] == list(g["s0/idxs"])
+
+
+def test_structural_known_answers():
+    """Known structural answers of the reference net (SURVEY 0 / 8c probes)."""
+    assert orc.embedding_size(6) == 255
+    p = orc.init_params(256, 2, 6, np.random.RandomState(0))
+    assert sum(v.size for v in p.values()) == 460033
+    assert len(p) == 14
