@@ -1,0 +1,210 @@
+/*
+ * isdf_hip.h -- C ABI of the MI355X-native iSDF training hot path.
+ *
+ * The reference (facebookresearch/iSDF) is pure Python/PyTorch and has no FFI;
+ * its seam for this path is the Python method `Trainer.step`
+ * (isdf/modules/trainer.py:951-1016) and the two methods it calls,
+ * `Trainer.sample_points` (:683-766) and `Trainer.sdf_eval_and_loss` (:768-868).
+ * This header is what a ctypes binding inside those methods binds to; the
+ * reference-side stub is shown in INTEGRATION.md, the in-repo host mirror is
+ * isdf_amd/trainer.py.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no torch types.  All pointers are
+ *     DEVICE pointers unless a parameter name ends in `_host`.
+ *   - The caller owns every buffer (torch allocates them); the library keeps
+ *     no state between calls and never allocates, frees or synchronises.
+ *   - All work is enqueued on `stream` (a hipStream_t passed as void*).
+ *   - Return value: 0 on success, a negative ISDF_E* code otherwise; never
+ *     throws.  isdf_error_string() names the code.
+ *   - Points are stored ray-major: point n = ray * S + s, S = n_strat + n_surf.
+ */
+#ifndef ISDF_HIP_H
+#define ISDF_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ISDF_ABI_VERSION 1
+
+enum {
+  ISDF_OK = 0,
+  ISDF_EINVAL = -1,       /* bad argument / null pointer / size mismatch      */
+  ISDF_EUNSUPPORTED = -2, /* configuration the kernels are not built for      */
+  ISDF_EWORKSPACE = -3,   /* caller workspace too small                       */
+  ISDF_EHIP = -4          /* a HIP runtime call failed (see hipGetLastError)  */
+};
+
+/* ---- network description ------------------------------------------------
+ * Mirrors SDFMap(PostionalEncoding) (isdf/modules/fc_map.py:63-111,
+ * isdf/modules/embedding.py:24-111).  Parameters live in ONE flat fp32 buffer
+ * in `named_parameters()` order:
+ *   in_layer.0.{weight[Hd,E],bias[Hd]}, mid1.i.0.{weight[Hd,Hd],bias}, i<B,
+ *   cat_layer.0.{weight[Hd,Hd+E],bias}, mid2.i.0.{...}, out_alpha.{weight[1,Hd],bias[1]}
+ * (the host mirror re-points the nn.Module parameters at views of it).       */
+typedef struct isdf_net_cfg {
+  int32_t hidden;        /* Hd: hidden_feature_size (replicaCAD.json:58)       */
+  int32_t blocks;        /* B : hidden_layers_block (replicaCAD.json:57)       */
+  int32_t n_freqs;       /* n_embed_funcs + 1 (embedding.py:36); E = 42*n+3    */
+  int32_t has_transform; /* 0: PE transform is None (live modes)    */
+  float scale_input;     /* embedding.scale_input                              */
+  float scale_output;    /* model.scale_output (fc_map.py:109)                 */
+  float bounds_T[12];    /* rows of inv_bounds_transform[:3,:4] (row-major)    */
+  int32_t fwd_operand;   /* 0: bf16, 1: fp16 MFMA operands in the forward and
+                            first-backward GEMMs (second-order passes: bf16)   */
+  int32_t reserved;
+} isdf_net_cfg;
+
+int isdf_abi_version(void);
+const char* isdf_error_string(int code);
+
+/* number of fp32 parameters (460033 for the default net) */
+int64_t isdf_param_count(const isdf_net_cfg* net);
+/* bytes of the packed 16-bit MFMA-operand copies of the weights ("shadow") */
+int64_t isdf_shadow_bytes(const isdf_net_cfg* net);
+/* bytes of scratch isdf_train_step / isdf_sdf_eval need for up to max_points */
+int64_t isdf_workspace_bytes(const isdf_net_cfg* net, int64_t max_points, int32_t train);
+/* number of floats in the flat reduction buffer written by isdf_train_step:
+ *   [ grad(n_params) | loss_sums(8) | block_loss(F*64) | block_cnt(F*64) ]    */
+int64_t isdf_reduce_floats(const isdf_net_cfg* net, int32_t n_frames);
+
+/* Rebuild the packed operand copies from the fp32 parameters (after loading a
+ * checkpoint; isdf_adamw does it itself after every update).                  */
+int isdf_pack_weights(const isdf_net_cfg* net, const float* params, void* shadow, void* stream);
+
+/* ---- K1: ray / point sampler ---------------------------------------------
+ * Replaces sample.sample_pixels + get_batch_data + sample_along_rays
+ * (isdf/modules/sample.py:11-178) and transform.origin_dirs_W
+ * (isdf/geometry/transform.py:36-41).  dirs_C is computed from the intrinsics
+ * (transform.py:13-33) instead of gathered from a [H,W,3] table.             */
+typedef struct isdf_sample_args {
+  /* keyframe store (data_util.FrameData, isdf/datasets/data_util.py:11-81)   */
+  const float* depth_batch;   /* [K,H,W]                                       */
+  const float* normal_batch;  /* [K,H,W,3] or NULL (do_normal false)           */
+  const float* T_WC_batch;    /* [K,4,4]                                       */
+  const int32_t* frame_idx;   /* [F] window -> keyframe index (trainer.py:965) */
+  const int32_t* normal_idx;  /* [F] keyframe index used for normals; the
+                                 reference passes the un-windowed normal_batch
+                                 (trainer.py:956,969): pass 0..F-1
+                                 to reproduce, frame_idx to fix                */
+  int32_t n_frames;           /* F                                             */
+  int32_t n_rays;             /* rays per frame (sample.n_rays)                */
+  int32_t H, W;
+  float fx, fy, cx, cy;
+  int32_t n_strat, n_surf;    /* sample.n_strat_samples / n_surf_samples       */
+  float min_depth;            /* sample.depth_range[0]                         */
+  float dist_behind_surf;
+  /* random inputs.  rng_mode 0 ("injected", parity): the caller supplies the
+   * draws the reference would make, in the reference's own shapes:
+   *   draw_h/draw_w [F*n_rays] int64  (torch.randint, sample.py:15-16)
+   *   draw_u [R,n_strat] (torch.rand, sample.py:123), draw_n [R,n_surf-1]
+   *   (torch.normal(0,0.1) on the CPU generator, sample.py:160-162), both
+   *   indexed by COMPACTED ray.  rng_mode 1: in-kernel Philox4x32-10 keyed by
+   *   (seed, offset, ray, slot); not stream-compatible with torch.            */
+  int32_t rng_mode;
+  const int64_t* draw_h;
+  const int64_t* draw_w;
+  const float* draw_u;
+  const float* draw_n;
+  uint64_t seed, offset;
+} isdf_sample_args;
+
+typedef struct isdf_sample_out {
+  int32_t* n_valid;      /* [1]  R = rays kept (depth != 0, normal not NaN)    */
+  int64_t* indices_b;    /* [F*n_rays] first R entries valid (ordered)         */
+  int64_t* indices_h;
+  int64_t* indices_w;
+  float* depth_sample;   /* [F*n_rays]                                         */
+  float* dirs_C_sample;  /* [F*n_rays,3]                                       */
+  float* norm_sample;    /* [F*n_rays,3] or NULL                               */
+  float* T_WC_sample;    /* [F*n_rays,4,4] or NULL (reference materialises it) */
+  float* dirs_W_sample;  /* [F*n_rays,3] world-frame ray direction             */
+  float* z_vals;         /* [F*n_rays,S]                                       */
+  float* pc;             /* [F*n_rays,S,3]                                     */
+} isdf_sample_out;
+
+/* pass 1: pixel draw (or injected), gather, validity, ORDER-PRESERVING compaction */
+int isdf_sample_pixels(const isdf_sample_args* a, const isdf_sample_out* o, void* stream);
+/* pass 2: per compacted ray: stratified + surface z values, world points       */
+int isdf_sample_along_rays(const isdf_sample_args* a, const isdf_sample_out* o, void* stream);
+
+/* ---- fused PE + MLP (+ input gradient) inference --------------------------
+ * Replaces SDFMap.forward and fc_map.gradient (fc_map.py:94-111,12-22) for
+ * arbitrary points.  noise: pre-scaled additive term on the raw output
+ * (fc_map.py:106-108) or NULL.  sdf_grad may be NULL.                          */
+int isdf_sdf_eval(const isdf_net_cfg* net, const float* params, const void* shadow,
+                  const float* pts, int64_t n_points, const float* noise,
+                  float* sdf, float* sdf_grad, void* workspace, int64_t workspace_bytes,
+                  void* stream);
+
+/* ---- training step (everything between sampling and the optimiser) --------
+ * Replaces Trainer.sdf_eval_and_loss + total_loss.backward()
+ * (trainer.py:768-868,981; loss.py:13-240).                                   */
+typedef struct isdf_loss_cfg {
+  int32_t bounds_method;  /* 0 "ray" (loss.py:13-22), 1 "pc" (loss.py:56-89)   */
+  int32_t loss_type;      /* 0 L1, 1 L2 (loss.py:138-143)                      */
+  float trunc_weight, trunc_distance, eik_weight, eik_apply_dist, grad_weight;
+  int32_t orien_loss;
+} isdf_loss_cfg;
+
+typedef struct isdf_step_args {
+  const int32_t* n_valid;     /* [1] device: R (from the sampler)              */
+  int32_t max_rays;           /* capacity of the per-ray arrays (F*n_rays)     */
+  int32_t S;                  /* samples per ray                               */
+  int32_t n_frames, H, W;     /* for the 8x8 block-loss bins (loss.py:208-240) */
+  const float* pc;            /* [max_rays,S,3]                                */
+  const float* z_vals;        /* [max_rays,S]                                  */
+  const float* depth_sample;  /* [max_rays]                                    */
+  const float* dirs_C_sample; /* [max_rays,3]                                  */
+  const float* dirs_W_sample; /* [max_rays,3]                                  */
+  const float* norm_sample;   /* [max_rays,3] (may be NULL when grad_weight=0) */
+  const int64_t* indices_b;   /* [max_rays]                                    */
+  const int64_t* indices_h;
+  const int64_t* indices_w;
+  const float* noise;         /* [max_rays,S] pre-scaled, or NULL              */
+  const float* pc_bounds;     /* [max_rays,S]   bounds_method "pc" only        */
+  const float* pc_grad_vec;   /* [max_rays,S,3] bounds_method "pc" only        */
+} isdf_step_args;
+
+typedef struct isdf_step_out {
+  float* reduce_buf;    /* [isdf_reduce_floats]: SUMS (not means) so that ranks
+                           can be all-reduced and scaled once      */
+  float* sdf;           /* optional [max_rays,S]  debug / parity outputs       */
+  float* sdf_grad;      /* optional [max_rays,S,3]                             */
+  float* tot_loss_mat;  /* optional [max_rays,S]                               */
+} isdf_step_out;
+
+/* layout of loss_sums inside reduce_buf (after the n_params gradient floats) */
+enum { ISDF_LS_SDF = 0, ISDF_LS_GRAD = 1, ISDF_LS_EIK = 2, ISDF_LS_TOTAL = 3, ISDF_LS_COUNT = 4 };
+
+int isdf_train_step(const isdf_net_cfg* net, const isdf_loss_cfg* loss, const float* params,
+                    const void* shadow, const isdf_step_args* a, const isdf_step_out* o,
+                    void* workspace, int64_t workspace_bytes, void* stream);
+
+/* nearest-surface-point bounds (bounds_method "pc", loss.py:56-89) */
+int isdf_bounds_pc(const int32_t* n_valid, int32_t max_rays, int32_t S, const float* pc,
+                   const float* z_vals, const float* depth_sample, float* bounds,
+                   float* grad_vec, void* stream);
+
+/* per-frame 8x8 block-loss averages from the reduced bins (loss.py:208-240):
+ * loss_approx [F,8,8], frame_avg_loss [F]                                      */
+int isdf_frame_avg(const float* reduce_buf, int64_t n_params, int32_t n_frames,
+                   float* loss_approx, float* frame_avg_loss, void* stream);
+
+/* ---- fused flat AdamW + operand-copy refresh -------------------------------
+ * Replaces torch.optim.AdamW.step (trainer.py:435-439,982): decoupled weight
+ * decay on all parameters, bias-corrected moments.  grad_scale multiplies the
+ * summed gradient; count_ptr (device, optional) divides it further by
+ * *count_ptr (the all-reduced number of loss elements).                        */
+int isdf_adamw(const isdf_net_cfg* net, float* params, float* exp_avg, float* exp_avg_sq,
+               const float* grad_sum, const float* count_ptr, float grad_scale,
+               float lr, float beta1, float beta2, float eps, float weight_decay,
+               int32_t step, void* shadow, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ISDF_HIP_H */

@@ -1,0 +1,186 @@
+// extern "C" entry points declared in include/isdf_hip.h: argument validation,
+// layout computation and kernel launches.  No allocation, no synchronisation,
+// no global state.
+#include "isdf_common.h"
+#include "chain_params.h"
+
+using namespace isdf;
+
+namespace isdf {
+int launch_chain(const ChainParams& p, int mode, int64_t nTiles, hipStream_t st);
+int launch_dw(const DwParams& p, hipStream_t st);
+int launch_dw_reduce(const NetLayout& L, const float* dwPart, float* grad, hipStream_t st);
+int launch_sample_pixels(const isdf_sample_args& a, const isdf_sample_out& o, hipStream_t st);
+int launch_sample_along_rays(const isdf_sample_args& a, const isdf_sample_out& o, hipStream_t st);
+int launch_adamw(float* p, float* m, float* v, const float* g, const float* cnt, float gs, float lr, float b1,
+                 float b2, float eps, float wd, int step, int64_t n, hipStream_t st);
+int launch_pack(const NetLayout& L, const float* params, uint16_t* shadow, hipStream_t st);
+int launch_finalize(const float* wg_loss, int64_t maxTiles, const int32_t* n_valid, int64_t nph, int S,
+                    const float* ray_loss, const int64_t* ib, const int64_t* ih, const int64_t* iw, int F, int H,
+                    int W, float* loss_sums, float* bl, float* bc, hipStream_t st);
+int launch_frame_avg(const float* bl, const float* bc, int F, float* la, float* fa, hipStream_t st);
+int launch_bounds_pc(const int32_t* n_valid, int max_rays, int S, const float* pc, const float* z, const float* depth,
+                     float* bounds, float* gv, hipStream_t st);
+}  // namespace isdf
+
+extern "C" {
+
+int isdf_abi_version(void) { return ISDF_ABI_VERSION; }
+
+const char* isdf_error_string(int code) {
+  switch (code) {
+    case ISDF_OK: return "ok";
+    case ISDF_EINVAL: return "invalid argument";
+    case ISDF_EUNSUPPORTED: return "unsupported configuration (kernels are built for hidden=256, n_freqs<=6)";
+    case ISDF_EWORKSPACE: return "workspace too small";
+    case ISDF_EHIP: return "HIP runtime error";
+  }
+  return "unknown error";
+}
+
+int64_t isdf_param_count(const isdf_net_cfg* net) {
+  NetLayout l; int rc = make_layout(net, &l);
+  return rc ? rc : l.n_params;
+}
+
+int64_t isdf_shadow_bytes(const isdf_net_cfg* net) {
+  NetLayout l; int rc = make_layout(net, &l);
+  return rc ? rc : l.shadowElems * 2;
+}
+
+int64_t isdf_workspace_bytes(const isdf_net_cfg* net, int64_t max_points, int32_t train) {
+  NetLayout l; int rc = make_layout(net, &l);
+  if (rc) return rc;
+  if (max_points < 0) return ISDF_EINVAL;
+  WorkspaceLayout w; make_workspace(l, max_points, max_points, train != 0, &w);
+  return w.totalBytes;
+}
+
+int64_t isdf_reduce_floats(const isdf_net_cfg* net, int32_t n_frames) {
+  NetLayout l; int rc = make_layout(net, &l);
+  if (rc) return rc;
+  return l.n_params + 8 + 2 * (int64_t)n_frames * 64;
+}
+
+int isdf_pack_weights(const isdf_net_cfg* net, const float* params, void* shadow, void* stream) {
+  NetLayout l; int rc = make_layout(net, &l);
+  if (rc) return rc;
+  if (!params || !shadow) return ISDF_EINVAL;
+  return launch_pack(l, params, (uint16_t*)shadow, (hipStream_t)stream);
+}
+
+int isdf_sample_pixels(const isdf_sample_args* a, const isdf_sample_out* o, void* stream) {
+  if (!a || !o || !a->depth_batch || !a->T_WC_batch || !a->frame_idx || !o->n_valid || !o->indices_b ||
+      !o->indices_h || !o->indices_w || !o->depth_sample || !o->dirs_C_sample || !o->dirs_W_sample)
+    return ISDF_EINVAL;
+  if (a->normal_batch && !a->normal_idx) return ISDF_EINVAL;
+  if (a->n_frames < 1 || a->n_rays < 1 || a->H < 8 || a->W < 8) return ISDF_EINVAL;
+  if (a->rng_mode == 0 && (!a->draw_h || !a->draw_w)) return ISDF_EINVAL;
+  return launch_sample_pixels(*a, *o, (hipStream_t)stream);
+}
+
+int isdf_sample_along_rays(const isdf_sample_args* a, const isdf_sample_out* o, void* stream) {
+  if (!a || !o || !o->n_valid || !o->z_vals || !o->pc || !o->depth_sample || !o->dirs_W_sample || !o->indices_b)
+    return ISDF_EINVAL;
+  if (a->n_strat < 1 || a->n_surf < 0) return ISDF_EINVAL;
+  if (a->rng_mode == 0 && (!a->draw_u || (a->n_surf > 1 && !a->draw_n))) return ISDF_EINVAL;
+  return launch_sample_along_rays(*a, *o, (hipStream_t)stream);
+}
+
+int isdf_sdf_eval(const isdf_net_cfg* net, const float* params, const void* shadow, const float* pts,
+                  int64_t n_points, const float* noise, float* sdf, float* sdf_grad, void* workspace,
+                  int64_t workspace_bytes, void* stream) {
+  NetLayout l; int rc = make_layout(net, &l);
+  if (rc) return rc;
+  if (!layout_supported(l)) return ISDF_EUNSUPPORTED;
+  if (!params || !shadow || !pts || !sdf || n_points < 0) return ISDF_EINVAL;
+  if (n_points == 0) return ISDF_OK;
+  ChainParams p = {};
+  p.lay = l; p.params = params; p.shadow = (const uint16_t*)shadow; p.pts = pts; p.noise = noise;
+  p.n_points_host = n_points; p.S = 1; p.sdf = sdf; p.sdf_grad = sdf_grad;
+  const int mode = sdf_grad ? 1 : 0;
+  WorkspaceLayout w; make_workspace(l, n_points, 0, false, &w);
+  if (mode == 1) {
+    if (!workspace || workspace_bytes < w.totalBytes) return ISDF_EWORKSPACE;
+    p.spill = (uint16_t*)((char*)workspace + w.offSpill); p.sp = w.sp;
+  }
+  return launch_chain(p, mode, w.nTiles, (hipStream_t)stream);
+}
+
+int isdf_train_step(const isdf_net_cfg* net, const isdf_loss_cfg* loss, const float* params, const void* shadow,
+                    const isdf_step_args* a, const isdf_step_out* o, void* workspace, int64_t workspace_bytes,
+                    void* stream) {
+  NetLayout l; int rc = make_layout(net, &l);
+  if (rc) return rc;
+  if (!layout_supported(l)) return ISDF_EUNSUPPORTED;
+  if (!loss || !params || !shadow || !a || !o || !workspace || !o->reduce_buf) return ISDF_EINVAL;
+  if (!a->pc || !a->z_vals || !a->depth_sample || !a->dirs_C_sample || !a->dirs_W_sample || !a->indices_b ||
+      !a->indices_h || !a->indices_w || !a->n_valid)
+    return ISDF_EINVAL;
+  if (a->max_rays < 1 || a->S < 1 || a->n_frames < 1 || a->H < 8 || a->W < 8) return ISDF_EINVAL;
+  if (loss->bounds_method != 0 && loss->bounds_method != 1) return ISDF_EUNSUPPORTED;  // "normal" is broken upstream (loss.py:29)
+  if (loss->bounds_method == 1 && (!a->pc_bounds || !a->pc_grad_vec)) return ISDF_EINVAL;
+  if (loss->loss_type != 0 && loss->loss_type != 1) return ISDF_EINVAL;
+  if (loss->grad_weight != 0.f && !a->norm_sample) return ISDF_EINVAL;
+  const int64_t maxPts = (int64_t)a->max_rays * a->S;
+  WorkspaceLayout w; make_workspace(l, maxPts, a->max_rays, true, &w);
+  if (workspace_bytes < w.totalBytes) return ISDF_EWORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  char* ws = (char*)workspace;
+  float* rayLoss = (float*)(ws + w.offRayLoss);
+  float* wgLoss = (float*)(ws + w.offWgLoss);
+  float* dwPart = (float*)(ws + w.offDwPart);
+  const int64_t nRed = l.n_params + 8 + 2 * (int64_t)a->n_frames * 64;
+  if (hipMemsetAsync(o->reduce_buf, 0, nRed * 4, st) != hipSuccess) return ISDF_EHIP;
+  if (hipMemsetAsync(rayLoss, 0, (size_t)a->max_rays * 4, st) != hipSuccess) return ISDF_EHIP;
+
+  ChainParams p = {};
+  p.lay = l; p.loss = *loss; p.params = params; p.shadow = (const uint16_t*)shadow;
+  p.pts = a->pc; p.noise = a->noise; p.n_valid = a->n_valid; p.S = a->S;
+  p.z_vals = a->z_vals; p.depth = a->depth_sample; p.dirsC = a->dirs_C_sample; p.dirsW = a->dirs_W_sample;
+  p.normals = a->norm_sample; p.pc_bounds = a->pc_bounds; p.pc_grad_vec = a->pc_grad_vec;
+  p.sdf = o->sdf; p.sdf_grad = o->sdf_grad; p.tot_loss_mat = o->tot_loss_mat;
+  p.ray_loss = rayLoss; p.wg_loss = wgLoss; p.grad = o->reduce_buf;
+  p.spill = (uint16_t*)(ws + w.offSpill); p.sp = w.sp;
+  rc = launch_chain(p, 2, w.nTiles, st);
+  if (rc) return rc;
+
+  DwParams d = {};
+  d.lay = l; d.sp = w.sp; d.spill = p.spill; d.n_valid = a->n_valid; d.S = a->S; d.dwPart = dwPart;
+  rc = launch_dw(d, st);
+  if (rc) return rc;
+  rc = launch_dw_reduce(l, dwPart, o->reduce_buf, st);
+  if (rc) return rc;
+  float* lossSums = o->reduce_buf + l.n_params;
+  float* blockLoss = lossSums + 8;
+  float* blockCnt = blockLoss + (int64_t)a->n_frames * 64;
+  return launch_finalize(wgLoss, w.nTiles, a->n_valid, 0, a->S, rayLoss, a->indices_b, a->indices_h, a->indices_w,
+                         a->n_frames, a->H, a->W, lossSums, blockLoss, blockCnt, st);
+}
+
+int isdf_bounds_pc(const int32_t* n_valid, int32_t max_rays, int32_t S, const float* pc, const float* z_vals,
+                   const float* depth_sample, float* bounds, float* grad_vec, void* stream) {
+  if (!n_valid || !pc || !z_vals || !depth_sample || !bounds || !grad_vec || max_rays < 1 || S < 1) return ISDF_EINVAL;
+  return launch_bounds_pc(n_valid, max_rays, S, pc, z_vals, depth_sample, bounds, grad_vec, (hipStream_t)stream);
+}
+
+int isdf_frame_avg(const float* reduce_buf, int64_t n_params, int32_t n_frames, float* loss_approx,
+                   float* frame_avg_loss, void* stream) {
+  if (!reduce_buf || !loss_approx || !frame_avg_loss || n_frames < 1 || n_params < 0) return ISDF_EINVAL;
+  const float* bl = reduce_buf + n_params + 8;
+  return launch_frame_avg(bl, bl + (int64_t)n_frames * 64, n_frames, loss_approx, frame_avg_loss, (hipStream_t)stream);
+}
+
+int isdf_adamw(const isdf_net_cfg* net, float* params, float* exp_avg, float* exp_avg_sq, const float* grad_sum,
+               const float* count_ptr, float grad_scale, float lr, float beta1, float beta2, float eps,
+               float weight_decay, int32_t step, void* shadow, void* stream) {
+  NetLayout l; int rc = make_layout(net, &l);
+  if (rc) return rc;
+  if (!params || !exp_avg || !exp_avg_sq || !grad_sum || step < 1) return ISDF_EINVAL;
+  rc = launch_adamw(params, exp_avg, exp_avg_sq, grad_sum, count_ptr, grad_scale, lr, beta1, beta2, eps, weight_decay,
+                    step, l.n_params, (hipStream_t)stream);
+  if (rc || !shadow) return rc;
+  return launch_pack(l, params, (uint16_t*)shadow, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,36 @@
+// Kernel-argument structs shared by the launchers (capi.hip) and the kernels.
+#pragma once
+#include "isdf_common.h"
+
+namespace isdf {
+
+struct ChainParams {
+  NetLayout lay;
+  isdf_loss_cfg loss;
+  const float* params;
+  const uint16_t* shadow;
+  const float* pts;           // [P,3]
+  const float* noise;         // [P] or null
+  const int32_t* n_valid;     // device: rays (points = n_valid*S); null -> n_points_host
+  int64_t n_points_host;
+  int32_t S;
+  // per-ray inputs (train)
+  const float* z_vals; const float* depth; const float* dirsC; const float* dirsW; const float* normals;
+  const float* pc_bounds; const float* pc_grad_vec;
+  // outputs
+  float* sdf; float* sdf_grad; float* tot_loss_mat;
+  float* ray_loss;            // [maxRays] atomically accumulated
+  float* wg_loss;             // [nTiles][8]
+  float* grad;                // flat fp32 gradient SUMS (bias / out-layer parts use atomics)
+  uint16_t* spill; SpillLayout sp;
+};
+
+struct DwParams {
+  NetLayout lay;
+  SpillLayout sp;
+  const uint16_t* spill;
+  const int32_t* n_valid; int64_t n_points_host; int32_t S;
+  float* dwPart;   // [units][DW_SPLITK][HD*HD]
+};
+
+}  // namespace isdf

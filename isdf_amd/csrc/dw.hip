@@ -1,0 +1,185 @@
+// Weight-gradient kernel (K3): for every hidden layer
+//   dW_l[o][i] = sum_pts  zbar_l[pt][o] * I_l[pt][i]  +  p_l[pt][o] * Gb_l[pt][i]
+// i.e. the two outer-product sums autograd accumulates in total_loss.backward()
+// (isdf/modules/trainer.py:981): the ordinary reverse sweep and the reverse of
+// the input-gradient graph.  Operands are the bf16 tiles chain.hip spilled.
+//
+// Mapping: one workgroup = one 256x256 dW "unit" (a layer; the cat layer is two
+// units) x one K-split over point tiles.  8 waves as 4(o) x 2(i), each wave a
+// 64x128 fp32 accumulator (128 VGPRs).  The contraction index is the POINT, but
+// the spilled tiles are [point][feature], so both MFMA operands are fetched
+// with ds_read_b64_tr_b16 (LDS transpose read, gfx950) from row-major LDS
+// tiles; rows are padded by 64 B so the 4-row x 32-B footprints of the two
+// 16-lane groups of a half-wave fall in disjoint bank windows.  Global loads of
+// the next stage are issued into registers before the MFMAs of the current one
+// and written to LDS after the barrier (issue-early / write-late).
+#include "isdf_common.h"
+#include "chain_params.h"
+
+namespace isdf {
+
+template <int HD> struct DwTile {
+  static constexpr int BM = TILE_PTS;
+  static constexpr int ROWB = HD * 2 + 64;        // padded LDS row (bytes)
+  static constexpr int TEN = BM * ROWB;           // one operand tile in LDS
+  static constexpr int LDS_BYTES = 2 * TEN;
+  static constexpr int CH = (BM * HD * 2) / (512 * 16);  // uint4 per thread per tensor
+};
+
+// frag16 chunk c (16 B = 8 elems) of a [BM][HD] tile -> (pt, f0): elems 0..3 at
+// features f0.., elems 4..7 at f0+8..   (inverse of chain.hip frag16_off)
+template <int HD> __device__ __forceinline__ void frag16_decode(int c, int& pt, int& f0) {
+  constexpr int FB = HD / 128, PB = TILE_PTS / 32;
+  const int lane = c & 63; int r = c >> 6;
+  const int qp = r & 1; r >>= 1;
+  const int pb = r % PB; r /= PB;
+  const int fb = r % FB; const int w = r / FB;
+  pt = pb * 32 + (lane & 31);
+  f0 = w * (FB * 32) + fb * 32 + 16 * qp + 4 * (lane >> 5);
+}
+
+template <int HD>
+__global__ __launch_bounds__(512, 2) void dw_kernel(const DwParams p) {
+  typedef DwTile<HD> T;
+  constexpr int BM = T::BM, ROWB = T::ROWB, CH = T::CH;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const NetLayout& L = p.lay;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int wo = w >> 1, wi = w & 1;
+  const int unit = blockIdx.x / DW_SPLITK, split = blockIdx.x % DW_SPLITK;
+  const int li = unit < L.L ? unit : L.cat;
+  const bool embHalf = unit == L.L;
+
+  const int64_t P = p.n_valid ? (int64_t)(*p.n_valid) * p.S : p.n_points_host;
+  const int nTiles = (int)((P + BM - 1) / BM);
+
+  // stage q of tile t: q=0 -> (ZB[li], I), q=1 -> (P[li], GB)
+  const int64_t offZ = p.sp.ZB[li], offP = p.sp.P[li];
+  const int64_t offI = embHalf ? p.sp.A[0] : p.sp.A[li];
+  const int64_t offG = embHalf ? p.sp.GB[0] : p.sp.GB[li];
+
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  const int nStages = split < nTiles ? 2 * ((nTiles - split + DW_SPLITK - 1) / DW_SPLITK) : 0;
+  uint4 regA[CH], regB[CH];
+  auto issue = [&](int st) {
+    const int t = split + (st >> 1) * DW_SPLITK;
+    const uint16_t* ta = p.spill + ((st & 1) ? offP : offZ) + (int64_t)t * BM * HD;
+    const uint16_t* tb = p.spill + ((st & 1) ? offG : offI) + (int64_t)t * BM * HD;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      regA[c] = *(const uint4*)(ta + (int64_t)(c * 512 + tid) * 8);
+      regB[c] = *(const uint4*)(tb + (int64_t)(c * 512 + tid) * 8);
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      int pt, f0;
+      frag16_decode<HD>(c * 512 + tid, pt, f0);
+      char* ra = smem + pt * ROWB + f0 * 2;
+      *(uint2*)(ra) = make_uint2(regA[c].x, regA[c].y);
+      *(uint2*)(ra + 16) = make_uint2(regA[c].z, regA[c].w);
+      char* rb = smem + T::TEN + pt * ROWB + f0 * 2;
+      *(uint2*)(rb) = make_uint2(regB[c].x, regB[c].y);
+      *(uint2*)(rb + 16) = make_uint2(regB[c].z, regB[c].w);
+    }
+  };
+
+  if (nStages > 0) { issue(0); commit(); }
+  __syncthreads();
+
+  // per-lane transpose-read addressing: in each 16-lane group source lane s
+  // supplies row (s>>2), 4-element column chunk (s&3); destination lane i gets
+  // column i of the 4x16 block (measured on gfx950: tools/probes/probe_layouts.hip)
+  const int s16 = lane & 15, cg = (lane >> 4) & 1, hi = lane >> 5;
+  const int trRow = 8 * hi + (s16 >> 2);
+  const int trColB = (16 * cg + 4 * (s16 & 3)) * 2;
+  typedef bf16x4 __attribute__((address_space(3))) * lds4;
+  auto trload = [&](const char* base, int ptBase, int colElem) -> bf16x8 {
+    const char* a0 = base + (ptBase + trRow) * ROWB + colElem * 2 + trColB;
+    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4)(a0));
+    bf16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4)(a0 + 4 * ROWB));
+    bf16x8 r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+    r[4] = hi4[0]; r[5] = hi4[1]; r[6] = hi4[2]; r[7] = hi4[3];
+    return r;
+  };
+
+  for (int st = 0; st < nStages; ++st) {
+    if (st + 1 < nStages) issue(st + 1);
+#pragma unroll
+    for (int ks = 0; ks < BM / 16; ++ks) {
+      bf16x8 a[2], b[4];
+#pragma unroll
+      for (int ob = 0; ob < 2; ++ob) a[ob] = trload(smem, ks * 16, wo * 64 + ob * 32);
+#pragma unroll
+      for (int ib = 0; ib < 4; ++ib) b[ib] = trload(smem + T::TEN, ks * 16, wi * 128 + ib * 32);
+#pragma unroll
+      for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+        for (int ib = 0; ib < 4; ++ib)
+          acc[ob][ib] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ob], b[ib], acc[ob][ib], 0, 0, 0);
+    }
+    __syncthreads();
+    if (st + 1 < nStages) commit();
+    __syncthreads();
+  }
+
+  // partial slab [o][i]
+  float* slab = p.dwPart + ((int64_t)unit * DW_SPLITK + split) * HD * HD;
+#pragma unroll
+  for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+    for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int o = wo * 64 + ob * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        const int i = wi * 128 + ib * 32 + (lane & 31);
+        slab[o * HD + i] = acc[ob][ib][r];
+      }
+}
+
+// Sum the K-split slabs into the flat gradient (weights only; biases and the
+// output layer were accumulated by chain.hip with atomics).
+__global__ void dw_reduce_kernel(NetLayout L, const float* __restrict__ dwPart, float* __restrict__ grad) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int HD = L.HD;
+  const int64_t perUnit = (int64_t)HD * HD;
+  const int unit = (int)(idx / perUnit);
+  if (unit > L.L) return;
+  const int rem = (int)(idx - unit * perUnit);
+  const int o = rem / HD, i = rem - o * HD;
+  const int li = unit < L.L ? unit : L.cat;
+  const bool embHalf = unit == L.L;
+  const int width = (li == 0 || embHalf) ? L.E : HD;
+  if (i >= width) return;
+  float s = 0.f;
+  const float* src = dwPart + (int64_t)unit * DW_SPLITK * perUnit + rem;
+#pragma unroll 4
+  for (int k = 0; k < DW_SPLITK; ++k) s += src[(int64_t)k * perUnit];
+  grad[L.offW[li] + (int64_t)o * L.K[li] + (embHalf ? HD : 0) + i] = s;
+}
+
+int launch_dw(const DwParams& p, hipStream_t st) {
+  if (!layout_supported(p.lay)) return ISDF_EUNSUPPORTED;
+  typedef DwTile<256> T;
+  auto k = dw_kernel<256>;
+  if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES) != hipSuccess) return ISDF_EHIP;
+  hipLaunchKernelGGL(k, dim3(dw_units(p.lay) * DW_SPLITK), dim3(512), T::LDS_BYTES, st, p);
+  return hipGetLastError() == hipSuccess ? ISDF_OK : ISDF_EHIP;
+}
+
+int launch_dw_reduce(const NetLayout& L, const float* dwPart, float* grad, hipStream_t st) {
+  const int64_t total = (int64_t)dw_units(L) * L.HD * L.HD;
+  hipLaunchKernelGGL(dw_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, L, dwPart, grad);
+  return hipGetLastError() == hipSuccess ? ISDF_OK : ISDF_EHIP;
+}
+
+}  // namespace isdf

@@ -1,0 +1,171 @@
+// Internal layout definitions shared by the host entry points and the kernels.
+// (Nothing here is part of the C ABI -- that is include/isdf_hip.h.)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/isdf_hip.h"
+
+namespace isdf {
+
+constexpr int MAXL = 16;       // max hidden layers (2B+2)
+constexpr int N_DIRS = 21;     // icosahedron directions, embedding.py:40-62
+constexpr int TILE_PTS = 64;   // points per chain-kernel workgroup (BM)
+constexpr int DW_SPLITK = 36;  // K-splits per dW unit (7 units x 36 = 252 workgroups)
+
+// Vector types for the 16-bit MFMA operands.
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+// Parameter / packed-weight / workspace layout, computed on the host by
+// make_layout() and passed to kernels by value.
+struct NetLayout {
+  int HD, EP, E, B, L, cat, n_freqs;
+  int fwd_f16;                 // 1: fp16 operands in forward/first-backward GEMMs
+  int has_transform;
+  float scale_input, scale_output;
+  float T[12];
+  int64_t n_params;
+  int32_t offW[MAXL], offB[MAXL], K[MAXL];  // fp32 flat offsets; K = fan-in (unpadded)
+  int32_t offWout, offBout;
+  // packed 16-bit matrices: offsets (elements) inside one "fwd set" / "bwd set"
+  int64_t fwdMat[MAXL];        // [HD x Kpad(li)]  = W_li          (A operand, M = out feature)
+  int64_t bwdMat[MAXL];        // [HD x HD]        = W_li^T[:HD]   (li >= 1)
+  int64_t bwdG;                // [EP x 2HD]       = [W_in^T | W_cat[:, HD:]^T]
+  int64_t fwdSetElems, bwdSetElems;
+  // the four sets inside the shadow buffer (element offsets)
+  int64_t setFwdA, setFwdB, setBwdA, setBwdB;  // A: fwd_operand type, B: bf16
+  int64_t shadowElems;
+};
+
+// Spill tensors written by the chain kernel and read by the dW kernel.  One
+// tensor = nTiles * TILE_PTS * HD 16-bit elements in "frag16" order (see
+// chain.hip): bf16 always.
+struct SpillLayout {
+  int64_t tensorElems;   // per tensor
+  int64_t A[MAXL + 1];   // A[0] = embedding, A[li+1] = activation after layer li
+  int64_t P[MAXL];       // d sdf / d z_li
+  int64_t GB[MAXL];      // GB[0] = Ebar, GB[li] = adjoint entering layer li (li >= 1)
+  int64_t INJ[MAXL];     // injected second-order term of layer li
+  int64_t ZB[MAXL];      // d loss / d z_li
+  int64_t totalElems;
+};
+
+struct WorkspaceLayout {
+  int64_t nTiles;
+  SpillLayout sp;
+  int64_t offSpill;      // bytes
+  int64_t offRayLoss;    // float [maxRays]
+  int64_t offWgLoss;     // float [nTiles][8]
+  int64_t offDwPart;     // float [units][DW_SPLITK][HD*HD]
+  int64_t offGxs;        // float [maxPts*3] scratch (inference: unused)
+  int64_t totalBytes;
+};
+
+inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+inline int make_layout(const isdf_net_cfg* c, NetLayout* l) {
+  if (!c || !l) return ISDF_EINVAL;
+  if (c->blocks < 1 || 2 * c->blocks + 2 > MAXL || c->n_freqs < 1 || c->hidden < 1) return ISDF_EINVAL;
+  l->HD = c->hidden; l->B = c->blocks; l->n_freqs = c->n_freqs;
+  l->E = 2 * N_DIRS * c->n_freqs + 3;
+  l->EP = round_up(l->E, 128);
+  l->L = 2 * c->blocks + 2; l->cat = c->blocks + 1;
+  l->fwd_f16 = c->fwd_operand ? 1 : 0;
+  l->has_transform = c->has_transform;
+  l->scale_input = c->scale_input; l->scale_output = c->scale_output;
+  for (int i = 0; i < 12; ++i) l->T[i] = c->has_transform ? c->bounds_T[i] : (i % 5 == 0 ? 1.f : 0.f);
+  int64_t off = 0;
+  for (int li = 0; li < l->L; ++li) {
+    int K = li == 0 ? l->E : (li == l->cat ? l->HD + l->E : l->HD);
+    l->K[li] = K;
+    l->offW[li] = (int32_t)off; off += (int64_t)l->HD * K;
+    l->offB[li] = (int32_t)off; off += l->HD;
+  }
+  l->offWout = (int32_t)off; off += l->HD;
+  l->offBout = (int32_t)off; off += 1;
+  l->n_params = off;
+  int64_t f = 0, b = 0;
+  for (int li = 0; li < l->L; ++li) {
+    int Kp = li == 0 ? l->EP : (li == l->cat ? l->HD + l->EP : l->HD);
+    l->fwdMat[li] = f; f += (int64_t)l->HD * Kp;
+    l->bwdMat[li] = b; if (li >= 1) b += (int64_t)l->HD * l->HD;
+  }
+  l->bwdG = b; b += (int64_t)l->EP * 2 * l->HD;
+  l->fwdSetElems = f; l->bwdSetElems = b;
+  l->setFwdA = 0; l->setFwdB = f; l->setBwdA = 2 * f; l->setBwdB = 2 * f + b;
+  l->shadowElems = 2 * f + 2 * b;
+  return ISDF_OK;
+}
+
+// The tile kernels are built for these shapes (the reference default net:
+// replicaCAD.json:57-58,65 -> Hd 256, E 255).  Other shapes: ISDF_EUNSUPPORTED.
+inline bool layout_supported(const NetLayout& l) { return l.HD == 256 && l.EP == 256; }
+
+inline int dw_units(const NetLayout& l) { return l.L + 1; }  // one per layer + cat's embedding half
+
+inline void make_workspace(const NetLayout& l, int64_t maxPts, int64_t maxRays, bool train, WorkspaceLayout* w) {
+  w->nTiles = (maxPts + TILE_PTS - 1) / TILE_PTS;
+  SpillLayout& s = w->sp;
+  s.tensorElems = w->nTiles * TILE_PTS * (int64_t)l.HD;
+  int64_t o = 0;
+  for (int i = 0; i <= l.L; ++i) { s.A[i] = o; o += s.tensorElems; }
+  if (train) {
+    for (int i = 0; i < l.L; ++i) { s.P[i] = o; o += s.tensorElems; }
+    for (int i = 0; i < l.L; ++i) { s.GB[i] = o; o += s.tensorElems; }
+    for (int i = 0; i < l.L; ++i) { s.INJ[i] = o; o += s.tensorElems; }
+    for (int i = 0; i < l.L; ++i) { s.ZB[i] = o; o += s.tensorElems; }
+  }
+  s.totalElems = o;
+  int64_t b = 0;
+  w->offSpill = b; b += o * 2; b = (b + 255) / 256 * 256;
+  w->offRayLoss = b; b += (train ? maxRays : 0) * 4; b = (b + 255) / 256 * 256;
+  w->offWgLoss = b; b += (train ? w->nTiles * 8 : 0) * 4; b = (b + 255) / 256 * 256;
+  w->offDwPart = b; b += train ? (int64_t)dw_units(l) * DW_SPLITK * l.HD * l.HD * 4 : 0; b = (b + 255) / 256 * 256;
+  w->offGxs = b;
+  w->totalBytes = b + 256;
+}
+
+// ---- device helpers ---------------------------------------------------------
+#if defined(__HIPCC__)
+
+static __constant__ float kDirs[3][N_DIRS] = {
+    {0.8506508f, 0.809017f, 0.5257311f, 1.f, 0.809017f, 0.8506508f, 0.309017f, 0.f, 0.5f, 0.f, -0.5257311f,
+     -0.309017f, 0.f, -0.309017f, 0.309017f, 0.5f, 0.5f, 0.f, -0.5f, -0.809017f, -0.809017f},
+    {0.f, 0.5f, 0.8506508f, 0.f, 0.5f, 0.f, 0.809017f, 0.5257311f, 0.309017f, 1.f, 0.8506508f, 0.809017f,
+     0.5257311f, 0.809017f, 0.809017f, 0.309017f, -0.309017f, 0.f, 0.309017f, 0.5f, 0.5f},
+    {0.5257311f, 0.309017f, 0.f, 0.f, -0.309017f, -0.5257311f, -0.5f, -0.8506508f, -0.809017f, 0.f, 0.f,
+     -0.5f, 0.8506508f, 0.5f, 0.5f, 0.809017f, 0.809017f, 1.f, 0.809017f, 0.309017f, -0.309017f}};
+
+template <bool F16> struct Op;
+template <> struct Op<true> {
+  typedef f16x8 v8; typedef f16x4 v4; typedef _Float16 e;
+  static __device__ __forceinline__ f32x16 mfma(v8 a, v8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ float clampf(float x) { return fminf(fmaxf(x, -65504.f), 65504.f); }
+};
+template <> struct Op<false> {
+  typedef bf16x8 v8; typedef bf16x4 v4; typedef __bf16 e;
+  static __device__ __forceinline__ f32x16 mfma(v8 a, v8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ float clampf(float x) { return x; }
+};
+
+template <bool F16> __device__ __forceinline__ uint2 pack4(float a, float b, float c, float d) {
+  typename Op<F16>::v4 v;
+  v[0] = (typename Op<F16>::e)Op<F16>::clampf(a); v[1] = (typename Op<F16>::e)Op<F16>::clampf(b);
+  v[2] = (typename Op<F16>::e)Op<F16>::clampf(c); v[3] = (typename Op<F16>::e)Op<F16>::clampf(d);
+  return __builtin_bit_cast(uint2, v);
+}
+__device__ __forceinline__ void unpack4_bf16(uint2 u, float (&o)[4]) {
+  o[0] = __uint_as_float(u.x << 16); o[1] = __uint_as_float(u.x & 0xffff0000u);
+  o[2] = __uint_as_float(u.y << 16); o[3] = __uint_as_float(u.y & 0xffff0000u);
+}
+
+#endif  // __HIPCC__
+}  // namespace isdf

@@ -1,0 +1,319 @@
+"""Tensor-level host API over the C ABI (include/isdf_hip.h).
+
+`Engine` owns the torch-allocated device buffers the kernels borrow -- one flat
+fp32 parameter buffer (+ AdamW moments), the packed 16-bit MFMA-operand copies,
+the step workspace and the flat reduction buffer -- and exposes the four
+kernel groups: sampler, fused inference, training step, AdamW.  torch is used
+for memory and streams only; every numeric operation on the hot path runs in
+the HIP kernels.
+"""
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import _ffi
+
+N_DIRS = 21
+
+
+@dataclass
+class NetConfig:
+    """SDFMap + PostionalEncoding hyper-parameters (replicaCAD.json `model`)."""
+    hidden: int = 256            # model.hidden_feature_size
+    blocks: int = 2              # model.hidden_layers_block
+    n_freqs: int = 6             # model.embedding.n_embed_funcs + 1 (embedding.py:36)
+    scale_input: float = 0.05937489
+    scale_output: float = 0.14
+    transform: Optional[np.ndarray] = None   # 4x4 inv_bounds_transform or None
+    fwd_operand: str = "fp16"    # MFMA operand type of forward/first-backward GEMMs
+
+    @property
+    def emb(self):
+        return 2 * N_DIRS * self.n_freqs + 3
+
+    def layer_names(self):
+        B = self.blocks
+        return (["in_layer.0"] + ["mid1.%d.0" % i for i in range(B)] + ["cat_layer.0"]
+                + ["mid2.%d.0" % i for i in range(B)])
+
+    def param_shapes(self):
+        """[(state_dict key, shape)] in the reference's named_parameters() order."""
+        H, E, B = self.hidden, self.emb, self.blocks
+        fan_in = [E] + [H] * B + [H + E] + [H] * B
+        out = []
+        for n, k in zip(self.layer_names(), fan_in):
+            out += [(n + ".weight", (H, k)), (n + ".bias", (H,))]
+        out += [("out_alpha.weight", (1, H)), ("out_alpha.bias", (1,))]
+        return out
+
+    def to_c(self):
+        c = _ffi.NetCfg()
+        c.hidden, c.blocks, c.n_freqs = self.hidden, self.blocks, self.n_freqs
+        c.has_transform = 0 if self.transform is None else 1
+        c.scale_input, c.scale_output = self.scale_input, self.scale_output
+        T = np.eye(4, dtype=np.float32) if self.transform is None else np.asarray(self.transform, np.float32)
+        for i in range(12):
+            c.bounds_T[i] = float(T[i // 4, i % 4])
+        if self.fwd_operand not in ("fp16", "bf16"):
+            raise ValueError("fwd_operand must be 'fp16' or 'bf16'")
+        c.fwd_operand = 1 if self.fwd_operand == "fp16" else 0
+        return c
+
+
+@dataclass
+class LossConfig:
+    """replicaCAD.json `loss` block (trainer.py:301-318)."""
+    bounds_method: str = "ray"
+    loss_type: str = "L1"
+    trunc_weight: float = 5.38344020
+    trunc_distance: float = 0.29365022
+    eik_weight: float = 0.268
+    eik_apply_dist: float = 0.1
+    grad_weight: float = 0.018
+    orien_loss: bool = False
+
+    def to_c(self):
+        if self.bounds_method not in ("ray", "pc"):
+            # "normal" cannot run in the reference either (loss.py:29 calls bounds_ray with 3 of 5 args)
+            raise ValueError("bounds_method must be 'ray' or 'pc'")
+        if self.loss_type not in ("L1", "L2"):
+            raise ValueError("Must be L1 or L2")
+        c = _ffi.LossCfg()
+        c.bounds_method = 0 if self.bounds_method == "ray" else 1
+        c.loss_type = 0 if self.loss_type == "L1" else 1
+        c.trunc_weight, c.trunc_distance = self.trunc_weight, self.trunc_distance
+        c.eik_weight, c.eik_apply_dist = self.eik_weight, self.eik_apply_dist
+        c.grad_weight, c.orien_loss = self.grad_weight, int(self.orien_loss)
+        return c
+
+
+@dataclass
+class SampleConfig:
+    """replicaCAD.json `sample` block + camera."""
+    n_rays: int = 200
+    n_strat: int = 19
+    n_surf: int = 8
+    min_depth: float = 0.07
+    dist_behind_surf: float = 0.1
+    H: int = 680
+    W: int = 1200
+    fx: float = 600.0
+    fy: float = 600.0
+    cx: float = 599.5
+    cy: float = 339.5
+
+    @property
+    def S(self):
+        return self.n_strat + self.n_surf
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class Engine:
+    def __init__(self, net: NetConfig, device="cuda"):
+        self.lib = _ffi.lib()
+        self.net = net
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _ffi.IsdfError("isdf_amd kernels need a HIP device (got %s); there is no CPU path" % device)
+        self.cnet = net.to_c()
+        n = self.lib.isdf_param_count(C.byref(self.cnet))
+        _ffi.check(min(n, 0), "isdf_param_count")
+        self.n_params = int(n)
+        self.params = torch.zeros(self.n_params, dtype=torch.float32, device=self.device)
+        self.exp_avg = torch.zeros_like(self.params)
+        self.exp_avg_sq = torch.zeros_like(self.params)
+        sb = self.lib.isdf_shadow_bytes(C.byref(self.cnet))
+        self.shadow = torch.zeros(int(sb), dtype=torch.uint8, device=self.device)
+        self._ws = None
+        self._ws_key = None
+        self.reduce_buf = None
+        self.opt_step = 0
+        self.slices = {}
+        off = 0
+        for k, shp in net.param_shapes():
+            cnt = int(np.prod(shp))
+            self.slices[k] = (off, shp)
+            off += cnt
+        assert off == self.n_params
+
+    # ---- parameters ---------------------------------------------------------
+    def param_view(self, key):
+        off, shp = self.slices[key]
+        return self.params[off:off + int(np.prod(shp))].view(*shp)
+
+    def load_params(self, state):
+        """state: dict key -> array/tensor (reference state_dict layout)."""
+        for k, (off, shp) in self.slices.items():
+            v = torch.as_tensor(np.asarray(state[k].detach().cpu() if torch.is_tensor(state[k]) else state[k]),
+                                dtype=torch.float32).reshape(-1)
+            self.params[off:off + v.numel()].copy_(v)
+        self.pack()
+
+    def pack(self):
+        _ffi.check(self.lib.isdf_pack_weights(C.byref(self.cnet), _ffi.ptr(self.params),
+                                              _ffi.ptr(self.shadow), _stream()), "isdf_pack_weights")
+
+    def workspace(self, max_points, train):
+        key = (int(max_points), bool(train))
+        if self._ws is None or self._ws_key[0] < key[0] or (key[1] and not self._ws_key[1]):
+            nb = self.lib.isdf_workspace_bytes(C.byref(self.cnet), int(max_points), int(train))
+            _ffi.check(min(nb, 0), "isdf_workspace_bytes")
+            self._ws = torch.empty(int(nb), dtype=torch.uint8, device=self.device)
+            self._ws_key = key
+        return self._ws
+
+    # ---- K1 sampler ---------------------------------------------------------
+    def sample(self, depth_batch, T_WC_batch, normal_batch, frame_idx, normal_idx, sc: SampleConfig,
+               draws=None, seed=0, offset=0, want_T=False):
+        """Pass 1 + pass 2 of the sampler.  draws: dict(indices_h, indices_w, U, N_off)
+        of device tensors in the reference's shapes (parity mode) or None (Philox)."""
+        dev = self.device
+        F = int(frame_idx.numel())
+        R0 = F * sc.n_rays
+        S = sc.S
+        a = _ffi.SampleArgs()
+        a.depth_batch, a.T_WC_batch = depth_batch.data_ptr(), T_WC_batch.data_ptr()
+        a.normal_batch = None if normal_batch is None else normal_batch.data_ptr()
+        a.frame_idx = frame_idx.data_ptr()
+        a.normal_idx = None if normal_idx is None else normal_idx.data_ptr()
+        a.n_frames, a.n_rays, a.H, a.W = F, sc.n_rays, sc.H, sc.W
+        a.fx, a.fy, a.cx, a.cy = sc.fx, sc.fy, sc.cx, sc.cy
+        a.n_strat, a.n_surf = sc.n_strat, sc.n_surf
+        a.min_depth, a.dist_behind_surf = sc.min_depth, sc.dist_behind_surf
+        keep = []
+        if draws is not None:
+            a.rng_mode = 0
+            for name, key, dt in (("draw_h", "indices_h", torch.int64), ("draw_w", "indices_w", torch.int64),
+                                  ("draw_u", "U", torch.float32), ("draw_n", "N_off", torch.float32)):
+                t = draws.get(key)
+                if t is not None:
+                    t = t.to(device=dev, dtype=dt).contiguous()
+                    keep.append(t)
+                    setattr(a, name, t.data_ptr())
+        else:
+            a.rng_mode = 1
+            a.seed, a.offset = int(seed), int(offset)
+        out = dict(
+            n_valid=torch.zeros(1, dtype=torch.int32, device=dev),
+            indices_b=torch.empty(R0, dtype=torch.int64, device=dev),
+            indices_h=torch.empty(R0, dtype=torch.int64, device=dev),
+            indices_w=torch.empty(R0, dtype=torch.int64, device=dev),
+            depth_sample=torch.empty(R0, dtype=torch.float32, device=dev),
+            dirs_C_sample=torch.empty(R0, 3, dtype=torch.float32, device=dev),
+            norm_sample=None if normal_batch is None else torch.empty(R0, 3, dtype=torch.float32, device=dev),
+            T_WC_sample=torch.empty(R0, 4, 4, dtype=torch.float32, device=dev) if want_T else None,
+            dirs_W_sample=torch.empty(R0, 3, dtype=torch.float32, device=dev),
+            z_vals=torch.empty(R0, S, dtype=torch.float32, device=dev),
+            pc=torch.empty(R0, S, 3, dtype=torch.float32, device=dev),
+        )
+        o = _ffi.SampleOut()
+        for k, v in out.items():
+            setattr(o, k, None if v is None else v.data_ptr())
+        _ffi.check(self.lib.isdf_sample_pixels(C.byref(a), C.byref(o), _stream()), "isdf_sample_pixels")
+        _ffi.check(self.lib.isdf_sample_along_rays(C.byref(a), C.byref(o), _stream()), "isdf_sample_along_rays")
+        out["max_rays"] = R0
+        out["S"] = S
+        out["n_frames"] = F
+        out["_keep"] = keep
+        return out
+
+    # ---- fused inference ------------------------------------------------------
+    def sdf_eval(self, pts, noise=None, want_grad=False):
+        """pts [..., 3] -> sdf [...] (and sdf_grad [..., 3]); SDFMap.forward /
+        fc_map.gradient (fc_map.py:94-111, 12-22)."""
+        shp = pts.shape[:-1]
+        x = pts.reshape(-1, 3).to(device=self.device, dtype=torch.float32).contiguous()
+        n = x.shape[0]
+        sdf = torch.empty(n, dtype=torch.float32, device=self.device)
+        grad = torch.empty(n, 3, dtype=torch.float32, device=self.device) if want_grad else None
+        ws = self.workspace(n, False) if want_grad else None
+        nz = None if noise is None else noise.reshape(-1).to(device=self.device, dtype=torch.float32).contiguous()
+        _ffi.check(self.lib.isdf_sdf_eval(C.byref(self.cnet), _ffi.ptr(self.params), _ffi.ptr(self.shadow),
+                                          _ffi.ptr(x), n, _ffi.ptr(nz), _ffi.ptr(sdf), _ffi.ptr(grad),
+                                          _ffi.ptr(ws), 0 if ws is None else ws.numel(), _stream()),
+                   "isdf_sdf_eval")
+        if want_grad:
+            return sdf.view(*shp), grad.view(*shp, 3)
+        return sdf.view(*shp)
+
+    # ---- training step ----------------------------------------------------------
+    def train_step(self, smp, lc: LossConfig, sc: SampleConfig, noise=None, debug=False):
+        """Everything between sampling and the optimiser.  Fills self.reduce_buf with
+        [grad sums | loss sums(8) | block_loss | block_cnt]; returns debug tensors."""
+        dev = self.device
+        F, R0, S = smp["n_frames"], smp["max_rays"], smp["S"]
+        nred = int(self.lib.isdf_reduce_floats(C.byref(self.cnet), F))
+        if self.reduce_buf is None or self.reduce_buf.numel() != nred:
+            self.reduce_buf = torch.zeros(nred, dtype=torch.float32, device=dev)
+        ws = self.workspace(R0 * S, True)
+        closs = lc.to_c()
+        a = _ffi.StepArgs()
+        a.n_valid = smp["n_valid"].data_ptr()
+        a.max_rays, a.S, a.n_frames, a.H, a.W = R0, S, F, sc.H, sc.W
+        for k in ("pc", "z_vals", "depth_sample", "dirs_C_sample", "dirs_W_sample", "indices_b",
+                  "indices_h", "indices_w"):
+            setattr(a, k, smp[k].data_ptr())
+        a.norm_sample = None if smp.get("norm_sample") is None else smp["norm_sample"].data_ptr()
+        keep = []
+        if noise is not None:
+            nz = torch.zeros(R0 * S, dtype=torch.float32, device=dev)
+            nn_ = noise.reshape(-1).to(device=dev, dtype=torch.float32)
+            nz[:nn_.numel()] = nn_
+            keep.append(nz)
+            a.noise = nz.data_ptr()
+        if lc.bounds_method == "pc":
+            pb = torch.empty(R0 * S, dtype=torch.float32, device=dev)
+            pg = torch.empty(R0 * S, 3, dtype=torch.float32, device=dev)
+            _ffi.check(self.lib.isdf_bounds_pc(_ffi.ptr(smp["n_valid"]), R0, S, _ffi.ptr(smp["pc"]),
+                                               _ffi.ptr(smp["z_vals"]), _ffi.ptr(smp["depth_sample"]),
+                                               _ffi.ptr(pb), _ffi.ptr(pg), _stream()), "isdf_bounds_pc")
+            a.pc_bounds, a.pc_grad_vec = pb.data_ptr(), pg.data_ptr()
+            keep += [pb, pg]
+        o = _ffi.StepOut()
+        o.reduce_buf = self.reduce_buf.data_ptr()
+        dbg = {}
+        if debug:
+            dbg = dict(sdf=torch.zeros(R0, S, device=dev), sdf_grad=torch.zeros(R0, S, 3, device=dev),
+                       tot_loss_mat=torch.zeros(R0, S, device=dev))
+            o.sdf, o.sdf_grad, o.tot_loss_mat = (dbg["sdf"].data_ptr(), dbg["sdf_grad"].data_ptr(),
+                                                 dbg["tot_loss_mat"].data_ptr())
+            if lc.bounds_method == "pc":
+                dbg["pc_bounds"], dbg["pc_grad_vec"] = keep[-2].view(R0, S), keep[-1].view(R0, S, 3)
+        _ffi.check(self.lib.isdf_train_step(C.byref(self.cnet), C.byref(closs), _ffi.ptr(self.params),
+                                            _ffi.ptr(self.shadow), C.byref(a), C.byref(o), _ffi.ptr(ws),
+                                            ws.numel(), _stream()), "isdf_train_step")
+        dbg["_keep"] = keep
+        return dbg
+
+    def grad_view(self, key):
+        off, shp = self.slices[key]
+        return self.reduce_buf[off:off + int(np.prod(shp))].view(*shp)
+
+    def loss_sums(self):
+        return self.reduce_buf[self.n_params:self.n_params + 8]
+
+    def frame_avg(self, n_frames):
+        la = torch.empty(n_frames, 8, 8, dtype=torch.float32, device=self.device)
+        fa = torch.empty(n_frames, dtype=torch.float32, device=self.device)
+        _ffi.check(self.lib.isdf_frame_avg(_ffi.ptr(self.reduce_buf), self.n_params, n_frames, _ffi.ptr(la),
+                                           _ffi.ptr(fa), _stream()), "isdf_frame_avg")
+        return la, fa
+
+    # ---- AdamW ----------------------------------------------------------------------
+    def adamw(self, lr=0.0013, weight_decay=0.012, betas=(0.9, 0.999), eps=1e-8, grad_scale=1.0,
+              use_device_count=True):
+        """torch.optim.AdamW.step on the flat buffer (trainer.py:435-439,982); the
+        summed gradient is divided by the (all-reduced) element count on device."""
+        self.opt_step += 1
+        cnt = self.reduce_buf[self.n_params + _ffi.LS_COUNT:] if use_device_count else None
+        _ffi.check(self.lib.isdf_adamw(C.byref(self.cnet), _ffi.ptr(self.params), _ffi.ptr(self.exp_avg),
+                                       _ffi.ptr(self.exp_avg_sq), _ffi.ptr(self.reduce_buf), _ffi.ptr(cnt),
+                                       float(grad_scale), float(lr), float(betas[0]), float(betas[1]),
+                                       float(eps), float(weight_decay), int(self.opt_step),
+                                       _ffi.ptr(self.shadow), _stream()), "isdf_adamw")

@@ -1,0 +1,70 @@
+"""CPU-side checks of the C-ABI library: it loads, exports every symbol
+include/isdf_hip.h declares, and its size queries (pure host code) are right.
+No kernel is launched here."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from isdf_amd import _ffi, build
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    build.build(verbose=False)
+    return _ffi.lib()
+
+
+def test_header_symbols_all_exported(lib):
+    hdr = open(os.path.join(ROOT, "include", "isdf_hip.h")).read()
+    declared = sorted(set(re.findall(r"\b(isdf_[a-z_0-9]+)\s*\(", hdr)))
+    assert declared == sorted(_ffi.SYMBOLS)
+    for s in declared:
+        assert hasattr(lib, s), s
+
+
+def test_abi_version_and_errors(lib):
+    assert lib.isdf_abi_version() == 1
+    assert lib.isdf_error_string(0) == b"ok"
+    assert b"invalid" in lib.isdf_error_string(-1)
+
+
+def test_size_queries_default_net(lib):
+    from isdf_amd.engine import NetConfig
+    c = NetConfig().to_c()
+    assert lib.isdf_param_count(C.byref(c)) == 460033          # probe of the reference net
+    assert lib.isdf_reduce_floats(C.byref(c), 5) == 460033 + 8 + 2 * 5 * 64
+    sh = lib.isdf_shadow_bytes(C.byref(c))
+    fwd = 256 * 256 + 4 * 256 * 256 + 256 * 512
+    bwd = 5 * 256 * 256 + 256 * 512
+    assert sh == 2 * (2 * fwd + 2 * bwd)
+    assert lib.isdf_workspace_bytes(C.byref(c), 27000, 1) > lib.isdf_workspace_bytes(C.byref(c), 27000, 0) > 0
+
+
+def test_invalid_arguments_are_reported_not_crashed(lib):
+    assert lib.isdf_param_count(None) == -1
+    from isdf_amd.engine import NetConfig
+    bad = NetConfig(blocks=0).to_c()
+    assert lib.isdf_param_count(C.byref(bad)) == -1
+    assert lib.isdf_sample_pixels(None, None, None) == -1
+    assert lib.isdf_adamw(C.byref(NetConfig().to_c()), None, None, None, None, None, 1.0, 1e-3, 0.9, 0.999,
+                          1e-8, 0.0, 1, None, None) == -1
+
+
+def test_param_layout_matches_reference_state_dict_order():
+    from isdf_amd.engine import NetConfig
+    import oracle.isdf_oracle as orc
+    import numpy as np
+    net = NetConfig()
+    ref = orc.init_params(256, 2, 6, np.random.RandomState(0))
+    assert [k for k, _ in net.param_shapes()] == list(ref.keys())
+    assert all(tuple(ref[k].shape) == tuple(s) for k, s in net.param_shapes())
+
+
+def test_engine_refuses_cpu():
+    from isdf_amd.engine import Engine, NetConfig
+    with pytest.raises(_ffi.IsdfError):
+        Engine(NetConfig(), "cpu")

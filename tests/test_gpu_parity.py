@@ -1,0 +1,262 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle and the
+reference-generated golden fixtures.  Needs a real MI355X: `pytest -m gpu`.
+
+Tolerances (BASELINE.json north_star / SURVEY 8c):
+  * sample indices, validity, compaction order: BIT-EXACT
+  * z_vals / pc: <= 1e-6 / 4e-6 abs (fp32 re-association only)
+  * sdf outputs and every loss term: <= 1e-3 relative
+  * sdf_grad: <= 5e-3 relative (fp16 operands; measured ~2e-3)
+  * weight gradients: cosine >= 0.999 and <= 1e-2 rel-L2 per tensor
+  * AdamW update given identical gradients: <= 1e-6
+"""
+import numpy as np
+import pytest
+import torch
+
+import oracle.isdf_oracle as orc
+from tests import golden_util as gu
+
+pytestmark = pytest.mark.gpu
+
+TOL_SDF = 1e-3
+TOL_LOSS = 1e-3
+TOL_SDF_GRAD = 5e-3
+TOL_DW = 1e-2
+
+
+def _engine(g, fwd_operand="fp16"):
+    from isdf_amd.engine import Engine, NetConfig
+    H, B, nf, si, so = g["net"]
+    has_T = int(g["has_transform"][0]) if "has_transform" in g else 1
+    net = NetConfig(hidden=int(H), blocks=int(B), n_freqs=int(nf), scale_input=float(si),
+                    scale_output=float(so), transform=g["bounds_T"] if has_T else None,
+                    fwd_operand=fwd_operand)
+    eng = Engine(net, "cuda")
+    eng.load_params(gu.params_of(g))
+    return eng
+
+
+def _cfgs(g):
+    from isdf_amd.engine import LossConfig, SampleConfig
+    cam, sc = gu.cam_of(g), gu.sample_of(g)
+    lcf = gu.loss_of(g)
+    lc = LossConfig(bounds_method=lcf.bounds_method, loss_type=lcf.loss_type, trunc_weight=lcf.trunc_weight,
+                    trunc_distance=lcf.trunc_distance, eik_weight=lcf.eik_weight,
+                    eik_apply_dist=lcf.eik_apply_dist, grad_weight=lcf.grad_weight, orien_loss=lcf.orien_loss)
+    smp = SampleConfig(n_rays=sc["n_rays"], n_strat=sc["n_strat"], n_surf=sc["n_surf"],
+                       min_depth=sc["min_depth"], dist_behind_surf=sc["dist_behind_surf"], **cam)
+    return lc, smp
+
+
+def _scaled_err(got, ref, floor):
+    """max |got-ref| relative to the output scale (never below `floor`): the per-element relative
+    error of a near-zero SDF value is meaningless, so tiny batches are judged on the scale of the
+    network output (scale_output = 0.14) / of a unit gradient."""
+    got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
+    return np.abs(got - ref).max() / max(np.abs(ref).max(), floor)
+
+
+def _dev(a, dtype=None):
+    t = torch.as_tensor(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.cuda()
+
+
+def _sample_hip(eng, g, smp_cfg, want_T=True):
+    F = g["depth_batch"].shape[0]
+    idx = torch.arange(F, dtype=torch.int32, device="cuda")
+    draws = dict(indices_h=_dev(g["draw_indices_h"]), indices_w=_dev(g["draw_indices_w"]),
+                 U=_dev(g["draw_U"]), N_off=_dev(g["draw_N_off"]))
+    return eng.sample(_dev(g["depth_batch"]), _dev(g["T_WC_batch"]), _dev(g["normal_batch"]), idx, idx,
+                      smp_cfg, draws=draws, want_T=want_T)
+
+
+def test_library_loaded_and_abi():
+    from isdf_amd import _ffi
+    assert _ffi.lib().isdf_abi_version() == _ffi.ABI_VERSION
+
+
+def test_sampler_bit_exact_vs_reference_fixture():
+    g = gu.load("eval_full_ray")
+    eng = _engine(g)
+    lc, sc = _cfgs(g)
+    s = _sample_hip(eng, g, sc)
+    torch.cuda.synchronize()
+    R = int(s["n_valid"].item())
+    assert R == g["depth_sample"].shape[0]
+    for k in ["indices_b", "indices_h", "indices_w"]:
+        assert np.array_equal(s[k][:R].cpu().numpy(), g[k]), k
+    assert np.array_equal(s["depth_sample"][:R].cpu().numpy(), g["depth_sample"])
+    assert np.array_equal(s["norm_sample"][:R].cpu().numpy(), g["norm_sample"])
+    assert np.array_equal(s["T_WC_sample"][:R].cpu().numpy(), g["T_WC_sample"])
+    np.testing.assert_allclose(s["dirs_C_sample"][:R].cpu().numpy(), g["dirs_C_sample"], rtol=0, atol=1e-7)
+    np.testing.assert_allclose(s["z_vals"][:R].cpu().numpy(), g["z_vals"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(s["pc"][:R].cpu().numpy(), g["pc"], rtol=0, atol=4e-6)
+
+
+@pytest.mark.parametrize("fwd_operand,tol", [("fp16", TOL_SDF), ("bf16", 8e-3)])
+def test_forward_sdf(fwd_operand, tol):
+    g = gu.load("eval_full_ray")
+    eng = _engine(g, fwd_operand)
+    x = g["pc"].reshape(-1, 3)
+    sdf = eng.sdf_eval(_dev(x)).cpu().numpy()
+    ref = g["sdf_nonoise"].reshape(-1)          # produced by the REAL reference
+    err = gu.rel_err(sdf, ref)
+    mx = np.abs(sdf - ref).max() / np.abs(ref).max()
+    assert err < tol and mx < 2 * tol, (fwd_operand, err, mx)
+
+
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 1000, 27000])
+def test_forward_ragged_sizes(n):
+    g = gu.load("eval_full_ray")
+    eng = _engine(g)
+    rng = np.random.RandomState(n)
+    x = rng.uniform(-3, 3, (n, 3)).astype(np.float32)
+    sdf, grad = eng.sdf_eval(_dev(x), want_grad=True)
+    cfg, params = gu.net_of(g), gu.params_of(g)
+    ref, refg = orc.sdf_forward_grad(params, cfg, x)
+    assert _scaled_err(sdf.cpu().numpy(), ref, 0.14) < 2 * TOL_SDF
+    assert _scaled_err(grad.cpu().numpy(), refg, 1.0) < 2 * TOL_SDF_GRAD
+    if n >= 64:
+        assert gu.rel_err(sdf.cpu().numpy(), ref) < TOL_SDF
+        assert gu.rel_err(grad.cpu().numpy(), refg) < TOL_SDF_GRAD
+
+
+def test_input_gradient_vs_reference_fixture():
+    g = gu.load("eval_full_ray")
+    eng = _engine(g)
+    x = g["pc"].reshape(-1, 3)
+    sdf, grad = eng.sdf_eval(_dev(x), want_grad=True)
+    err = gu.rel_err(grad.cpu().numpy(), g["sdf_grad"].reshape(-1, 3))
+    assert err < TOL_SDF_GRAD, err
+    assert gu.rel_err(sdf.cpu().numpy(), g["sdf_nonoise"].reshape(-1)) < TOL_SDF
+
+
+def _run_step(g, bounds_method=None, loss_type=None, fwd_operand="fp16"):
+    eng = _engine(g, fwd_operand)
+    lc, sc = _cfgs(g)
+    if bounds_method:
+        lc.bounds_method = bounds_method
+    if loss_type:
+        lc.loss_type = loss_type
+    s = _sample_hip(eng, g, sc)
+    R = g["depth_sample"].shape[0]
+    noise = g["draw_noise"].reshape(R, -1) * np.float32(g["noise_std"][0])
+    dbg = eng.train_step(s, lc, sc, noise=_dev(noise), debug=True)
+    torch.cuda.synchronize()
+    # oracle on the same inputs
+    cfg, params = gu.net_of(g), gu.params_of(g)
+    lco = gu.loss_of(g)
+    lco.bounds_method, lco.loss_type = lc.bounds_method, lc.loss_type
+    terms, grads = orc.loss_and_grads(params, cfg, lco, g["pc"], g["z_vals"], g["depth_sample"],
+                                      g["dirs_C_sample"], g["T_WC_sample"], g["norm_sample"], noise=noise)
+    return eng, s, dbg, terms, grads, R
+
+
+@pytest.mark.parametrize("bm,lt", [("ray", "L1"), ("ray", "L2"), ("pc", "L1")])
+def test_train_step_losses_and_gradients(bm, lt):
+    g = gu.load("eval_full_ray")
+    eng, s, dbg, terms, grads, R = _run_step(g, bm, lt)
+    S = g["z_vals"].shape[1]
+    N = R * S
+    sdf = dbg["sdf"][:R].cpu().numpy()
+    assert gu.rel_err(sdf, terms["sdf"]) < TOL_SDF
+    assert gu.rel_err(dbg["sdf_grad"][:R].cpu().numpy(), terms["sdf_grad"]) < TOL_SDF_GRAD
+    ls = eng.loss_sums().cpu().numpy()
+    assert ls[4] == N
+    for k, name in [(0, "sdf_loss"), (1, "grad_loss"), (2, "eikonal_loss"), (3, "total_loss")]:
+        got = ls[k] / N
+        assert abs(got - terms[name]) < TOL_LOSS * abs(terms[name]), (name, got, terms[name])
+    tl = dbg["tot_loss_mat"][:R].cpu().numpy()
+    assert gu.rel_err(tl, terms["tot_loss_mat"]) < 5e-3
+    cam = gu.cam_of(g)
+    F = g["depth_batch"].shape[0]
+    la_ref, fa_ref = orc.frame_avg(terms["tot_loss_mat"], g["indices_b"], g["indices_h"], g["indices_w"],
+                                   F, cam["H"], cam["W"])
+    la, fa = eng.frame_avg(F)
+    np.testing.assert_allclose(fa.cpu().numpy(), fa_ref, rtol=5e-3, atol=1e-6)
+    np.testing.assert_allclose(la.cpu().numpy(), la_ref, rtol=2e-2, atol=1e-5)
+    for k in grads:
+        got = (eng.grad_view(k).cpu().numpy().astype(np.float64) / N).reshape(-1)
+        ref = grads[k].astype(np.float64).reshape(-1)
+        cos = got @ ref / (np.linalg.norm(got) * np.linalg.norm(ref))
+        assert cos > 0.999 and gu.rel_err(got, ref) < TOL_DW, (k, cos, gu.rel_err(got, ref))
+
+
+def test_train_step_vs_reference_fixture_digest():
+    """Directly against what the REAL reference produced (losses + gradient digests)."""
+    g = gu.load("eval_full_ray")
+    eng, s, dbg, terms, grads, R = _run_step(g)
+    N = R * g["z_vals"].shape[1]
+    ls = eng.loss_sums().cpu().numpy()
+    for k, name in [(0, "sdf_loss"), (1, "grad_loss"), (2, "eikonal_loss"), (3, "total_loss")]:
+        assert abs(ls[k] / N - g[name][0]) < TOL_LOSS * abs(g[name][0]), name
+    prng = np.random.RandomState(1234)
+    for k in gu.params_of(g):
+        v = eng.grad_view(k).cpu().numpy().astype(np.float64) / N
+        probe = prng.standard_normal(v.shape)
+        nrm, dot = g["gdig/" + k]
+        assert abs(np.linalg.norm(v) - nrm) < TOL_DW * nrm, k
+        assert abs((v * probe).sum() - dot) < TOL_DW * nrm * np.sqrt(v.size), k
+
+
+def test_adamw_matches_oracle_given_identical_grads():
+    g = gu.load("eval_full_ray")
+    eng = _engine(g)
+    params = gu.params_of(g)
+    rng = np.random.RandomState(5)
+    F = 5
+    nred = int(eng.lib.isdf_reduce_floats(__import__("ctypes").byref(eng.cnet), F))
+    eng.reduce_buf = torch.zeros(nred, device="cuda")
+    grads = {}
+    for k, (off, shp) in eng.slices.items():
+        grads[k] = (rng.standard_normal(shp) * 1e-2).astype(np.float32)
+        eng.reduce_buf[off:off + grads[k].size] = _dev(grads[k].reshape(-1))
+    state = orc.new_adam_state()
+    for _ in range(3):
+        eng.adamw(use_device_count=False)
+        orc.adamw_step(params, grads, state)
+    torch.cuda.synchronize()
+    for k in params:
+        got = eng.param_view(k).cpu().numpy()
+        assert np.abs(got - params[k]).max() <= 1e-6 * max(1.0, np.abs(params[k]).max()), k
+
+
+def test_three_full_steps_track_oracle():
+    """sampler -> step -> AdamW x3 with injected draws.  AdamW's early updates are ~lr*sign(g), so an
+    element whose gradient is ~0 may move by +-lr either way whatever the gradient accuracy: the drift
+    from the oracle trajectory is therefore judged against the distance the tensor has moved."""
+    g = gu.load("eval_full_ray")
+    eng = _engine(g)
+    lc, sc = _cfgs(g)
+    cfg, params = gu.net_of(g), gu.params_of(g)
+    init = {k: v.copy() for k, v in params.items()}
+    lco, cam, sco = gu.loss_of(g), gu.cam_of(g), gu.sample_of(g)
+    state = orc.new_adam_state()
+    F = g["depth_batch"].shape[0]
+    frames = dict(depth_batch=g["depth_batch"], T_WC_batch=g["T_WC_batch"], normal_batch=g["normal_batch"])
+    rng = np.random.RandomState(99)
+    for it in range(3):
+        R0 = F * sc.n_rays
+        draws = dict(indices_h=rng.randint(0, cam["H"], R0).astype(np.int64),
+                     indices_w=rng.randint(0, cam["W"], R0).astype(np.int64),
+                     U=rng.uniform(size=(R0, sc.n_strat)).astype(np.float32),
+                     N_off=(0.1 * rng.standard_normal((R0, sc.n_surf - 1))).astype(np.float32),
+                     noise=(0.04 * rng.standard_normal((R0, sc.S))).astype(np.float32))
+        out = orc.train_step(params, state, cfg, lco, frames, cam, sco, draws)
+        idx = torch.arange(F, dtype=torch.int32, device="cuda")
+        s = eng.sample(_dev(g["depth_batch"]), _dev(g["T_WC_batch"]), _dev(g["normal_batch"]), idx, idx, sc,
+                       draws={k: _dev(v) for k, v in draws.items() if k != "noise"})
+        R = out["depth_sample"].shape[0]
+        eng.train_step(s, lc, sc, noise=_dev(draws["noise"][:R]))
+        ls = eng.loss_sums().cpu().numpy()
+        assert int(s["n_valid"].item()) == R
+        assert abs(ls[3] / ls[4] - out["total_loss"]) < 2e-3 * abs(out["total_loss"]), it
+        eng.adamw()
+    torch.cuda.synchronize()
+    for k in params:
+        got = eng.param_view(k).cpu().numpy().astype(np.float64)
+        moved = np.linalg.norm(params[k].astype(np.float64) - init[k])
+        drift = np.linalg.norm(got - params[k]) / moved
+        assert drift < 0.1, (k, drift)
