@@ -1,0 +1,268 @@
+#!/usr/bin/env python3
+"""Benchmark of the iSDF training hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one pass of `Trainer.step`'s hot path (sampler -> fused PE+MLP chain
+-> dW -> reductions -> [RCCL all-reduce] -> AdamW -> frame averages) over one
+batch of synthetic posed-depth keyframes.  Workload (BASELINE.json configs[1],
+read as SURVEY 0 explains): replicaCAD.json defaults = 5 keyframes x 200 rays x
+27 samples = 27 000 points per rank-step, 680x1200 depth, 6x256 Softplus MLP
+with 255-wide icosahedron PE, eikonal + normal terms on, bounds "ray".  With N
+ranks every rank draws its own 1000 rays (rays shard over ranks, weak scaling:
+N x 27k points per optimiser step) and ONE RCCL all-reduce carries the flat
+[grad | loss sums | bins] buffer.  Prints one JSON line on rank 0.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+M_MAC = 255 * 256 + 4 * 256 * 256 + (256 + 255) * 256 + 256      # 458 496 MAC/point
+MFMA_PEAK = 2.5e15                                                # dense bf16/f16 MFMA peak, gfx950
+
+
+class HipEvents:
+    """hipEvent_t via ctypes on the HIP runtime (events live on the stream the kernels use)."""
+
+    def __init__(self, n):
+        self.hip = ctypes.CDLL("libamdhip64.so")
+        self.ev = (ctypes.c_void_p * n)()
+        for i in range(n):
+            e = ctypes.c_void_p()
+            assert self.hip.hipEventCreate(ctypes.byref(e)) == 0
+            self.ev[i] = e
+
+    def group(self, i, k=4):
+        return ctypes.cast(ctypes.byref(self.ev, i * k * ctypes.sizeof(ctypes.c_void_p)),
+                           ctypes.POINTER(ctypes.c_void_p))
+
+    def ms(self, a, b):
+        out = ctypes.c_float()
+        rc = self.hip.hipEventElapsedTime(ctypes.byref(out), ctypes.c_void_p(self.ev[a]), ctypes.c_void_p(self.ev[b]))
+        assert rc == 0, rc
+        return out.value
+
+
+def reference_config():
+    """replicaCAD.json defaults (isdf/train/configs/replicaCAD.json) for the hot path."""
+    return {
+        "dataset": {"camera": {"w": 1200, "h": 680, "fx": 600.0, "fy": 600.0, "cx": 599.5, "cy": 339.5}},
+        "optimiser": {"lr": 0.0013, "weight_decay": 0.012},
+        "sample": {"n_rays": 200, "n_rays_is_kf": 400, "n_strat_samples": 19, "n_surf_samples": 8,
+                   "depth_range": [0.07, 12.0], "dist_behind_surf": 0.1},
+        "model": {"do_active": 0, "frac_time_perception": 1.0, "scale_output": 0.14, "noise_std": 0.25,
+                  "noise_kf": 0.08, "noise_frame": 0.04, "window_size": 5, "hidden_layers_block": 2,
+                  "hidden_feature_size": 256, "iters_per_kf": 60, "iters_per_frame": 10,
+                  "embedding": {"scale_input": 0.05937489, "n_embed_funcs": 5}},
+        "loss": {"bounds_method": "ray", "loss_type": "L1", "trunc_weight": 5.38344020,
+                 "trunc_distance": 0.29365022, "eik_weight": 0.268, "eik_apply_dist": 0.1,
+                 "grad_weight": 0.018, "orien_loss": 0},
+    }
+
+
+def make_keyframes(cam, n, seed=1):
+    from isdf_amd import synthetic
+    cache = "/tmp/isdf_bench_kf_%dx%d_%d_%d.npz" % (cam["H"], cam["W"], n, seed)
+    if os.path.exists(cache):
+        try:
+            z = np.load(cache)
+            return z["depth"], z["normal"], z["T"]
+        except Exception:
+            pass
+    d, nrm, T = synthetic.keyframes(n, cam, seed=seed, noise_std=0.01)
+    try:
+        tmp = cache + ".%d.tmp.npz" % os.getpid()
+        np.savez(tmp, depth=d, normal=nrm, T=T)
+        os.replace(tmp, cache)
+    except Exception:
+        pass
+    return d, nrm, T
+
+
+def cpu_baseline(depth, normal, T, cam, cfg, budget_s=12.0):
+    """The reference's CPU PyTorch path (torch port, oracle/torch_port.py) on the host
+    cores of this box, bounded sample of the same workload."""
+    from oracle import torch_port as tp
+    cores = os.cpu_count() or 1
+    threads = min(cores, 64)
+    torch.set_num_threads(threads)
+    sc = dict(n_rays=cfg["sample"]["n_rays"], n_strat=19, n_surf=8, min_depth=0.07, dist_behind_surf=0.1)
+    lc = dict(trunc_distance=cfg["loss"]["trunc_distance"], loss_type="L1", trunc_weight=cfg["loss"]["trunc_weight"],
+              eik_apply_dist=0.1, eik_weight=cfg["loss"]["eik_weight"], grad_weight=cfg["loss"]["grad_weight"])
+    d, n, Tt = torch.from_numpy(depth), torch.from_numpy(normal), torch.from_numpy(T)
+    out = {}
+    for label, ftz in (("ftz", True), ("as_shipped", False)):
+        torch.set_flush_denormal(ftz)
+        torch.manual_seed(1)
+        net = tp.PortNet(256, 2, 6, 0.05937489, 0.14, None)
+        opt = torch.optim.AdamW(net.parameters(), lr=0.0013, weight_decay=0.012)
+        gen = torch.Generator().manual_seed(1)
+        tp.train_step(net, opt, d, Tt, n, cam, sc, lc, 0.25, gen)           # warm-up
+        t0 = time.perf_counter(); k = 0
+        while True:
+            tp.train_step(net, opt, d, Tt, n, cam, sc, lc, 0.25, gen); k += 1
+            el = time.perf_counter() - t0
+            if el > budget_s or k >= 40:
+                break
+        out[label] = (k / el, k, el)
+    torch.set_flush_denormal(False)
+    v, k, el = out["ftz"]
+    return {"value": round(v, 4), "unit": "train-steps/s", "cores": threads, "kind": "port",
+            "sample": "%d steps of the same 27k-point workload in %.1f s, torch %s CPU, %d threads of %d logical CPUs, "
+                      "flush-denormal on (the faster setting; the reference ships with it off)"
+                      % (k, el, torch.__version__, threads, cores),
+            "as_shipped_value": round(out["as_shipped"][0], 4),
+            "as_shipped_sample": "%d steps in %.1f s, denormals not flushed" % out["as_shipped"][1:]}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--rays-per-frame", type=int, default=200)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--fwd-operand", default="fp16", choices=["fp16", "bf16"])
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+    torch.cuda.set_device(local)
+    group = None
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local))
+        group = torch.distributed.group.WORLD
+
+    import __graft_entry__
+    __graft_entry__.build(verbose=False)
+    from isdf_amd.trainer import HipTrainer, FrameData
+    from isdf_amd import synthetic
+
+    cfg = reference_config()
+    cfg["sample"]["n_rays"] = args.rays_per_frame
+    cam = dict(synthetic.REPLICA_CAM)
+    F = cfg["model"]["window_size"]
+    depth, normal, T = make_keyframes(cam, F)
+
+    torch.manual_seed(1)
+    np.random.seed(1)
+    tr = HipTrainer("cuda:%d" % local, cfg, incremental=True, inv_bounds_transform=synthetic.bounds_transform(),
+                    rng="philox", seed=1, dist_group=group, fwd_operand=args.fwd_operand)
+    if world > 1:   # identical replicas
+        torch.distributed.broadcast(tr.engine.params, 0)
+        tr.engine.pack()
+    dev = tr.device
+    tr.frames = FrameData(frame_id=np.arange(F), depth_batch=torch.from_numpy(depth).to(dev),
+                          T_WC_batch=torch.from_numpy(T).to(dev), normal_batch=torch.from_numpy(normal).to(dev),
+                          frame_avg_losses=torch.zeros(F, device=dev))
+    eng = tr.engine
+    sc = tr._sample_cfg()
+    lc = tr._loss_cfg()
+    S = sc.S
+    fidx = torch.arange(F, dtype=torch.int32, device=dev)
+    max_rays = F * sc.n_rays
+    noise_buf = torch.empty(max_rays, S, device=dev)
+    K, W = args.steps, args.warmup
+    events = HipEvents(4 * K)
+
+    def one_step(i, ev=None):
+        s = eng.sample(tr.frames.depth_batch, tr.frames.T_WC_batch, tr.frames.normal_batch, fidx, fidx, sc,
+                       seed=1 + 7919 * rank, offset=i)
+        noise_buf.normal_(0.0, tr.noise_std)                      # fc_map.py:106-108
+        eng.train_step(s, lc, sc, noise=noise_buf, prof_events=ev)
+        if group is not None:
+            torch.distributed.all_reduce(eng.reduce_buf, group=group)
+        tr.optimiser.step()
+        la, fa = eng.frame_avg(F)
+        tr.frames.frame_avg_losses[fidx.long()] = fa            # trainer.py:979
+        return s
+
+    for i in range(W):
+        one_step(i)
+    torch.cuda.synchronize()
+    if group is not None:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(K):
+        one_step(W + i, events.group(i))
+    torch.cuda.synchronize()
+    if group is not None:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if group is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- per-kernel timing from the HIP events recorded inside the timed region
+    t_chain = np.mean([events.ms(4 * i, 4 * i + 1) for i in range(K)]) * 1e-3
+    t_dw = np.mean([events.ms(4 * i + 1, 4 * i + 2) for i in range(K)]) * 1e-3
+    t_red = np.mean([events.ms(4 * i + 2, 4 * i + 3) for i in range(K)]) * 1e-3
+    # valid points per launch: replay the same Philox draws (sampler only) and read n_valid
+    nv = []
+    for i in range(min(K, 50)):
+        s = eng.sample(tr.frames.depth_batch, tr.frames.T_WC_batch, tr.frames.normal_batch, fidx, fidx, sc,
+                       seed=1 + 7919 * rank, offset=W + i)
+        nv.append(int(s["n_valid"].item()))
+    P = float(np.mean(nv)) * S
+    ls = eng.loss_sums().cpu().numpy()
+    final_loss = float(ls[3] / max(ls[4], 1))
+
+    if rank == 0:
+        flops_chain = 8.0 * M_MAC * P      # fwd 2M + input-grad 2M + its adjoint 2M + reverse sweep 2M
+        res = {
+            "metric": "train-steps/sec (27k-point ray batches through Trainer.step's hot path; whole job)",
+            "value": round(world * K / elapsed, 2),
+            "unit": "train-steps/s",
+            "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": round(1e3 * elapsed / K, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f16/bf16 MFMA operands, f32 accumulate" if args.fwd_operand == "fp16" else "bf16 MFMA operands, f32 accumulate",
+            "data": "synthetic",
+            "config": {"workload": "replicaCAD.json defaults: 5 keyframes x %d rays x 27 samples = %d points per "
+                                   "rank-step, 680x1200 synthetic room depth, 6x256 Softplus MLP + 255-wide "
+                                   "icosahedron PE (460033 params), eik+normal loss, bounds=ray, AdamW"
+                                   % (sc.n_rays, max_rays * S),
+                       "global_points_per_step": int(world * max_rays * S),
+                       "parallelism": "dp%d (rays sharded, one RCCL all-reduce of %d floats)" % (world, eng.reduce_buf.numel())
+                       if world > 1 else "single GPU"},
+            "points_per_s": round(world * P * K / elapsed, 1),
+            "valid_points_per_step": round(P, 1),
+            "final_total_loss": round(final_loss, 5),
+            "kernel_ms": {"chain": round(t_chain * 1e3, 4), "dw": round(t_dw * 1e3, 4),
+                          "reduce+finalize": round(t_red * 1e3, 4)},
+            "roofline": {"bound": "mfma", "kernel": "chain_kernel (fused PE+MLP fwd / input-grad / adjoint / reverse)",
+                         "achieved": round(flops_chain / t_chain / 1e12, 3), "peak": MFMA_PEAK / 1e12,
+                         "unit": "TFLOP/s", "frac": round(flops_chain / t_chain / MFMA_PEAK, 5), "traffic": None,
+                         "algorithmic_flop_per_launch": flops_chain,
+                         "whole_step_frac_of_mfma_peak": round(12.0 * M_MAC * P * K / elapsed / MFMA_PEAK, 5)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(depth, normal, T, cam, cfg)
+            res["speedup_vs_cpu_baseline"] = round(res["value"] / res["cpu_baseline"]["value"], 1)
+        print(json.dumps(res), flush=True)
+    if group is not None:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -175,6 +175,9 @@ typedef struct isdf_step_out {
   float* sdf;           /* optional [max_rays,S]  debug / parity outputs       */
   float* sdf_grad;      /* optional [max_rays,S,3]                             */
   float* tot_loss_mat;  /* optional [max_rays,S]                               */
+  void** prof_events;   /* optional HOST array of 4 hipEvent_t recorded on `stream`:
+                           [0] before the chain kernel, [1] after it, [2] after
+                           the dW kernel, [3] after the reductions (bench.py)    */
 } isdf_step_out;
 
 /* layout of loss_sums inside reduce_buf (after the n_params gradient floats) */

@@ -66,7 +66,7 @@ class StepArgs(C.Structure):
 
 class StepOut(C.Structure):
     _fields_ = [("reduce_buf", C.c_void_p), ("sdf", C.c_void_p), ("sdf_grad", C.c_void_p),
-                ("tot_loss_mat", C.c_void_p)]
+                ("tot_loss_mat", C.c_void_p), ("prof_events", C.POINTER(C.c_void_p))]
 
 
 class IsdfError(RuntimeError):

@@ -142,20 +142,27 @@ int isdf_train_step(const isdf_net_cfg* net, const isdf_loss_cfg* loss, const fl
   p.sdf = o->sdf; p.sdf_grad = o->sdf_grad; p.tot_loss_mat = o->tot_loss_mat;
   p.ray_loss = rayLoss; p.wg_loss = wgLoss; p.grad = o->reduce_buf;
   p.spill = (uint16_t*)(ws + w.offSpill); p.sp = w.sp;
+  hipEvent_t* ev = (hipEvent_t*)o->prof_events;
+  if (ev && hipEventRecord(ev[0], st) != hipSuccess) return ISDF_EHIP;
   rc = launch_chain(p, 2, w.nTiles, st);
   if (rc) return rc;
+  if (ev && hipEventRecord(ev[1], st) != hipSuccess) return ISDF_EHIP;
 
   DwParams d = {};
   d.lay = l; d.sp = w.sp; d.spill = p.spill; d.n_valid = a->n_valid; d.S = a->S; d.dwPart = dwPart;
   rc = launch_dw(d, st);
   if (rc) return rc;
+  if (ev && hipEventRecord(ev[2], st) != hipSuccess) return ISDF_EHIP;
   rc = launch_dw_reduce(l, dwPart, o->reduce_buf, st);
   if (rc) return rc;
   float* lossSums = o->reduce_buf + l.n_params;
   float* blockLoss = lossSums + 8;
   float* blockCnt = blockLoss + (int64_t)a->n_frames * 64;
-  return launch_finalize(wgLoss, w.nTiles, a->n_valid, 0, a->S, rayLoss, a->indices_b, a->indices_h, a->indices_w,
-                         a->n_frames, a->H, a->W, lossSums, blockLoss, blockCnt, st);
+  rc = launch_finalize(wgLoss, w.nTiles, a->n_valid, 0, a->S, rayLoss, a->indices_b, a->indices_h, a->indices_w,
+                       a->n_frames, a->H, a->W, lossSums, blockLoss, blockCnt, st);
+  if (rc) return rc;
+  if (ev && hipEventRecord(ev[3], st) != hipSuccess) return ISDF_EHIP;
+  return ISDF_OK;
 }
 
 int isdf_bounds_pc(const int32_t* n_valid, int32_t max_rays, int32_t S, const float* pc, const float* z_vals,

@@ -243,7 +243,7 @@ class Engine:
         return sdf.view(*shp)
 
     # ---- training step ----------------------------------------------------------
-    def train_step(self, smp, lc: LossConfig, sc: SampleConfig, noise=None, debug=False):
+    def train_step(self, smp, lc: LossConfig, sc: SampleConfig, noise=None, debug=False, prof_events=None):
         """Everything between sampling and the optimiser.  Fills self.reduce_buf with
         [grad sums | loss sums(8) | block_loss | block_cnt]; returns debug tensors."""
         dev = self.device
@@ -262,9 +262,13 @@ class Engine:
         a.norm_sample = None if smp.get("norm_sample") is None else smp["norm_sample"].data_ptr()
         keep = []
         if noise is not None:
-            nz = torch.zeros(R0 * S, dtype=torch.float32, device=dev)
-            nn_ = noise.reshape(-1).to(device=dev, dtype=torch.float32)
-            nz[:nn_.numel()] = nn_
+            if (noise.numel() == R0 * S and noise.dtype == torch.float32 and noise.device == dev
+                    and noise.is_contiguous()):
+                nz = noise                       # already one value per (ray slot, sample): borrow it
+            else:                                # per-valid-ray noise: pad to the slot count
+                nz = torch.zeros(R0 * S, dtype=torch.float32, device=dev)
+                nn_ = noise.reshape(-1).to(device=dev, dtype=torch.float32)
+                nz[:nn_.numel()] = nn_
             keep.append(nz)
             a.noise = nz.data_ptr()
         if lc.bounds_method == "pc":
@@ -277,6 +281,8 @@ class Engine:
             keep += [pb, pg]
         o = _ffi.StepOut()
         o.reduce_buf = self.reduce_buf.data_ptr()
+        if prof_events is not None:   # ctypes array of 4 hipEvent_t (bench.py)
+            o.prof_events = prof_events
         dbg = {}
         if debug:
             dbg = dict(sdf=torch.zeros(R0, S, device=dev), sdf_grad=torch.zeros(R0, S, 3, device=dev),

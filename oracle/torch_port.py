@@ -1,0 +1,131 @@
+"""torch-CPU port of one reference training step -- TEST INFRASTRUCTURE, used only as
+the timed `cpu_baseline` of bench.py (kind "port") and as a second checker.
+
+The reference runs this path as PyTorch eager ops + autograd on whatever device
+it is given (`isdf/modules/trainer.py:951-1016`); it cannot travel to the GPU
+box (Python package with absent dependencies), so its op chain is restated here
+in the same order with the same torch primitives (Linear, Softplus(beta=100),
+autograd.grad(create_graph=True), CosineSimilarity(eps=1e-6), AdamW), which is
+what "the reference's CPU PyTorch path timed on the same box's host cores"
+means.  Pinned in tests/test_torch_port.py against the golden fixtures.
+"""
+import numpy as np
+import torch
+
+from .isdf_oracle import ICO_DIRS, layer_names
+
+
+class PortNet(torch.nn.Module):
+    """SDFMap + PostionalEncoding (`fc_map.py:63-111`, `embedding.py:24-111`)."""
+
+    def __init__(self, hidden=256, blocks=2, n_freqs=6, scale_input=0.05937489, scale_output=0.14,
+                 transform=None):
+        super().__init__()
+        self.hidden, self.blocks, self.n_freqs = hidden, blocks, n_freqs
+        self.scale_input, self.scale_output = scale_input, scale_output
+        self.transform = None if transform is None else torch.as_tensor(transform, dtype=torch.float32)
+        self.dirs = torch.tensor(ICO_DIRS, dtype=torch.float32)
+        E = 2 * 21 * n_freqs + 3
+        sp = lambda i, o: torch.nn.Sequential(torch.nn.Linear(i, o), torch.nn.Softplus(beta=100))
+        self.in_layer = sp(E, hidden)
+        self.mid1 = torch.nn.Sequential(*[sp(hidden, hidden) for _ in range(blocks)])
+        self.cat_layer = sp(hidden + E, hidden)
+        self.mid2 = torch.nn.Sequential(*[sp(hidden, hidden) for _ in range(blocks)])
+        self.out_alpha = torch.nn.Linear(hidden, 1)
+        for m in self.modules():
+            if isinstance(m, torch.nn.Linear):
+                torch.nn.init.xavier_normal_(m.weight)       # fc_map.py:58-60
+
+    def embed(self, x):
+        if self.transform is not None:                        # transform.py:287-304
+            x = x @ self.transform[:3, :3].T + self.transform[:3, 3]
+        x = x * self.scale_input
+        freq = 2.0 ** torch.linspace(0, self.n_freqs - 1, self.n_freqs)
+        proj = x @ self.dirs
+        xb = (proj[..., None] * freq).reshape(*proj.shape[:-1], -1)
+        return torch.cat([x, torch.sin(torch.cat([xb, xb + 0.5 * np.pi], -1))], -1)
+
+    def forward(self, x, noise=None):
+        e = self.embed(x)
+        h = self.mid1(self.in_layer(e))
+        h = self.mid2(self.cat_layer(torch.cat((h, e), -1)))
+        raw = self.out_alpha(h)
+        if noise is not None:
+            raw = raw + noise[..., None]
+        return (raw * self.scale_output).squeeze(-1)
+
+
+def sample_step(depth, T_WC, normals, cam, sc, gen):
+    """sample_pixels + get_batch_data + sample_along_rays (`sample.py:11-178`)."""
+    F, H, W = depth.shape
+    n = sc["n_rays"]
+    ih = torch.randint(0, H, (F * n,), generator=gen)
+    iw = torch.randint(0, W, (F * n,), generator=gen)
+    ib = torch.arange(F).repeat_interleave(n)
+    d = depth[ib, ih, iw]
+    nm = normals[ib, ih, iw]
+    ok = (d != 0) & ~torch.isnan(nm[:, 0])
+    d, nm, ib, ih, iw = d[ok], nm[ok], ib[ok], ih[ok], iw[ok]
+    Tm = T_WC[ib]
+    dC = torch.stack(((iw.float() - cam["cx"]) / cam["fx"], (ih.float() - cam["cy"]) / cam["fy"],
+                      torch.ones_like(d)), -1)
+    dW = (Tm[:, :3, :3] * dC[:, None, :]).sum(-1)
+    R = d.shape[0]
+    maxd = d + sc["dist_behind_surf"]
+    rng = (maxd - sc["min_depth"])[:, None]
+    lim = torch.linspace(0, 1, sc["n_strat"] + 1)[None, :].repeat(R, 1) * rng + sc["min_depth"]
+    z = lim[:, :-1] + torch.rand(R, sc["n_strat"], generator=gen) * (rng / sc["n_strat"])
+    off = torch.normal(torch.zeros(R, sc["n_surf"] - 1), 0.1, generator=gen)
+    near = torch.clamp(d[:, None] + off, torch.full((R, 1), sc["min_depth"]), maxd[:, None])
+    z = torch.cat((d[:, None], near, z), 1)
+    pc = Tm[:, None, :3, 3] + dW[:, None, :] * z[:, :, None]
+    return dict(pc=pc, z=z, depth=d, dC=dC, dW=dW, normals=nm, ib=ib, ih=ih, iw=iw)
+
+
+def loss_step(net, s, lc, noise_std, gen, noise=None):
+    """`Trainer.sdf_eval_and_loss` with bounds_method "ray" (`trainer.py:768-868`).
+    noise: optional pre-drawn, pre-scaled noise (parity tests)."""
+    pc = s["pc"].clone().requires_grad_()
+    if noise is None and noise_std is not None:
+        noise = torch.randn(pc.shape[:-1], generator=gen) * noise_std
+    sdf = net(pc, noise)
+    g = torch.autograd.grad(sdf, pc, torch.ones_like(sdf), create_graph=True, retain_graph=True)[0]
+    bounds = s["dC"].norm(dim=-1)[:, None] * (s["depth"][:, None] - s["z"])
+    gvec = -s["dW"][:, None, :].repeat(1, s["z"].shape[1] - 1, 1)
+    free = bounds > lc["trunc_distance"]
+    fs = torch.max(torch.relu(sdf - bounds), torch.exp(-5.0 * sdf) - 1.0)
+    mat = torch.where(free, fs, sdf - bounds)
+    mat = mat.abs() if lc["loss_type"] == "L1" else mat.square()
+    mat = torch.where(free, mat, mat * lc["trunc_weight"])
+    cos = torch.nn.CosineSimilarity(dim=-1, eps=1e-6)
+    gl = torch.cat(((1 - cos(g[:, 0], s["normals"]))[:, None], 1 - cos(gvec, g[:, 1:])), 1)
+    eik = (g.norm(2, dim=-1) - 1).abs()
+    eik = torch.where(bounds < lc["eik_apply_dist"], torch.zeros_like(eik), eik) * lc["eik_weight"]
+    tot = mat + lc["grad_weight"] * gl + eik
+    return tot.mean(), dict(sdf_loss=mat.mean().item(), grad_loss=gl.mean().item(),
+                            eikonal_loss=eik.mean().item()), tot
+
+
+def frame_avg_step(tot, s, F, H, W):
+    """`loss.frame_avg` (`loss.py:208-240`) incl. its dense [F,H,W] scatter images."""
+    full = torch.zeros(F, H, W)
+    mask = torch.zeros(F, H, W)
+    full[s["ib"], s["ih"], s["iw"]] = tot.sum(-1).detach()
+    mask[s["ib"], s["ih"], s["iw"]] = 1
+    la = full.view(-1, 8, H // 8, 8, W // 8).sum(dim=(2, 4))
+    ac = mask.view(-1, 8, H // 8, 8, W // 8).sum(dim=(2, 4))
+    ac[ac == 0] = 1.0
+    la = la / ac
+    return la, la.sum(dim=(1, 2)) / 64
+
+
+def train_step(net, opt, depth, T_WC, normals, cam, sc, lc, noise_std, gen):
+    s = sample_step(depth, T_WC, normals, cam, sc, gen)
+    total, losses, tot = loss_step(net, s, lc, noise_std, gen)
+    _, fa = frame_avg_step(tot, s, depth.shape[0], cam["H"], cam["W"])
+    total.backward()
+    opt.step()
+    for p in net.parameters():
+        p.grad = None
+    losses["total_loss"] = total.item()
+    return losses, fa
