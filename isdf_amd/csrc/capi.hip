@@ -9,15 +9,15 @@ using namespace isdf;
 namespace isdf {
 int launch_chain(const ChainParams& p, int mode, int64_t nTiles, hipStream_t st);
 int launch_dw(const DwParams& p, hipStream_t st);
-int launch_dw_reduce(const NetLayout& L, const float* dwPart, float* grad, hipStream_t st);
+int launch_dw_reduce(const ReduceParams& p, hipStream_t st);
 int launch_sample_pixels(const isdf_sample_args& a, const isdf_sample_out& o, hipStream_t st);
 int launch_sample_along_rays(const isdf_sample_args& a, const isdf_sample_out& o, hipStream_t st);
 int launch_adamw(float* p, float* m, float* v, const float* g, const float* cnt, float gs, float lr, float b1,
                  float b2, float eps, float wd, int step, int64_t n, hipStream_t st);
 int launch_pack(const NetLayout& L, const float* params, uint16_t* shadow, hipStream_t st);
-int launch_finalize(const float* wg_loss, int64_t maxTiles, const int32_t* n_valid, int64_t nph, int S,
-                    const float* ray_loss, const int64_t* ib, const int64_t* ih, const int64_t* iw, int F, int H,
-                    int W, float* loss_sums, float* bl, float* bc, hipStream_t st);
+int launch_finalize(const float* wg_loss, int64_t maxTiles, const int32_t* n_valid, int S, const float* tot_ws,
+                    const int64_t* ib, const int64_t* ih, const int64_t* iw, int F, int H, int W, float* loss_sums,
+                    float* bl, float* bc, hipStream_t st);
 int launch_frame_avg(const float* bl, const float* bc, int F, float* la, float* fa, hipStream_t st);
 int launch_bounds_pc(const int32_t* n_valid, int max_rays, int S, const float* pc, const float* z, const float* depth,
                      float* bounds, float* gv, hipStream_t st);
@@ -127,12 +127,11 @@ int isdf_train_step(const isdf_net_cfg* net, const isdf_loss_cfg* loss, const fl
   if (workspace_bytes < w.totalBytes) return ISDF_EWORKSPACE;
   hipStream_t st = (hipStream_t)stream;
   char* ws = (char*)workspace;
-  float* rayLoss = (float*)(ws + w.offRayLoss);
   float* wgLoss = (float*)(ws + w.offWgLoss);
   float* dwPart = (float*)(ws + w.offDwPart);
-  const int64_t nRed = l.n_params + 8 + 2 * (int64_t)a->n_frames * 64;
-  if (hipMemsetAsync(o->reduce_buf, 0, nRed * 4, st) != hipSuccess) return ISDF_EHIP;
-  if (hipMemsetAsync(rayLoss, 0, (size_t)a->max_rays * 4, st) != hipSuccess) return ISDF_EHIP;
+  float* vecPart = (float*)(ws + w.offVecPart);
+  float* totLoss = (float*)(ws + w.offTotLoss);
+  // every element of reduce_buf is written exactly once below (no memset, no atomics)
 
   ChainParams p = {};
   p.lay = l; p.loss = *loss; p.params = params; p.shadow = (const uint16_t*)shadow;
@@ -140,7 +139,7 @@ int isdf_train_step(const isdf_net_cfg* net, const isdf_loss_cfg* loss, const fl
   p.z_vals = a->z_vals; p.depth = a->depth_sample; p.dirsC = a->dirs_C_sample; p.dirsW = a->dirs_W_sample;
   p.normals = a->norm_sample; p.pc_bounds = a->pc_bounds; p.pc_grad_vec = a->pc_grad_vec;
   p.sdf = o->sdf; p.sdf_grad = o->sdf_grad; p.tot_loss_mat = o->tot_loss_mat;
-  p.ray_loss = rayLoss; p.wg_loss = wgLoss; p.grad = o->reduce_buf;
+  p.tot_ws = totLoss; p.wg_loss = wgLoss; p.vec_part = vecPart; p.vecStride = w.vecStride;
   p.spill = (uint16_t*)(ws + w.offSpill); p.sp = w.sp;
   hipEvent_t* ev = (hipEvent_t*)o->prof_events;
   if (ev && hipEventRecord(ev[0], st) != hipSuccess) return ISDF_EHIP;
@@ -153,12 +152,15 @@ int isdf_train_step(const isdf_net_cfg* net, const isdf_loss_cfg* loss, const fl
   rc = launch_dw(d, st);
   if (rc) return rc;
   if (ev && hipEventRecord(ev[2], st) != hipSuccess) return ISDF_EHIP;
-  rc = launch_dw_reduce(l, dwPart, o->reduce_buf, st);
+  ReduceParams rp = {};
+  rp.lay = l; rp.dwPart = dwPart; rp.vecPart = vecPart; rp.vecStride = w.vecStride; rp.n_valid = a->n_valid;
+  rp.S = a->S; rp.grad = o->reduce_buf;
+  rc = launch_dw_reduce(rp, st);
   if (rc) return rc;
   float* lossSums = o->reduce_buf + l.n_params;
   float* blockLoss = lossSums + 8;
   float* blockCnt = blockLoss + (int64_t)a->n_frames * 64;
-  rc = launch_finalize(wgLoss, w.nTiles, a->n_valid, 0, a->S, rayLoss, a->indices_b, a->indices_h, a->indices_w,
+  rc = launch_finalize(wgLoss, w.nTiles, a->n_valid, a->S, totLoss, a->indices_b, a->indices_h, a->indices_w,
                        a->n_frames, a->H, a->W, lossSums, blockLoss, blockCnt, st);
   if (rc) return rc;
   if (ev && hipEventRecord(ev[3], st) != hipSuccess) return ISDF_EHIP;

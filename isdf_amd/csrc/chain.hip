@@ -31,7 +31,7 @@ constexpr float kBeta = 100.f;
 template <int HD, int EP>
 struct Tile {
   static constexpr int BM = TILE_PTS;
-  static constexpr int NW = 4;
+  static constexpr int NW = CHAIN_NW;
   static constexpr int FB = HD / (NW * 32);   // 32-row feature blocks per wave
   static constexpr int PB = BM / 32;          // 32-point blocks
   static constexpr int R2 = (EP > HD ? EP : HD);
@@ -40,36 +40,73 @@ struct Tile {
   static constexpr int XBYTES = BM * ROWB;
   // small fp32 arrays after the X tile
   static constexpr int OFF_XS = XBYTES;                   // [BM][4] x' (scaled/transformed point)
-  static constexpr int OFF_PART = OFF_XS + BM * 16;       // [8][BM][4] partial sums (raw / g)
-  static constexpr int OFF_GB = OFF_PART + 8 * BM * 16;   // [BM][4] gbar in x' space, [3] = sbar*so
+  static constexpr int OFF_PART = OFF_XS + BM * 16;       // [NW][BM][4] partial sums (raw / g)
+  static constexpr int OFF_GB = OFF_PART + NW * BM * 16;   // [BM][4] gbar in x' space, [3] = sbar*so
   static constexpr int OFF_RED = OFF_GB + BM * 16;        // [8] block loss sums
   static constexpr int LDS_BYTES = OFF_RED + 64;
 };
 
+// Workgroup barrier that only waits for this wave's LDS traffic.  The global
+// spill tiles are thread-private (the lane that stores a piece is the lane that
+// re-reads it), so global stores/loads may stay in flight across the barrier;
+// __syncthreads() would drain them (s_waitcnt vmcnt(0)) at every layer.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
 __device__ __forceinline__ int swz(int row, int colbytes) { return colbytes ^ ((row & 15) << 4); }
 
 // C[FB*32 feats][PB*32 pts] += Wpacked[feat][k] * X[pt][k]  over KSTEPS*16 k.
-template <bool F16, int KSTEPS, int FBN, int PBN, int ROWB>
+// Weight fragments come straight from L2 (~500-800 cycles away): the loop is a
+// real (not unrolled) loop over stages of KS k-steps whose next-stage fragments
+// are requested before the current stage's MFMAs, so one stage of MFMA time
+// (KS*FBN*PBN*32 cycles) covers the load latency and the compiler cannot hoist
+// loads beyond one stage (register budget).
+template <bool F16, int KSTEPS, int FBN, int PBN, int ROWB, typename Hook>
 __device__ __forceinline__ void gemm(f32x16 (&acc)[FBN][PBN], const uint4* __restrict__ wp,
-                                     int rbStride, const char* xl, int colByteBase, int lane) {
+                                     int rbStride, const char* xl, int colByteBase, int lane, Hook&& lateHook) {
+  constexpr int KS = 2;
+  static_assert(KSTEPS % KS == 0, "K must be a multiple of 64");
+  constexpr int NST = KSTEPS / KS;
   const int j = lane & 31, hi = lane >> 5;
   const int sw = (j & 15) << 4;
-#pragma unroll 4
-  for (int ks = 0; ks < KSTEPS; ++ks) {
-    typename Op<F16>::v8 a[FBN], b[PBN];
+  const uint4* wl = wp + lane;
+  uint4 cur[KS][FBN], nxt[KS][FBN];
 #pragma unroll
-    for (int fb = 0; fb < FBN; ++fb)
-      a[fb] = __builtin_bit_cast(typename Op<F16>::v8, wp[fb * rbStride + ks * 64 + lane]);
+  for (int s = 0; s < KS; ++s)
 #pragma unroll
-    for (int pb = 0; pb < PBN; ++pb) {
-      const int cb = (colByteBase + ks * 32 + hi * 16) ^ sw;
-      b[pb] = __builtin_bit_cast(typename Op<F16>::v8,
-                                 *(const uint4*)(xl + (pb * 32 + j) * ROWB + cb));
+    for (int fb = 0; fb < FBN; ++fb) cur[s][fb] = wl[fb * rbStride + s * 64];
+#pragma unroll 1
+  for (int st = 0; st < NST; ++st) {
+    if (st + 1 < NST) {
+#pragma unroll
+      for (int s = 0; s < KS; ++s)
+#pragma unroll
+        for (int fb = 0; fb < FBN; ++fb) nxt[s][fb] = wl[fb * rbStride + ((st + 1) * KS + s) * 64];
+    }
+    // after the LAST weight stage has been requested: memory returns in order, so
+    // anything issued here (the epilogue's spill prefetch) cannot stall the weight stream
+    if (st == NST - 2) lateHook();
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      typename Op<F16>::v8 b[PBN];
+#pragma unroll
+      for (int pb = 0; pb < PBN; ++pb) {
+        const int cb = (colByteBase + (st * KS + s) * 32 + hi * 16) ^ sw;
+        b[pb] = __builtin_bit_cast(typename Op<F16>::v8, *(const uint4*)(xl + (pb * 32 + j) * ROWB + cb));
+      }
+#pragma unroll
+      for (int fb = 0; fb < FBN; ++fb)
+#pragma unroll
+        for (int pb = 0; pb < PBN; ++pb)
+          acc[fb][pb] = Op<F16>::mfma(__builtin_bit_cast(typename Op<F16>::v8, cur[s][fb]), b[pb], acc[fb][pb]);
     }
 #pragma unroll
-    for (int fb = 0; fb < FBN; ++fb)
+    for (int s = 0; s < KS; ++s)
 #pragma unroll
-      for (int pb = 0; pb < PBN; ++pb) acc[fb][pb] = Op<F16>::mfma(a[fb], b[pb], acc[fb][pb]);
+      for (int fb = 0; fb < FBN; ++fb) cur[s][fb] = nxt[s][fb];
   }
 }
 
@@ -88,25 +125,37 @@ __device__ __forceinline__ int frag16_off(int w, int fb, int pb, int qp, int lan
   return ((((w * FBN + fb) * PBN + pb) * 2 + qp) * 64 + lane) * 8;
 }
 
-// sum v over the 32 lanes that share `hi`, lane j==0 of each half adds to dst.
-__device__ __forceinline__ void half_wave_atomic(float v, float* dst, int lane) {
+// sum v over the 32 lanes that share `hi`; lane j==0 of each half stores it.  Each
+// (layer, feature) has exactly ONE owner half-wave per workgroup, so the
+// per-workgroup partial needs no atomics (same-address global atomics from 422
+// workgroups serialise at ~12 ns each and dominated the first version).
+__device__ __forceinline__ void half_wave_store(float v, float* dst, int lane) {
 #pragma unroll
   for (int m = 16; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-  if ((lane & 31) == 0) atomicAdd(dst, v);
+  if ((lane & 31) == 0) *dst = v;
 }
 
-__device__ __forceinline__ float softplus_f(float z, float& s1) {
-  const float bz = kBeta * z;
-  const float t = __expf(fminf(bz, 20.f));
-  const float soft = __logf(1.f + t) * (1.f / kBeta);
-  s1 = bz > 20.f ? 1.f : t / (1.f + t);
-  return bz > 20.f ? z : soft;
+// Softplus(beta=100, threshold=20) on the hardware's base-2 transcendental units:
+//   a = max(z, ln2/beta * log2(1 + 2^(beta*log2e*z)))
+// (softplus(z) > z always, and torch's threshold branch returns z where the
+// two differ by < 2e-11, so max() reproduces it without a select).
+constexpr float kC1 = kBeta * 1.4426950408889634f;   // beta * log2(e)
+constexpr float kC2 = 0.6931471805599453f / kBeta;   // ln2 / beta
+__device__ __forceinline__ float softplus_f(float z) {
+  const float t = __builtin_amdgcn_exp2f(fminf(kC1 * z, 30.f));
+  return fmaxf(z, kC2 * __builtin_amdgcn_logf(1.f + t));
+}
+__device__ __forceinline__ float softplus_s1(float z, float& s1) {   // also sigma'(z) = t/(1+t)
+  const float t = __builtin_amdgcn_exp2f(fminf(kC1 * z, 30.f));
+  const float u = 1.f + t;
+  s1 = t * __builtin_amdgcn_rcpf(u);
+  return fmaxf(z, kC2 * __builtin_amdgcn_logf(u));
 }
 // sigma'(z) recovered from the stored activation: 1 - exp(-beta a)
-__device__ __forceinline__ float s1_from_a(float a) { return 1.f - __expf(-kBeta * a); }
+__device__ __forceinline__ float s1_from_a(float a) { return 1.f - __builtin_amdgcn_exp2f(-kC1 * a); }
 
 template <int HD, int EP, bool F16, int MODE>
-__global__ __launch_bounds__(256, 2) void chain_kernel(const ChainParams p) {
+__global__ __launch_bounds__(CHAIN_NW * 64, 4) void chain_kernel(const ChainParams p) {
   typedef Tile<HD, EP> T;
   static_assert(HD == EP, "tile kernels assume padded embedding width == hidden width");
   constexpr int BM = T::BM, FB = T::FB, PB = T::PB, ROWB = T::ROWB;
@@ -131,6 +180,7 @@ __global__ __launch_bounds__(256, 2) void chain_kernel(const ChainParams p) {
   const uint16_t* setBwdA = p.shadow + L.setBwdA;
   const uint16_t* setBwdB = p.shadow + L.setBwdB;
   uint16_t* spillTile = p.spill + (int64_t)blockIdx.x * BM * HD;
+  float* vecTile = MODE == 2 ? p.vec_part + (int64_t)blockIdx.x * p.vecStride : nullptr;
   (void)setFwdB; (void)setBwdB; (void)spillTile;
 
   // ------------------------------------------------------------------ PE stage
@@ -139,7 +189,7 @@ __global__ __launch_bounds__(256, 2) void chain_kernel(const ChainParams p) {
   // spill (dW operand A_0).
   {
     const int pt = tid & (BM - 1), prt = tid / BM;
-    constexpr int NPART = 256 / BM;
+    constexpr int NPART = (T::NW * 64) / BM;
     const int64_t n = n0 + pt;
     float x0 = 0.f, x1 = 0.f, x2 = 0.f;
     if (n < P) { x0 = p.pts[n * 3]; x1 = p.pts[n * 3 + 1]; x2 = p.pts[n * 3 + 2]; }
@@ -169,7 +219,7 @@ __global__ __launch_bounds__(256, 2) void chain_kernel(const ChainParams p) {
       }
     }
   }
-  __syncthreads();
+  lds_barrier();
   auto spill_region = [&](int colElemBase, uint16_t* dstTile) {
     // copy a bf16 [BM][HD] region of X to global in frag16 order (16 B per lane)
 #pragma unroll
@@ -187,7 +237,7 @@ __global__ __launch_bounds__(256, 2) void chain_kernel(const ChainParams p) {
   };
   if (MODE == 2) {
     spill_region(0, spillTile + p.sp.A[0]);
-    __syncthreads();
+    lds_barrier();
   }
 
   // ------------------------------------------------------------------ forward
@@ -210,8 +260,22 @@ __global__ __launch_bounds__(256, 2) void chain_kernel(const ChainParams p) {
       }
   };
   auto for_blocks = [&](auto&& fn) { for_blocks2(fn, [](int) {}); };
-  auto load_tile8 = [&](int64_t tensorOff, int fb, int pb, int qp, float (&o)[8]) {
-    const uint4 u = *(const uint4*)(spillTile + tensorOff + frag16_off<FB, PB>(w, fb, pb, qp, lane));
+  // A spilled tile is re-read by the same lanes that wrote it; the reads are
+  // issued BEFORE the layer's GEMM (prefetch) and consumed in its epilogue.
+  struct Pre { uint4 v[FB][2][PB]; };
+  const int laneChunk = frag16_off<FB, PB>(w, 0, 0, 0, lane) / 8;   // uint4 index of this lane's first piece
+  auto chunkOf = [](int fb, int pb, int qp) { return ((fb * PB + pb) * 2 + qp) * 64; };   // compile-time
+  auto prefetch = [&](int64_t tensorOff, Pre& pr) {
+    const uint4* base = (const uint4*)(spillTile + tensorOff) + laneChunk;
+#pragma unroll
+    for (int fb = 0; fb < FB; ++fb)
+#pragma unroll
+      for (int qp = 0; qp < 2; ++qp)
+#pragma unroll
+        for (int pb = 0; pb < PB; ++pb) pr.v[fb][qp][pb] = base[chunkOf(fb, pb, qp)];
+  };
+  auto load_tile8 = [&](const Pre& pr, int fb, int pb, int qp, float (&o)[8]) {
+    const uint4 u = pr.v[fb][qp][pb];
     float a[4], b[4];
     unpack4_bf16(make_uint2(u.x, u.y), a); unpack4_bf16(make_uint2(u.z, u.w), b);
 #pragma unroll
@@ -219,7 +283,7 @@ __global__ __launch_bounds__(256, 2) void chain_kernel(const ChainParams p) {
   };
   auto store_tile8 = [&](int64_t tensorOff, int fb, int pb, int qp, const float (&v)[8]) {
     const uint2 a = pack4<false>(v[0], v[1], v[2], v[3]), b = pack4<false>(v[4], v[5], v[6], v[7]);
-    *(uint4*)(spillTile + tensorOff + frag16_off<FB, PB>(w, fb, pb, qp, lane)) = make_uint4(a.x, a.y, b.x, b.y);
+    ((uint4*)(spillTile + tensorOff) + laneChunk)[chunkOf(fb, pb, qp)] = make_uint4(a.x, a.y, b.x, b.y);
   };
   auto put_x = [&](bool f16, int row, int f0, const float (&v)[8], int colElemBase) {
     uint2 a, b;
@@ -236,46 +300,67 @@ __global__ __launch_bounds__(256, 2) void chain_kernel(const ChainParams p) {
   for (int li = 0; li < L.L; ++li) {
     zero_acc(acc);
     if (li == 0)
-      gemm<F16, EP / 16, FB, PB, ROWB>(acc, wptr(setFwdA, L.fwdMat[0], EP), (EP / 16) * 64, X, HD * 2, lane);
+      gemm<F16, EP / 16, FB, PB, ROWB>(acc, wptr(setFwdA, L.fwdMat[0], EP), (EP / 16) * 64, X, HD * 2, lane, [] {});
     else if (li == L.cat)
-      gemm<F16, (HD + EP) / 16, FB, PB, ROWB>(acc, wptr(setFwdA, L.fwdMat[li], HD + EP), ((HD + EP) / 16) * 64, X, 0, lane);
+      gemm<F16, (HD + EP) / 16, FB, PB, ROWB>(acc, wptr(setFwdA, L.fwdMat[li], HD + EP), ((HD + EP) / 16) * 64, X, 0, lane, [] {});
     else
-      gemm<F16, HD / 16, FB, PB, ROWB>(acc, wptr(setFwdA, L.fwdMat[li], HD), (HD / 16) * 64, X, 0, lane);
-    __syncthreads();  // all waves finished reading region 1
+      gemm<F16, HD / 16, FB, PB, ROWB>(acc, wptr(setFwdA, L.fwdMat[li], HD), (HD / 16) * 64, X, 0, lane, [] {});
+    lds_barrier();  // all waves finished reading region 1
     const float* bias = p.params + L.offB[li];
     const bool last = li == L.L - 1;
     const float* wout = p.params + L.offWout;
-    for_blocks([&](int fb, int pb, int qp, int f0, int row) {
-      float a[8], pl[8];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const int f = f0 + (e & 3) + 8 * (e >> 2);
-        float s1;
-        a[e] = softplus_f(acc[fb][pb][8 * qp + e] + bias[f], s1);
-        if (last) {
-          rawp[pb] += wout[f] * a[e];
-          pl[e] = so * wout[f] * s1;   // p_L = q_L * sigma'(z_L), q_L = so * w_out
+    if (!last) {
+      float bv[8];
+      for_blocks2([&](int fb, int pb, int qp, int f0, int row) {
+        if (pb == 0) {
+          const float4 b0 = *(const float4*)(bias + f0), b1 = *(const float4*)(bias + f0 + 8);
+          bv[0] = b0.x; bv[1] = b0.y; bv[2] = b0.z; bv[3] = b0.w; bv[4] = b1.x; bv[5] = b1.y; bv[6] = b1.z; bv[7] = b1.w;
         }
-      }
-      if (MODE >= 1) store_tile8(p.sp.A[li + 1], fb, pb, qp, a);
-      if (!last) put_x(F16, row, f0, a, 0);
-      else if (MODE >= 1) {
-        put_x(F16, row, f0, pl, 0);
-        if (MODE == 2) store_tile8(p.sp.P[li], fb, pb, qp, pl);
-      }
-    });
+        float a[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a[e] = softplus_f(acc[fb][pb][8 * qp + e] + bv[e]);
+        if (MODE >= 1) store_tile8(p.sp.A[li + 1], fb, pb, qp, a);
+        put_x(F16, row, f0, a, 0);
+      }, [](int) {});
+    } else {
+      float bv[8], wv[8];
+      for_blocks2([&](int fb, int pb, int qp, int f0, int row) {
+        if (pb == 0) {
+          const float4 b0 = *(const float4*)(bias + f0), b1 = *(const float4*)(bias + f0 + 8);
+          const float4 w0 = *(const float4*)(wout + f0), w1 = *(const float4*)(wout + f0 + 8);
+          bv[0] = b0.x; bv[1] = b0.y; bv[2] = b0.z; bv[3] = b0.w; bv[4] = b1.x; bv[5] = b1.y; bv[6] = b1.z; bv[7] = b1.w;
+          wv[0] = w0.x; wv[1] = w0.y; wv[2] = w0.z; wv[3] = w0.w; wv[4] = w1.x; wv[5] = w1.y; wv[6] = w1.z; wv[7] = w1.w;
+        }
+        float a[8], pl[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float s1;
+          a[e] = softplus_s1(acc[fb][pb][8 * qp + e] + bv[e], s1);
+          rawp[pb] += wv[e] * a[e];
+          pl[e] = so * wv[e] * s1;   // p_L = q_L * sigma'(z_L), q_L = so * w_out
+        }
+        if (MODE >= 1) {
+          store_tile8(p.sp.A[li + 1], fb, pb, qp, a);
+          put_x(F16, row, f0, pl, 0);
+          if (MODE == 2) store_tile8(p.sp.P[li], fb, pb, qp, pl);
+        }
+      }, [](int) {});
+    }
     if (last) {
 #pragma unroll
-      for (int pb = 0; pb < PB; ++pb) part[((w * 2 + hi) * BM + pb * 32 + j) * 4] = rawp[pb];
+      for (int pb = 0; pb < PB; ++pb) {
+        const float v = rawp[pb] + __shfl_xor(rawp[pb], 32, 64);   // add the two feature halves
+        if (hi == 0) part[(w * BM + pb * 32 + j) * 4] = v;
+      }
     }
-    __syncthreads();
+    lds_barrier();
   }
   // sdf = (raw + noise) * so   (fc_map.py:104-109)
   float my_sdf = 0.f;
   if (tid < BM) {
     float r = p.params[L.offBout];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) r += part[(k * BM + tid) * 4];
+    for (int k = 0; k < T::NW; ++k) r += part[(k * BM + tid) * 4];
     const int64_t n = n0 + tid;
     if (p.noise && n < P) r += p.noise[n];
     my_sdf = r * so;
@@ -285,24 +370,26 @@ __global__ __launch_bounds__(256, 2) void chain_kernel(const ChainParams p) {
 
   // ------------------------------------------------------------------ first reverse sweep
   for (int li = L.L - 1; li >= 1; --li) {
+    Pre preA;
     zero_acc(acc);
-    gemm<F16, HD / 16, FB, PB, ROWB>(acc, wptr(setBwdA, L.bwdMat[li], HD), (HD / 16) * 64, X, 0, lane);
-    __syncthreads();
+    gemm<F16, HD / 16, FB, PB, ROWB>(acc, wptr(setBwdA, L.bwdMat[li], HD), (HD / 16) * 64, X, 0, lane,
+                                     [&] { prefetch(p.sp.A[li], preA); });
+    lds_barrier();
     const bool toR2 = (li - 1 == L.cat);
     for_blocks([&](int fb, int pb, int qp, int f0, int row) {
       float a[8], pv[8];
-      load_tile8(p.sp.A[li], fb, pb, qp, a);
+      load_tile8(preA, fb, pb, qp, a);
 #pragma unroll
       for (int e = 0; e < 8; ++e) pv[e] = acc[fb][pb][8 * qp + e] * s1_from_a(a[e]);
       put_x(F16, row, f0, pv, 0);
       if (toR2) put_x(F16, row, f0, pv, HD);
       if (MODE == 2) store_tile8(p.sp.P[li - 1], fb, pb, qp, pv);
     });
-    __syncthreads();
+    lds_barrier();
   }
   // Eg = [W_in^T | W_cat[:,HD:]^T] [p_0 ; p_cat]   (rows = embedding features)
   zero_acc(acc);
-  gemm<F16, (2 * HD) / 16, FB, PB, ROWB>(acc, wptr(setBwdA, L.bwdG, 2 * HD), ((2 * HD) / 16) * 64, X, 0, lane);
+  gemm<F16, (2 * HD) / 16, FB, PB, ROWB>(acc, wptr(setBwdA, L.bwdG, 2 * HD), ((2 * HD) / 16) * 64, X, 0, lane, [] {});
   // g_x' = J_pe^T Eg : contract the wave's 64 embedding rows against d emb / d x'
   {
     float g0[PB], g1[PB], g2[PB];
@@ -334,14 +421,18 @@ __global__ __launch_bounds__(256, 2) void chain_kernel(const ChainParams p) {
           }
         }
       }
-    __syncthreads();  // part[] reuse; X reads of the G gemm complete
+    lds_barrier();  // part[] reuse; X reads of the G gemm complete
 #pragma unroll
     for (int pb = 0; pb < PB; ++pb) {
-      float* d = part + ((w * 2 + hi) * BM + pb * 32 + j) * 4;
-      d[0] = g0[pb]; d[1] = g1[pb]; d[2] = g2[pb];
+      const float a0 = g0[pb] + __shfl_xor(g0[pb], 32, 64), a1 = g1[pb] + __shfl_xor(g1[pb], 32, 64),
+                  a2 = g2[pb] + __shfl_xor(g2[pb], 32, 64);
+      if (hi == 0) {
+        float* d = part + (w * BM + pb * 32 + j) * 4;
+        d[0] = a0; d[1] = a1; d[2] = a2;
+      }
     }
   }
-  __syncthreads();
+  lds_barrier();
 
   // ------------------------------------------------------------------ loss + adjoints (one thread per point)
   float lsum[4] = {0.f, 0.f, 0.f, 0.f};
@@ -349,7 +440,7 @@ __global__ __launch_bounds__(256, 2) void chain_kernel(const ChainParams p) {
     const int64_t n = n0 + tid;
     float e0 = 0.f, e1 = 0.f, e2 = 0.f;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
+    for (int k = 0; k < T::NW; ++k) {
       const float* s = part + (k * BM + tid) * 4;
       e0 += s[0]; e1 += s[1]; e2 += s[2];
     }
@@ -423,7 +514,7 @@ __global__ __launch_bounds__(256, 2) void chain_kernel(const ChainParams p) {
       }
       lsum[3] = tot;
       if (p.tot_loss_mat) p.tot_loss_mat[n] = tot;
-      atomicAdd(p.ray_loss + ray, tot);
+      p.tot_ws[n] = tot;
     }
     if (MODE == 2) {
       // gbar in x' space: x' = si (R x + t)  =>  gbar_x' = si * R gbar_x
@@ -447,12 +538,12 @@ __global__ __launch_bounds__(256, 2) void chain_kernel(const ChainParams p) {
       p.wg_loss[(int64_t)blockIdx.x * 8 + 4] = (float)(rem < BM ? rem : BM);
     }
   }
-  __syncthreads();
+  lds_barrier();
 
   // ------------------------------------------------------------------ Ebar = J_pe gbar  -> region 2 (bf16)
   {
     const int pt = tid & (BM - 1), prt = tid / BM;
-    constexpr int NPART = 256 / BM;
+    constexpr int NPART = (T::NW * 64) / BM;
     const float y0 = xs[pt * 4], y1 = xs[pt * 4 + 1], y2 = xs[pt * 4 + 2];
     const float b0 = gbs[pt * 4], b1 = gbs[pt * 4 + 1], b2 = gbs[pt * 4 + 2];
     char* row = X + pt * ROWB;
@@ -474,27 +565,29 @@ __global__ __launch_bounds__(256, 2) void chain_kernel(const ChainParams p) {
       }
     }
   }
-  __syncthreads();
+  lds_barrier();
   spill_region(HD, spillTile + p.sp.GB[0]);
 
   // ------------------------------------------------------------------ adjoint of the first reverse sweep (upward)
   for (int li = 0; li < L.L; ++li) {
+    Pre preA, preP;
+    auto pf = [&] { prefetch(p.sp.A[li + 1], preA); prefetch(p.sp.P[li], preP); };
     zero_acc(acc);
     if (li == 0)
-      gemm<false, EP / 16, FB, PB, ROWB>(acc, wptr(setFwdB, L.fwdMat[0], EP), (EP / 16) * 64, X, HD * 2, lane);
+      gemm<false, EP / 16, FB, PB, ROWB>(acc, wptr(setFwdB, L.fwdMat[0], EP), (EP / 16) * 64, X, HD * 2, lane, pf);
     else if (li == L.cat)
-      gemm<false, (HD + EP) / 16, FB, PB, ROWB>(acc, wptr(setFwdB, L.fwdMat[li], HD + EP), ((HD + EP) / 16) * 64, X, 0, lane);
+      gemm<false, (HD + EP) / 16, FB, PB, ROWB>(acc, wptr(setFwdB, L.fwdMat[li], HD + EP), ((HD + EP) / 16) * 64, X, 0, lane, pf);
     else
-      gemm<false, HD / 16, FB, PB, ROWB>(acc, wptr(setFwdB, L.fwdMat[li], HD), (HD / 16) * 64, X, 0, lane);
-    __syncthreads();
+      gemm<false, HD / 16, FB, PB, ROWB>(acc, wptr(setFwdB, L.fwdMat[li], HD), (HD / 16) * 64, X, 0, lane, pf);
+    lds_barrier();
     const bool last = li == L.L - 1;
     float qsum[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) qsum[e] = 0.f;
     for_blocks2([&](int fb, int pb, int qp, int f0, int row) {
       float a[8], pv[8], qb[8], inj[8];
-      load_tile8(p.sp.A[li + 1], fb, pb, qp, a);
-      load_tile8(p.sp.P[li], fb, pb, qp, pv);
+      load_tile8(preA, fb, pb, qp, a);
+      load_tile8(preP, fb, pb, qp, pv);
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const float u = acc[fb][pb][8 * qp + e];
@@ -512,12 +605,12 @@ __global__ __launch_bounds__(256, 2) void chain_kernel(const ChainParams p) {
       if (last) {  // d w_out += so * sum_pts qbar_L
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          half_wave_atomic(so * qsum[e], p.grad + L.offWout + f0 + (e & 3) + 8 * (e >> 2), lane);
+          half_wave_store(so * qsum[e], vecTile + L.L * HD + f0 + (e & 3) + 8 * (e >> 2), lane);
           qsum[e] = 0.f;
         }
       }
     });
-    __syncthreads();
+    lds_barrier();
   }
 
   // ------------------------------------------------------------------ ordinary reverse sweep with injection
@@ -527,27 +620,30 @@ __global__ __launch_bounds__(256, 2) void chain_kernel(const ChainParams p) {
       float v = gbs[tid * 4 + 3];
 #pragma unroll
       for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-      if (lane == 0) atomicAdd(p.grad + L.offBout, v);
+      if (lane == 0) vecTile[L.L * HD + 2 * HD] = v;
     }
     for (int li = L.L - 1; li >= 0; --li) {
       const bool top = li == L.L - 1;
+      Pre preA, preI;
+      auto pf = [&] { prefetch(p.sp.A[li + 1], preA); prefetch(p.sp.INJ[li], preI); };
       if (!top) {
         zero_acc(acc);
-        gemm<false, HD / 16, FB, PB, ROWB>(acc, wptr(setBwdB, L.bwdMat[li + 1], HD), (HD / 16) * 64, X, 0, lane);
-        __syncthreads();
+        gemm<false, HD / 16, FB, PB, ROWB>(acc, wptr(setBwdB, L.bwdMat[li + 1], HD), (HD / 16) * 64, X, 0, lane, pf);
+        lds_barrier();
+      } else {
+        pf();
       }
       float bsum[8], wsum[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) { bsum[e] = 0.f; wsum[e] = 0.f; }
       for_blocks2([&](int fb, int pb, int qp, int f0, int row) {
         float a[8], inj[8], zb[8];
-        load_tile8(p.sp.A[li + 1], fb, pb, qp, a);
-        load_tile8(p.sp.INJ[li], fb, pb, qp, inj);
+        load_tile8(preA, fb, pb, qp, a);
+        load_tile8(preI, fb, pb, qp, inj);
         const float sb = gbs[row * 4 + 3];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          const int f = f0 + (e & 3) + 8 * (e >> 2);
-          const float ab = top ? sb * wout[f] : acc[fb][pb][8 * qp + e];
+          const float ab = top ? sb * wout[f0 + (e & 3) + 8 * (e >> 2)] : acc[fb][pb][8 * qp + e];
           zb[e] = ab * s1_from_a(a[e]) + inj[e];
           bsum[e] += zb[e];
           if (top) wsum[e] += sb * a[e];
@@ -558,12 +654,12 @@ __global__ __launch_bounds__(256, 2) void chain_kernel(const ChainParams p) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const int f = f0 + (e & 3) + 8 * (e >> 2);
-          half_wave_atomic(bsum[e], p.grad + L.offB[li] + f, lane);
-          if (top) half_wave_atomic(wsum[e], p.grad + L.offWout + f, lane);
+          half_wave_store(bsum[e], vecTile + li * HD + f, lane);
+          if (top) half_wave_store(wsum[e], vecTile + L.L * HD + HD + f, lane);
           bsum[e] = 0.f; wsum[e] = 0.f;
         }
       });
-      __syncthreads();
+      lds_barrier();
     }
   }
 }
@@ -572,7 +668,7 @@ __global__ __launch_bounds__(256, 2) void chain_kernel(const ChainParams p) {
 template <int MODE>
 static int launch_mode(const ChainParams& p, int64_t nTiles, hipStream_t st) {
   typedef Tile<256, 256> T;
-  dim3 grid((unsigned)nTiles), block(256);
+  dim3 grid((unsigned)nTiles), block(CHAIN_NW * 64);
   if (p.lay.fwd_f16) {
     auto k = chain_kernel<256, 256, true, MODE>;
     if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES) != hipSuccess) return ISDF_EHIP;

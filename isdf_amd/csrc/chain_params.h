@@ -19,9 +19,10 @@ struct ChainParams {
   const float* pc_bounds; const float* pc_grad_vec;
   // outputs
   float* sdf; float* sdf_grad; float* tot_loss_mat;
-  float* ray_loss;            // [maxRays] atomically accumulated
+  float* tot_ws;              // [maxPts] per-point total loss (train)
   float* wg_loss;             // [nTiles][8]
-  float* grad;                // flat fp32 gradient SUMS (bias / out-layer parts use atomics)
+  float* vec_part;            // [nTiles][vecStride] bias / out-layer gradient partials (no atomics)
+  int32_t vecStride;
   uint16_t* spill; SpillLayout sp;
 };
 
@@ -31,6 +32,14 @@ struct DwParams {
   const uint16_t* spill;
   const int32_t* n_valid; int64_t n_points_host; int32_t S;
   float* dwPart;   // [units][DW_SPLITK][HD*HD]
+};
+
+struct ReduceParams {
+  NetLayout lay;
+  const float* dwPart;
+  const float* vecPart; int32_t vecStride;
+  const int32_t* n_valid; int32_t S;
+  float* grad;
 };
 
 }  // namespace isdf

@@ -29,7 +29,7 @@ template <int HD> struct DwTile {
 // frag16 chunk c (16 B = 8 elems) of a [BM][HD] tile -> (pt, f0): elems 0..3 at
 // features f0.., elems 4..7 at f0+8..   (inverse of chain.hip frag16_off)
 template <int HD> __device__ __forceinline__ void frag16_decode(int c, int& pt, int& f0) {
-  constexpr int FB = HD / 128, PB = TILE_PTS / 32;
+  constexpr int FB = HD / (CHAIN_NW * 32), PB = TILE_PTS / 32;
   const int lane = c & 63; int r = c >> 6;
   const int qp = r & 1; r >>= 1;
   const int pb = r % PB; r /= PB;
@@ -146,25 +146,62 @@ __global__ __launch_bounds__(512, 2) void dw_kernel(const DwParams p) {
       }
 }
 
-// Sum the K-split slabs into the flat gradient (weights only; biases and the
-// output layer were accumulated by chain.hip with atomics).
-__global__ void dw_reduce_kernel(NetLayout L, const float* __restrict__ dwPart, float* __restrict__ grad) {
+// Sum the K-split dW slabs and the per-workgroup bias / out-layer partials into
+// the flat gradient (every gradient element is written exactly once).
+__global__ void dw_reduce_kernel(const ReduceParams p) {
+  const NetLayout& L = p.lay;
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int HD = L.HD;
   const int64_t perUnit = (int64_t)HD * HD;
-  const int unit = (int)(idx / perUnit);
-  if (unit > L.L) return;
-  const int rem = (int)(idx - unit * perUnit);
-  const int o = rem / HD, i = rem - o * HD;
-  const int li = unit < L.L ? unit : L.cat;
-  const bool embHalf = unit == L.L;
-  const int width = (li == 0 || embHalf) ? L.E : HD;
-  if (i >= width) return;
-  float s = 0.f;
-  const float* src = dwPart + (int64_t)unit * DW_SPLITK * perUnit + rem;
+  const int64_t nW = (int64_t)(L.L + 1) * perUnit;
+  if (idx < nW) {
+    const int unit = (int)(idx / perUnit);
+    const int rem = (int)(idx - unit * perUnit);
+    const int o = rem / HD, i = rem - o * HD;
+    const int li = unit < L.L ? unit : L.cat;
+    const bool embHalf = unit == L.L;
+    const int width = (li == 0 || embHalf) ? L.E : HD;
+    if (i >= width) return;
+    float s = 0.f;
+    const float* src = p.dwPart + (int64_t)unit * DW_SPLITK * perUnit + rem;
 #pragma unroll 4
-  for (int k = 0; k < DW_SPLITK; ++k) s += src[(int64_t)k * perUnit];
-  grad[L.offW[li] + (int64_t)o * L.K[li] + (embHalf ? HD : 0) + i] = s;
+    for (int k = 0; k < DW_SPLITK; ++k) s += src[(int64_t)k * perUnit];
+    p.grad[L.offW[li] + (int64_t)o * L.K[li] + (embHalf ? HD : 0) + i] = s;
+  }
+}
+
+// biases (L*HD), w_out (HD), b_out (1): sum the per-workgroup partials.  256
+// threads = 64 parameters x 4 tile groups so the loads of a block are
+// independent (a single thread walking all tiles is latency-bound).
+__global__ __launch_bounds__(1024) void vec_reduce_kernel(const ReduceParams p) {
+  __shared__ float sh[16][64];
+  const NetLayout& L = p.lay;
+  const int HD = L.HD;
+  const int pi = threadIdx.x & 63, g = threadIdx.x >> 6;     // 16 tile groups
+  const int v = blockIdx.x * 64 + pi;
+  const int nVec = L.L * HD + HD + 1;
+  const int64_t P = (int64_t)(*p.n_valid) * p.S;
+  const int nTiles = (int)((P + TILE_PTS - 1) / TILE_PTS);
+  int slotA = 0, slotB = -1, dst = -1;
+  if (v < L.L * HD) { slotA = v; dst = L.offB[v / HD] + v % HD; }
+  else if (v < L.L * HD + HD) { slotA = v; slotB = v + HD; dst = L.offWout + (v - L.L * HD); }
+  else if (v < nVec) { slotA = L.L * HD + 2 * HD; dst = L.offBout; }
+  float s = 0.f;
+  if (dst >= 0) {
+    for (int t = g; t < nTiles; t += 16) {
+      const float* row = p.vecPart + (int64_t)t * p.vecStride;
+      s += row[slotA];
+      if (slotB >= 0) s += row[slotB];
+    }
+  }
+  sh[g][pi] = s;
+  __syncthreads();
+  if (g == 0 && dst >= 0) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += sh[k][pi];
+    p.grad[dst] = t;
+  }
 }
 
 int launch_dw(const DwParams& p, hipStream_t st) {
@@ -176,9 +213,12 @@ int launch_dw(const DwParams& p, hipStream_t st) {
   return hipGetLastError() == hipSuccess ? ISDF_OK : ISDF_EHIP;
 }
 
-int launch_dw_reduce(const NetLayout& L, const float* dwPart, float* grad, hipStream_t st) {
+int launch_dw_reduce(const ReduceParams& p, hipStream_t st) {
+  const NetLayout& L = p.lay;
   const int64_t total = (int64_t)dw_units(L) * L.HD * L.HD;
-  hipLaunchKernelGGL(dw_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, L, dwPart, grad);
+  hipLaunchKernelGGL(dw_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, p);
+  const int nVec = L.L * L.HD + L.HD + 1;
+  hipLaunchKernelGGL(vec_reduce_kernel, dim3((unsigned)((nVec + 63) / 64)), dim3(1024), 0, st, p);
   return hipGetLastError() == hipSuccess ? ISDF_OK : ISDF_EHIP;
 }
 

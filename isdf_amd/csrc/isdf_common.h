@@ -10,6 +10,7 @@ namespace isdf {
 constexpr int MAXL = 16;       // max hidden layers (2B+2)
 constexpr int N_DIRS = 21;     // icosahedron directions, embedding.py:40-62
 constexpr int TILE_PTS = 64;   // points per chain-kernel workgroup (BM)
+constexpr int CHAIN_NW = 8;    // waves per chain-kernel workgroup (each owns HD/CHAIN_NW features)
 constexpr int DW_SPLITK = 36;  // K-splits per dW unit (7 units x 36 = 252 workgroups)
 
 // Vector types for the 16-bit MFMA operands.
@@ -61,7 +62,9 @@ struct WorkspaceLayout {
   int64_t offRayLoss;    // float [maxRays]
   int64_t offWgLoss;     // float [nTiles][8]
   int64_t offDwPart;     // float [units][DW_SPLITK][HD*HD]
-  int64_t offGxs;        // float [maxPts*3] scratch (inference: unused)
+  int64_t offVecPart;    // float [nTiles][vecStride]: per-workgroup bias / out-layer gradient partials
+  int64_t offTotLoss;    // float [maxPts] per-point total loss
+  int32_t vecStride;
   int64_t totalBytes;
 };
 
@@ -125,7 +128,9 @@ inline void make_workspace(const NetLayout& l, int64_t maxPts, int64_t maxRays, 
   w->offRayLoss = b; b += (train ? maxRays : 0) * 4; b = (b + 255) / 256 * 256;
   w->offWgLoss = b; b += (train ? w->nTiles * 8 : 0) * 4; b = (b + 255) / 256 * 256;
   w->offDwPart = b; b += train ? (int64_t)dw_units(l) * DW_SPLITK * l.HD * l.HD * 4 : 0; b = (b + 255) / 256 * 256;
-  w->offGxs = b;
+  w->vecStride = round_up(l.L * l.HD + 2 * l.HD + 8, 64);   // [db_0..db_{L-1} | dwout(adjoint) | dwout(reverse) | dbout]
+  w->offVecPart = b; b += train ? w->nTiles * (int64_t)w->vecStride * 4 : 0; b = (b + 255) / 256 * 256;
+  w->offTotLoss = b; b += train ? maxPts * 4 : 0; b = (b + 255) / 256 * 256;
   w->totalBytes = b + 256;
 }
 
@@ -146,7 +151,7 @@ template <> struct Op<true> {
   static __device__ __forceinline__ f32x16 mfma(v8 a, v8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
   }
-  static __device__ __forceinline__ float clampf(float x) { return fminf(fmaxf(x, -65504.f), 65504.f); }
+  static __device__ __forceinline__ float clampf(float x) { return x; }
 };
 template <> struct Op<false> {
   typedef bf16x8 v8; typedef bf16x4 v4; typedef __bf16 e;

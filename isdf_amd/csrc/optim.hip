@@ -88,50 +88,79 @@ __global__ void pack_kernel(NetLayout L, const float* __restrict__ P, uint16_t* 
 }
 
 // ---- loss sums + 8x8 block-loss bins ------------------------------------------
-// One workgroup.  (a) deterministic sum of the per-tile loss partials;
-// (b) per ray: drop it if a LATER ray of the batch hits the same pixel (the
-// reference scatters into a dense image, loss.py:229 -- last writer wins, the
-// pixel counts once), else add its loss to the (frame, 8x8 block) bin.
+// Block 0: deterministic sum of the per-tile loss partials.  Block 1+f: frame f.
+// The reference scatters per-ray loss sums into a dense [F,H,W] image and a
+// 0/1 mask (loss.py:225-229, sample.py:58-61): duplicate pixels -> the LAST ray
+// wins and the pixel counts once.  Here the frame's rays (contiguous in the
+// compacted, frame-sorted ray list) are staged in LDS as packed pixel keys, each
+// ray is dropped if a later ray has its key, and the survivors are binned with
+// LDS atomics; each frame's 64 bins are then written once (no global atomics).
+constexpr int FIN_CAP = 12288;   // rays per frame staged in LDS (48 KB)
 __global__ __launch_bounds__(1024) void finalize_kernel(const float* __restrict__ wg_loss, int64_t maxTiles,
-                                                        const int32_t* __restrict__ n_valid, int64_t n_points_host,
-                                                        int S, const float* __restrict__ ray_loss,
+                                                        const int32_t* __restrict__ n_valid, int S,
+                                                        const float* __restrict__ tot_ws,
                                                         const int64_t* __restrict__ ib, const int64_t* __restrict__ ih,
                                                         const int64_t* __restrict__ iw, int n_frames, int H, int W,
                                                         float* __restrict__ loss_sums, float* __restrict__ block_loss,
                                                         float* __restrict__ block_cnt) {
   __shared__ float sh[16][8];
+  __shared__ float binS[64], binC[64];
+  __shared__ int range[2];
+  __shared__ uint32_t keys[FIN_CAP];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int64_t P = n_valid ? (int64_t)(*n_valid) * S : n_points_host;
-  const int64_t R = P / S;
-  const int64_t nTiles = (P + TILE_PTS - 1) / TILE_PTS;
-  float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
-  for (int64_t t = tid; t < nTiles && t < maxTiles; t += 1024)
+  const int64_t R = *n_valid;
+  const int64_t P = R * S;
+  if (blockIdx.x == 0) {
+    const int64_t nTiles = (P + TILE_PTS - 1) / TILE_PTS;
+    float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int64_t t = tid; t < nTiles && t < maxTiles; t += 1024)
 #pragma unroll
-    for (int k = 0; k < 5; ++k) acc[k] += wg_loss[t * 8 + k];
+      for (int k = 0; k < 5; ++k) acc[k] += wg_loss[t * 8 + k];
 #pragma unroll
-  for (int k = 0; k < 5; ++k) {
-    float v = acc[k];
+    for (int k = 0; k < 5; ++k) {
+      float v = acc[k];
 #pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-    if (lane == 0) sh[wv][k] = v;
+      for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+      if (lane == 0) sh[wv][k] = v;
+    }
+    __syncthreads();
+    if (tid < 8) {
+      float v = 0.f;
+      if (tid < 5) for (int k = 0; k < 16; ++k) v += sh[k][tid];
+      loss_sums[tid] = v;
+    }
+    return;
+  }
+  const int f = blockIdx.x - 1;
+  if (tid < 2) {  // lower_bound(indices_b, f + tid): rays are sorted by frame
+    int64_t lo = 0, hi = R;
+    const int64_t key = f + tid;
+    while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (ib[mid] < key) lo = mid + 1; else hi = mid; }
+    range[tid] = (int)lo;
+  }
+  if (tid < 64) { binS[tid] = 0.f; binC[tid] = 0.f; }
+  __syncthreads();
+  const int lo = range[0], n = range[1] - range[0];
+  const bool staged = n <= FIN_CAP;
+  if (staged) for (int r = tid; r < n; r += 1024) keys[r] = ((uint32_t)ih[lo + r] << 16) | (uint32_t)iw[lo + r];
+  __syncthreads();
+  const int hb = H / 8, wb = W / 8;
+  for (int r = tid; r < n; r += 1024) {
+    const uint32_t h = (uint32_t)ih[lo + r], w = (uint32_t)iw[lo + r];
+    const uint32_t key = (h << 16) | w;
+    bool dup = false;
+    if (staged) { for (int q = r + 1; q < n; ++q) dup |= keys[q] == key; }
+    else { for (int q = r + 1; q < n; ++q) dup |= ((((uint32_t)ih[lo + q]) << 16) | (uint32_t)iw[lo + q]) == key; }
+    if (dup) continue;
+    float s = 0.f;
+    const float* tp = tot_ws + (int64_t)(lo + r) * S;
+    for (int k = 0; k < S; ++k) s += tp[k];               // total_loss_mat.sum(-1), loss.py:229
+    const int bin = (int)((h / hb) * 8 + (w / wb));
+    atomicAdd(&binS[bin], s);
+    atomicAdd(&binC[bin], 1.f);
   }
   __syncthreads();
-  if (tid < 5) {
-    float v = 0.f;
-    for (int k = 0; k < 16; ++k) v += sh[k][tid];
-    loss_sums[tid] = v;
-  }
-  const int hb = H / 8, wb = W / 8;
-  for (int64_t r = tid; r < R; r += 1024) {
-    const int64_t b = ib[r], h = ih[r], w = iw[r];
-    bool dup = false;
-    for (int64_t q = r + 1; q < R && ib[q] == b; ++q)
-      if (ih[q] == h && iw[q] == w) { dup = true; break; }
-    if (dup) continue;
-    const int bin = (int)(b * 64 + (h / hb) * 8 + (w / wb));
-    atomicAdd(block_loss + bin, ray_loss[r]);
-    atomicAdd(block_cnt + bin, 1.f);
-  }
+  if (tid < 64) { block_loss[f * 64 + tid] = binS[tid]; block_cnt[f * 64 + tid] = binC[tid]; }
 }
 
 __global__ void frame_avg_kernel(const float* __restrict__ block_loss, const float* __restrict__ block_cnt,
@@ -196,11 +225,11 @@ int launch_pack(const NetLayout& L, const float* params, uint16_t* shadow, hipSt
   hipLaunchKernelGGL(pack_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, st, L, params, shadow);
   return hipGetLastError() == hipSuccess ? ISDF_OK : ISDF_EHIP;
 }
-int launch_finalize(const float* wg_loss, int64_t maxTiles, const int32_t* n_valid, int64_t nph, int S,
-                    const float* ray_loss, const int64_t* ib, const int64_t* ih, const int64_t* iw, int F, int H,
-                    int W, float* loss_sums, float* bl, float* bc, hipStream_t st) {
-  hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(1024), 0, st, wg_loss, maxTiles, n_valid, nph, S, ray_loss, ib,
-                     ih, iw, F, H, W, loss_sums, bl, bc);
+int launch_finalize(const float* wg_loss, int64_t maxTiles, const int32_t* n_valid, int S, const float* tot_ws,
+                    const int64_t* ib, const int64_t* ih, const int64_t* iw, int F, int H, int W, float* loss_sums,
+                    float* bl, float* bc, hipStream_t st) {
+  hipLaunchKernelGGL(finalize_kernel, dim3(1 + F), dim3(1024), 0, st, wg_loss, maxTiles, n_valid, S, tot_ws, ib, ih,
+                     iw, F, H, W, loss_sums, bl, bc);
   return hipGetLastError() == hipSuccess ? ISDF_OK : ISDF_EHIP;
 }
 int launch_frame_avg(const float* bl, const float* bc, int F, float* la, float* fa, hipStream_t st) {
