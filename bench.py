@@ -151,7 +151,7 @@ def main():
     import __graft_entry__
     __graft_entry__.build(verbose=False)
     from isdf_amd.trainer import HipTrainer, FrameData
-    from isdf_amd import synthetic
+    from isdf_amd import synthetic, dp
 
     cfg = reference_config()
     cfg["sample"]["n_rays"] = args.rays_per_frame
@@ -182,11 +182,11 @@ def main():
 
     def one_step(i, ev=None):
         s = eng.sample(tr.frames.depth_batch, tr.frames.T_WC_batch, tr.frames.normal_batch, fidx, fidx, sc,
-                       seed=1 + 7919 * rank, offset=i)
+                       seed=dp.rank_seed(1, rank), offset=i)
         noise_buf.normal_(0.0, tr.noise_std)                      # fc_map.py:106-108
         eng.train_step(s, lc, sc, noise=noise_buf, prof_events=ev)
         if group is not None:
-            torch.distributed.all_reduce(eng.reduce_buf, group=group)
+            dp.allreduce_(eng.reduce_buf, group)
         tr.optimiser.step()
         la, fa = eng.frame_avg(F)
         tr.frames.frame_avg_losses[fidx.long()] = fa            # trainer.py:979
@@ -219,7 +219,7 @@ def main():
     nv = []
     for i in range(min(K, 50)):
         s = eng.sample(tr.frames.depth_batch, tr.frames.T_WC_batch, tr.frames.normal_batch, fidx, fidx, sc,
-                       seed=1 + 7919 * rank, offset=W + i)
+                       seed=dp.rank_seed(1, rank), offset=W + i)
         nv.append(int(s["n_valid"].item()))
     P = float(np.mean(nv)) * S
     ls = eng.loss_sums().cpu().numpy()

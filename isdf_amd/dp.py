@@ -1,0 +1,55 @@
+"""Data-parallel protocol of the training step: rays shard over ranks,
+every rank fills the same flat fp32 buffer with SUMS (never means)
+
+    [ grad sums (n_params) | loss sums (8: sdf, grad, eik, total, count, -, -, -) |
+      block_loss (F*64) | block_cnt (F*64) ]
+
+and ONE all-reduce(sum) over it (RCCL on GPUs; gloo in the CPU tests) makes
+gradients, logged losses and the per-frame block averages global.  AdamW then
+divides the summed gradient by the reduced element count, which reproduces the
+single-process `mean` exactly even when ranks drop different numbers of
+invalid-depth rays (sample.py:39-55).  No other collective is on the step path;
+keyframe selection stays identical across ranks because its inputs
+(frame_avg_losses from the reduced bins, the numpy seed) are identical.
+"""
+import torch
+
+LS_SDF, LS_GRAD, LS_EIK, LS_TOTAL, LS_COUNT = 0, 1, 2, 3, 4
+N_LOSS = 8
+
+
+def layout(n_params, n_frames):
+    """slices of the flat reduction buffer"""
+    o = n_params
+    return dict(grad=slice(0, o), loss=slice(o, o + N_LOSS),
+                block_loss=slice(o + N_LOSS, o + N_LOSS + 64 * n_frames),
+                block_cnt=slice(o + N_LOSS + 64 * n_frames, o + N_LOSS + 128 * n_frames),
+                total=o + N_LOSS + 128 * n_frames)
+
+
+def allreduce_(buf, group=None):
+    """in-place sum over ranks of the flat buffer (no-op without a process group)"""
+    if group is None and not (torch.distributed.is_available() and torch.distributed.is_initialized()):
+        return buf
+    torch.distributed.all_reduce(buf, op=torch.distributed.ReduceOp.SUM, group=group)
+    return buf
+
+
+def finish(buf, n_params, n_frames):
+    """What the step does with the reduced buffer: mean gradient, mean losses,
+    block averages (loss.py:208-240).  Used by the CPU protocol tests; on the GPU
+    the same arithmetic is inside isdf_adamw / isdf_frame_avg."""
+    L = layout(n_params, n_frames)
+    cnt = buf[L["loss"]][LS_COUNT]
+    grad = buf[L["grad"]] / cnt
+    losses = {k: buf[L["loss"]][i] / cnt for k, i in
+              (("sdf_loss", LS_SDF), ("grad_loss", LS_GRAD), ("eikonal_loss", LS_EIK), ("total_loss", LS_TOTAL))}
+    bc = buf[L["block_cnt"]].clone()
+    bc[bc == 0] = 1.0
+    approx = (buf[L["block_loss"]] / bc).view(n_frames, 8, 8)
+    return grad, losses, approx, approx.sum(dim=(1, 2)) / 64.0
+
+
+def rank_seed(seed, rank):
+    """rank-distinct Philox key for the sampler (each rank draws its own rays)"""
+    return int(seed) + 7919 * int(rank)

@@ -21,7 +21,7 @@ import time
 import numpy as np
 import torch
 
-from . import _ffi
+from . import _ffi, dp
 from .engine import LossConfig, SampleConfig
 from .modules import PositionalEncodingHIP, SDFMapHIP
 
@@ -281,7 +281,7 @@ class HipTrainer:
         rank = 0 if self.dist_group is None else torch.distributed.get_rank(self.dist_group)
         self._draw_count = getattr(self, "_draw_count", 0) + 1
         return eng.sample(depth_batch, T_WC_batch, norm_batch, frame_idx, normal_idx, sc,
-                          seed=self.seed + 7919 * rank, offset=self._draw_count, want_T=True)
+                          seed=dp.rank_seed(self.seed, rank), offset=self._draw_count, want_T=True)
 
     def sample_points(self, depth_batch, T_WC_batch, norm_batch=None, active_loss_approx=None, n_rays=None,
                       dist_behind_surf=None, n_strat_samples=None, n_surf_samples=None, _idx=None):
@@ -317,7 +317,7 @@ class HipTrainer:
                 noise = torch.randn(s["max_rays"], sc.S, device=self.device) * self.noise_std
         self.engine.train_step(s, self._loss_cfg(), sc, noise=noise)
         if self.dist_group is not None:   # sums over ranks; AdamW divides by the reduced count
-            torch.distributed.all_reduce(self.engine.reduce_buf, group=self.dist_group)
+            dp.allreduce_(self.engine.reduce_buf, self.dist_group)
         ls = self.engine.loss_sums()
         losses = LazyLosses(ls, self.grad_weight != 0, self.eik_weight != 0)
         total_loss = ls[_ffi.LS_TOTAL] / ls[_ffi.LS_COUNT]
