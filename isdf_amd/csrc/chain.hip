@@ -42,8 +42,8 @@ struct Tile {
   static constexpr int OFF_XS = XBYTES;                   // [BM][4] x' (scaled/transformed point)
   static constexpr int OFF_PART = OFF_XS + BM * 16;       // [NW][BM][4] partial sums (raw / g)
   static constexpr int OFF_GB = OFF_PART + NW * BM * 16;   // [BM][4] gbar in x' space, [3] = sbar*so
-  static constexpr int OFF_RED = OFF_GB + BM * 16;        // [8] block loss sums
-  static constexpr int LDS_BYTES = OFF_RED + 64;
+  static constexpr int OFF_RED = OFF_GB + BM * 16;        // [BM/64][8] per-wave loss sums
+  static constexpr int LDS_BYTES = OFF_RED + (BM / 64) * 32 + 32;
 };
 
 // Workgroup barrier that only waits for this wave's LDS traffic.  The global
@@ -61,9 +61,12 @@ __device__ __forceinline__ int swz(int row, int colbytes) { return colbytes ^ ((
 // C[FB*32 feats][PB*32 pts] += Wpacked[feat][k] * X[pt][k]  over KSTEPS*16 k.
 // Weight fragments come straight from L2 (~500-800 cycles away): the loop is a
 // real (not unrolled) loop over stages of KS k-steps whose next-stage fragments
-// are requested before the current stage's MFMAs, so one stage of MFMA time
-// (KS*FBN*PBN*32 cycles) covers the load latency and the compiler cannot hoist
-// loads beyond one stage (register budget).
+// are requested before the current stage's MFMAs.  NOTE (measured):
+// the `cur = nxt` copy makes the compiler wait for the prefetch at the end of
+// every iteration, so the overlap is partial; a ping-pong variant with pinned
+// issue order overlaps properly but costs ~90 more spilled VGPRs in the train
+// kernel at the 128-register budget and was slower end-to-end -- the GEMM phase
+// is bound by the per-CU L2->L1 weight stream (~50 B/clk/CU) either way.
 template <bool F16, int KSTEPS, int FBN, int PBN, int ROWB, typename Hook>
 __device__ __forceinline__ void gemm(f32x16 (&acc)[FBN][PBN], const uint4* __restrict__ wp,
                                      int rbStride, const char* xl, int colByteBase, int lane, Hook&& lateHook) {
@@ -174,12 +177,18 @@ __global__ __launch_bounds__(CHAIN_NW * 64, 4) void chain_kernel(const ChainPara
   if (n0 >= P) return;
   const int nf = L.n_freqs;
   const float so = L.scale_output;
+  int tsn = 0;
+  auto TS = [&]() {   // debug timeline: wave 0 of workgroup 100 stamps phase boundaries
+    if (p.dbg_times && blockIdx.x == 100 && tid == 0) p.dbg_times[tsn] = __builtin_amdgcn_s_memtime();
+    ++tsn;
+  };
+  TS();
 
   const uint16_t* setFwdA = p.shadow + L.setFwdA;
   const uint16_t* setFwdB = p.shadow + L.setFwdB;
   const uint16_t* setBwdA = p.shadow + L.setBwdA;
   const uint16_t* setBwdB = p.shadow + L.setBwdB;
-  uint16_t* spillTile = p.spill + (int64_t)blockIdx.x * BM * HD;
+  uint16_t* spillTile = p.spill + (int64_t)(p.dbg_alias ? (blockIdx.x % p.dbg_alias) : blockIdx.x) * BM * HD;
   float* vecTile = MODE == 2 ? p.vec_part + (int64_t)blockIdx.x * p.vecStride : nullptr;
   (void)setFwdB; (void)setBwdB; (void)spillTile;
 
@@ -305,7 +314,9 @@ __global__ __launch_bounds__(CHAIN_NW * 64, 4) void chain_kernel(const ChainPara
       gemm<F16, (HD + EP) / 16, FB, PB, ROWB>(acc, wptr(setFwdA, L.fwdMat[li], HD + EP), ((HD + EP) / 16) * 64, X, 0, lane, [] {});
     else
       gemm<F16, HD / 16, FB, PB, ROWB>(acc, wptr(setFwdA, L.fwdMat[li], HD), (HD / 16) * 64, X, 0, lane, [] {});
+    TS();
     lds_barrier();  // all waves finished reading region 1
+    TS();
     const float* bias = p.params + L.offB[li];
     const bool last = li == L.L - 1;
     const float* wout = p.params + L.offWout;
@@ -353,7 +364,9 @@ __global__ __launch_bounds__(CHAIN_NW * 64, 4) void chain_kernel(const ChainPara
         if (hi == 0) part[(w * BM + pb * 32 + j) * 4] = v;
       }
     }
+    TS();
     lds_barrier();
+    TS();
   }
   // sdf = (raw + noise) * so   (fc_map.py:104-109)
   float my_sdf = 0.f;
@@ -374,7 +387,9 @@ __global__ __launch_bounds__(CHAIN_NW * 64, 4) void chain_kernel(const ChainPara
     zero_acc(acc);
     gemm<F16, HD / 16, FB, PB, ROWB>(acc, wptr(setBwdA, L.bwdMat[li], HD), (HD / 16) * 64, X, 0, lane,
                                      [&] { prefetch(p.sp.A[li], preA); });
+    TS();
     lds_barrier();
+    TS();
     const bool toR2 = (li - 1 == L.cat);
     for_blocks([&](int fb, int pb, int qp, int f0, int row) {
       float a[8], pv[8];
@@ -385,7 +400,9 @@ __global__ __launch_bounds__(CHAIN_NW * 64, 4) void chain_kernel(const ChainPara
       if (toR2) put_x(F16, row, f0, pv, HD);
       if (MODE == 2) store_tile8(p.sp.P[li - 1], fb, pb, qp, pv);
     });
+    TS();
     lds_barrier();
+    TS();
   }
   // Eg = [W_in^T | W_cat[:,HD:]^T] [p_0 ; p_cat]   (rows = embedding features)
   zero_acc(acc);
@@ -525,20 +542,28 @@ __global__ __launch_bounds__(CHAIN_NW * 64, 4) void chain_kernel(const ChainPara
     }
   }
   if (MODE != 2) return;
-  if (tid < 64) {  // wave 0: block loss sums -> per-workgroup partial (deterministic final sum later)
+  if (tid < BM) {  // per-wave loss / sbar sums -> LDS, one thread combines (deterministic)
+    float v5[5] = {lsum[0], lsum[1], lsum[2], lsum[3], gbs[tid * 4 + 3]};
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      float v = lsum[k];
+    for (int k = 0; k < 5; ++k) {
+      float v = v5[k];
 #pragma unroll
       for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-      if (lane == 0) p.wg_loss[(int64_t)blockIdx.x * 8 + k] = v;
-    }
-    if (lane == 0) {
-      const int64_t rem = P - n0;
-      p.wg_loss[(int64_t)blockIdx.x * 8 + 4] = (float)(rem < BM ? rem : BM);
+      if (lane == 0) red[w * 8 + k] = v;
     }
   }
   lds_barrier();
+  if (tid == 0) {
+    float s[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int q = 0; q < BM / 64; ++q)
+#pragma unroll
+      for (int k = 0; k < 5; ++k) s[k] += red[q * 8 + k];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) p.wg_loss[(int64_t)blockIdx.x * 8 + k] = s[k];
+    const int64_t rem = P - n0;
+    p.wg_loss[(int64_t)blockIdx.x * 8 + 4] = (float)(rem < BM ? rem : BM);
+    vecTile[L.L * HD + 2 * HD] = s[4];   // d b_out = sum sbar*so
+  }
 
   // ------------------------------------------------------------------ Ebar = J_pe gbar  -> region 2 (bf16)
   {
@@ -579,7 +604,9 @@ __global__ __launch_bounds__(CHAIN_NW * 64, 4) void chain_kernel(const ChainPara
       gemm<false, (HD + EP) / 16, FB, PB, ROWB>(acc, wptr(setFwdB, L.fwdMat[li], HD + EP), ((HD + EP) / 16) * 64, X, 0, lane, pf);
     else
       gemm<false, HD / 16, FB, PB, ROWB>(acc, wptr(setFwdB, L.fwdMat[li], HD), (HD / 16) * 64, X, 0, lane, pf);
+    TS();
     lds_barrier();
+    TS();
     const bool last = li == L.L - 1;
     float qsum[8];
 #pragma unroll
@@ -616,12 +643,6 @@ __global__ __launch_bounds__(CHAIN_NW * 64, 4) void chain_kernel(const ChainPara
   // ------------------------------------------------------------------ ordinary reverse sweep with injection
   {
     const float* wout = p.params + L.offWout;
-    if (tid < BM) {  // d b_out = sum sbar*so
-      float v = gbs[tid * 4 + 3];
-#pragma unroll
-      for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-      if (lane == 0) vecTile[L.L * HD + 2 * HD] = v;
-    }
     for (int li = L.L - 1; li >= 0; --li) {
       const bool top = li == L.L - 1;
       Pre preA, preI;

@@ -24,6 +24,8 @@ struct ChainParams {
   float* vec_part;            // [nTiles][vecStride] bias / out-layer gradient partials (no atomics)
   int32_t vecStride;
   uint16_t* spill; SpillLayout sp;
+  int32_t dbg_alias;          // timing experiments only (ISDF_DEBUG_ALIAS_SPILL): alias tiles' spills
+  unsigned long long* dbg_times;  // optional [256] s_memtime stamps of one workgroup (ISDF_DEBUG_TIMELINE)
 };
 
 struct DwParams {

@@ -19,23 +19,25 @@
 namespace isdf {
 
 template <int HD> struct DwTile {
-  static constexpr int BM = TILE_PTS;
+  static constexpr int BM = DW_PTS;
   static constexpr int ROWB = HD * 2 + 64;        // padded LDS row (bytes)
   static constexpr int TEN = BM * ROWB;           // one operand tile in LDS
   static constexpr int LDS_BYTES = 2 * TEN;
   static constexpr int CH = (BM * HD * 2) / (512 * 16);  // uint4 per thread per tensor
 };
 
-// frag16 chunk c (16 B = 8 elems) of a [BM][HD] tile -> (pt, f0): elems 0..3 at
-// features f0.., elems 4..7 at f0+8..   (inverse of chain.hip frag16_off)
-template <int HD> __device__ __forceinline__ void frag16_decode(int c, int& pt, int& f0) {
-  constexpr int FB = HD / (CHAIN_NW * 32), PB = TILE_PTS / 32;
+// Piece c (16 B = 8 elems) of the `half`-th 64-point half of a chain tile in
+// frag16 order (chain.hip): returns the uint4 index inside the tile and the
+// (point-in-half, first feature): elems 0..3 at features f0.., elems 4..7 at f0+8..
+template <int HD> __device__ __forceinline__ int frag16_half(int c, int half, int& pt, int& f0) {
+  constexpr int FB = HD / (CHAIN_NW * 32), PB = TILE_PTS / 32, HB = DW_PTS / 32;   // HB point-blocks per half
   const int lane = c & 63; int r = c >> 6;
   const int qp = r & 1; r >>= 1;
-  const int pb = r % PB; r /= PB;
+  const int pbh = r % HB; r /= HB;
   const int fb = r % FB; const int w = r / FB;
-  pt = pb * 32 + (lane & 31);
+  pt = pbh * 32 + (lane & 31);
   f0 = w * (FB * 32) + fb * 32 + 16 * qp + 4 * (lane >> 5);
+  return ((((w * FB + fb) * PB + half * HB + pbh) * 2 + qp) * 64 + lane);
 }
 
 template <int HD>
@@ -51,7 +53,8 @@ __global__ __launch_bounds__(512, 2) void dw_kernel(const DwParams p) {
   const bool embHalf = unit == L.L;
 
   const int64_t P = p.n_valid ? (int64_t)(*p.n_valid) * p.S : p.n_points_host;
-  const int nTiles = (int)((P + BM - 1) / BM);
+  constexpr int HALVES = TILE_PTS / DW_PTS;
+  const int nTiles = (int)((P + TILE_PTS - 1) / TILE_PTS) * HALVES;   // 64-point half tiles
 
   // stage q of tile t: q=0 -> (ZB[li], I), q=1 -> (P[li], GB)
   const int64_t offZ = p.sp.ZB[li], offP = p.sp.P[li];
@@ -68,21 +71,25 @@ __global__ __launch_bounds__(512, 2) void dw_kernel(const DwParams p) {
 
   const int nStages = split < nTiles ? 2 * ((nTiles - split + DW_SPLITK - 1) / DW_SPLITK) : 0;
   uint4 regA[CH], regB[CH];
+  int curHalf = 0;
   auto issue = [&](int st) {
-    const int t = split + (st >> 1) * DW_SPLITK;
-    const uint16_t* ta = p.spill + ((st & 1) ? offP : offZ) + (int64_t)t * BM * HD;
-    const uint16_t* tb = p.spill + ((st & 1) ? offG : offI) + (int64_t)t * BM * HD;
+    const int u = split + (st >> 1) * DW_SPLITK;      // half-tile index
+    const int t = u / HALVES, half = u % HALVES;
+    const uint4* ta = (const uint4*)(p.spill + ((st & 1) ? offP : offZ) + (int64_t)t * TILE_PTS * HD);
+    const uint4* tb = (const uint4*)(p.spill + ((st & 1) ? offG : offI) + (int64_t)t * TILE_PTS * HD);
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
-      regA[c] = *(const uint4*)(ta + (int64_t)(c * 512 + tid) * 8);
-      regB[c] = *(const uint4*)(tb + (int64_t)(c * 512 + tid) * 8);
+      int pt, f0;
+      const int idx = frag16_half<HD>(c * 512 + tid, half, pt, f0);
+      regA[c] = ta[idx];
+      regB[c] = tb[idx];
     }
   };
   auto commit = [&]() {
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
       int pt, f0;
-      frag16_decode<HD>(c * 512 + tid, pt, f0);
+      frag16_half<HD>(c * 512 + tid, curHalf, pt, f0);
       char* ra = smem + pt * ROWB + f0 * 2;
       *(uint2*)(ra) = make_uint2(regA[c].x, regA[c].y);
       *(uint2*)(ra + 16) = make_uint2(regA[c].z, regA[c].w);

@@ -9,7 +9,8 @@ namespace isdf {
 
 constexpr int MAXL = 16;       // max hidden layers (2B+2)
 constexpr int N_DIRS = 21;     // icosahedron directions, embedding.py:40-62
-constexpr int TILE_PTS = 64;   // points per chain-kernel workgroup (BM)
+constexpr int TILE_PTS = 64;   // points per chain-kernel workgroup (two workgroups per CU)
+constexpr int DW_PTS = 64;     // points per dW-kernel stage (half a chain tile)
 constexpr int CHAIN_NW = 8;    // waves per chain-kernel workgroup (each owns HD/CHAIN_NW features)
 constexpr int DW_SPLITK = 36;  // K-splits per dW unit (7 units x 36 = 252 workgroups)
 
@@ -125,13 +126,13 @@ inline void make_workspace(const NetLayout& l, int64_t maxPts, int64_t maxRays, 
   s.totalElems = o;
   int64_t b = 0;
   w->offSpill = b; b += o * 2; b = (b + 255) / 256 * 256;
-  w->offRayLoss = b; b += (train ? maxRays : 0) * 4; b = (b + 255) / 256 * 256;
+  (void)maxRays; w->offRayLoss = b;
   w->offWgLoss = b; b += (train ? w->nTiles * 8 : 0) * 4; b = (b + 255) / 256 * 256;
   w->offDwPart = b; b += train ? (int64_t)dw_units(l) * DW_SPLITK * l.HD * l.HD * 4 : 0; b = (b + 255) / 256 * 256;
   w->vecStride = round_up(l.L * l.HD + 2 * l.HD + 8, 64);   // [db_0..db_{L-1} | dwout(adjoint) | dwout(reverse) | dbout]
   w->offVecPart = b; b += train ? w->nTiles * (int64_t)w->vecStride * 4 : 0; b = (b + 255) / 256 * 256;
   w->offTotLoss = b; b += train ? maxPts * 4 : 0; b = (b + 255) / 256 * 256;
-  w->totalBytes = b + 256;
+  w->totalBytes = b + 256 + 4096;   // last 4 KB: debug timeline stamps
 }
 
 // ---- device helpers ---------------------------------------------------------
