@@ -176,15 +176,14 @@ def main():
     S = sc.S
     fidx = torch.arange(F, dtype=torch.int32, device=dev)
     max_rays = F * sc.n_rays
-    noise_buf = torch.empty(max_rays, S, device=dev)
     K, W = args.steps, args.warmup
     events = HipEvents(4 * K)
 
     def one_step(i, ev=None):
         s = eng.sample(tr.frames.depth_batch, tr.frames.T_WC_batch, tr.frames.normal_batch, fidx, fidx, sc,
                        seed=dp.rank_seed(1, rank), offset=i)
-        noise_buf.normal_(0.0, tr.noise_std)                      # fc_map.py:106-108
-        eng.train_step(s, lc, sc, noise=noise_buf, prof_events=ev)
+        eng.train_step(s, lc, sc, prof_events=ev, noise_std=tr.noise_std, noise_seed=1 + rank,
+                       noise_offset=i)                              # in-kernel N(0,1)*noise_std (fc_map.py:106-108)
         if group is not None:
             dp.allreduce_(eng.reduce_buf, group)
         tr.optimiser.step()

@@ -165,6 +165,10 @@ typedef struct isdf_step_args {
   const int64_t* indices_h;
   const int64_t* indices_w;
   const float* noise;         /* [max_rays,S] pre-scaled, or NULL              */
+  float noise_std;            /* used when noise == NULL and noise_std != 0:   */
+  uint32_t reserved0;         /* in-kernel Philox N(0,1) * noise_std keyed by  */
+  uint64_t noise_seed;        /* (noise_seed, noise_offset, point)             */
+  uint64_t noise_offset;      /* (fc_map.py:106-108)                            */
   const float* pc_bounds;     /* [max_rays,S]   bounds_method "pc" only        */
   const float* pc_grad_vec;   /* [max_rays,S,3] bounds_method "pc" only        */
 } isdf_step_args;

@@ -60,7 +60,9 @@ class StepArgs(C.Structure):
                 ("pc", C.c_void_p), ("z_vals", C.c_void_p), ("depth_sample", C.c_void_p),
                 ("dirs_C_sample", C.c_void_p), ("dirs_W_sample", C.c_void_p),
                 ("norm_sample", C.c_void_p), ("indices_b", C.c_void_p), ("indices_h", C.c_void_p),
-                ("indices_w", C.c_void_p), ("noise", C.c_void_p), ("pc_bounds", C.c_void_p),
+                ("indices_w", C.c_void_p), ("noise", C.c_void_p), ("noise_std", C.c_float),
+                ("reserved0", C.c_uint32), ("noise_seed", C.c_uint64), ("noise_offset", C.c_uint64),
+                ("pc_bounds", C.c_void_p),
                 ("pc_grad_vec", C.c_void_p)]
 
 

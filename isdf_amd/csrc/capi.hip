@@ -137,6 +137,7 @@ int isdf_train_step(const isdf_net_cfg* net, const isdf_loss_cfg* loss, const fl
   ChainParams p = {};
   p.lay = l; p.loss = *loss; p.params = params; p.shadow = (const uint16_t*)shadow;
   p.pts = a->pc; p.noise = a->noise; p.n_valid = a->n_valid; p.S = a->S;
+  p.noise_std = a->noise_std; p.noise_seed = a->noise_seed; p.noise_off = a->noise_offset;
   p.z_vals = a->z_vals; p.depth = a->depth_sample; p.dirsC = a->dirs_C_sample; p.dirsW = a->dirs_W_sample;
   p.normals = a->norm_sample; p.pc_bounds = a->pc_bounds; p.pc_grad_vec = a->pc_grad_vec;
   p.sdf = o->sdf; p.sdf_grad = o->sdf_grad; p.tot_loss_mat = o->tot_loss_mat;

@@ -375,7 +375,13 @@ __global__ __launch_bounds__(CHAIN_NW * 64, 4) void chain_kernel(const ChainPara
 #pragma unroll
     for (int k = 0; k < T::NW; ++k) r += part[(k * BM + tid) * 4];
     const int64_t n = n0 + tid;
-    if (p.noise && n < P) r += p.noise[n];
+    if (p.noise) { if (n < P) r += p.noise[n]; }
+    else if (p.noise_std != 0.f) {   // Box-Muller on Philox4x32-10 keyed by (seed, offset, point)
+      const uint4 u = philox4x32_10(make_uint4((uint32_t)n, (uint32_t)(n >> 32), (uint32_t)p.noise_off, (uint32_t)(p.noise_off >> 32)),
+                                    make_uint2((uint32_t)p.noise_seed, (uint32_t)(p.noise_seed >> 32) ^ 0x5eedu));
+      const float u1 = fmaxf(u01(u.x), 1e-7f), u2 = u01(u.y);
+      r += p.noise_std * sqrtf(-2.f * __logf(u1)) * __cosf(6.2831853f * u2);
+    }
     my_sdf = r * so;
     if (p.sdf && n < P) p.sdf[n] = my_sdf;
   }

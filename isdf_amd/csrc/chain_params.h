@@ -11,6 +11,7 @@ struct ChainParams {
   const uint16_t* shadow;
   const float* pts;           // [P,3]
   const float* noise;         // [P] or null
+  float noise_std; uint64_t noise_seed, noise_off;   // in-kernel Philox noise when noise == null
   const int32_t* n_valid;     // device: rays (points = n_valid*S); null -> n_points_host
   int64_t n_points_host;
   int32_t S;

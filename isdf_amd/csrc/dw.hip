@@ -193,13 +193,26 @@ __global__ __launch_bounds__(1024) void vec_reduce_kernel(const ReduceParams p) 
   if (v < L.L * HD) { slotA = v; dst = L.offB[v / HD] + v % HD; }
   else if (v < L.L * HD + HD) { slotA = v; slotB = v + HD; dst = L.offWout + (v - L.L * HD); }
   else if (v < nVec) { slotA = L.L * HD + 2 * HD; dst = L.offBout; }
-  float s = 0.f;
+  float s = 0.f, s2 = 0.f;
   if (dst >= 0) {
-    for (int t = g; t < nTiles; t += 16) {
+    int t = g;
+    for (; t + 48 < nTiles; t += 64) {      // 4 independent loads in flight per thread
+      const float* r0 = p.vecPart + (int64_t)t * p.vecStride;
+      const float a0 = r0[slotA], a1 = r0[(int64_t)16 * p.vecStride + slotA],
+                  a2 = r0[(int64_t)32 * p.vecStride + slotA], a3 = r0[(int64_t)48 * p.vecStride + slotA];
+      s += (a0 + a1) + (a2 + a3);
+      if (slotB >= 0) {
+        const float b0 = r0[slotB], b1 = r0[(int64_t)16 * p.vecStride + slotB],
+                    b2 = r0[(int64_t)32 * p.vecStride + slotB], b3 = r0[(int64_t)48 * p.vecStride + slotB];
+        s2 += (b0 + b1) + (b2 + b3);
+      }
+    }
+    for (; t < nTiles; t += 16) {
       const float* row = p.vecPart + (int64_t)t * p.vecStride;
       s += row[slotA];
-      if (slotB >= 0) s += row[slotB];
+      if (slotB >= 0) s2 += row[slotB];
     }
+    s += s2;
   }
   sh[g][pi] = s;
   __syncthreads();

@@ -243,7 +243,8 @@ class Engine:
         return sdf.view(*shp)
 
     # ---- training step ----------------------------------------------------------
-    def train_step(self, smp, lc: LossConfig, sc: SampleConfig, noise=None, debug=False, prof_events=None):
+    def train_step(self, smp, lc: LossConfig, sc: SampleConfig, noise=None, debug=False, prof_events=None,
+                   noise_std=0.0, noise_seed=0, noise_offset=0):
         """Everything between sampling and the optimiser.  Fills self.reduce_buf with
         [grad sums | loss sums(8) | block_loss | block_cnt]; returns debug tensors."""
         dev = self.device
@@ -261,6 +262,7 @@ class Engine:
             setattr(a, k, smp[k].data_ptr())
         a.norm_sample = None if smp.get("norm_sample") is None else smp["norm_sample"].data_ptr()
         keep = []
+        a.noise_std, a.noise_seed, a.noise_offset = float(noise_std), int(noise_seed), int(noise_offset)
         if noise is not None:
             if (noise.numel() == R0 * S and noise.dtype == torch.float32 and noise.device == dev
                     and noise.is_contiguous()):

@@ -313,9 +313,13 @@ class HipTrainer:
             if self.rng == "torch":
                 R = sample["pc"].shape[0]
                 noise = torch.randn(R, sc.S, device=self.device) * self.noise_std
-            else:
-                noise = torch.randn(s["max_rays"], sc.S, device=self.device) * self.noise_std
-        self.engine.train_step(s, self._loss_cfg(), sc, noise=noise)
+        kw = {}
+        if noise is None and self.noise_std is not None:   # philox mode: noise drawn inside the kernel
+            self._noise_count = getattr(self, "_noise_count", 0) + 1
+            rank = 0 if self.dist_group is None else torch.distributed.get_rank(self.dist_group)
+            kw = dict(noise_std=self.noise_std, noise_seed=dp.rank_seed(self.seed, rank),
+                      noise_offset=self._noise_count)
+        self.engine.train_step(s, self._loss_cfg(), sc, noise=noise, **kw)
         if self.dist_group is not None:   # sums over ranks; AdamW divides by the reduced count
             dp.allreduce_(self.engine.reduce_buf, self.dist_group)
         ls = self.engine.loss_sums()

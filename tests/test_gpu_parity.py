@@ -260,3 +260,56 @@ def test_three_full_steps_track_oracle():
         moved = np.linalg.norm(params[k].astype(np.float64) - init[k])
         drift = np.linalg.norm(got - params[k]) / moved
         assert drift < 0.25, (k, drift)
+
+
+def test_in_kernel_noise_is_standard_normal_and_deterministic():
+    """Fast path: the raw-output noise (fc_map.py:106-108) is drawn inside the kernel
+    (Philox + Box-Muller).  sdf_noisy - sdf_clean = so * noise_std * N(0,1)."""
+    g = gu.load("eval_full_ray")
+    eng = _engine(g)
+    lc, sc = _cfgs(g)
+    s = _sample_hip(eng, g, sc)
+    R = g["depth_sample"].shape[0]
+    clean = eng.train_step(s, lc, sc, debug=True)["sdf"][:R].clone()
+    n1 = eng.train_step(s, lc, sc, debug=True, noise_std=0.25, noise_seed=3, noise_offset=7)["sdf"][:R].clone()
+    n2 = eng.train_step(s, lc, sc, debug=True, noise_std=0.25, noise_seed=3, noise_offset=7)["sdf"][:R].clone()
+    n3 = eng.train_step(s, lc, sc, debug=True, noise_std=0.25, noise_seed=3, noise_offset=8)["sdf"][:R].clone()
+    assert torch.equal(n1, n2)
+    assert not torch.equal(n1, n3)
+    z = ((n1 - clean) / (0.14 * 0.25)).cpu().numpy().ravel()
+    assert abs(z.mean()) < 0.08 and abs(z.std() - 1.0) < 0.05, (z.mean(), z.std())
+    assert np.abs(z).max() < 6.0
+
+
+def test_hip_trainer_step_contract():
+    """Host mirror: HipTrainer.step returns (losses, step_time_ms) with the reference's keys/types
+    and side effects (trainer.py:951-1016), K > window exercises select_keyframes."""
+    from isdf_amd.trainer import HipTrainer, FrameData
+    from isdf_amd import synthetic
+    import bench
+    cam = dict(synthetic.SCANNET_CAM)
+    cfg = bench.reference_config()
+    cfg["dataset"]["camera"] = {"w": cam["W"], "h": cam["H"], "fx": cam["fx"], "fy": cam["fy"], "cx": cam["cx"], "cy": cam["cy"]}
+    depth, normal, T = synthetic.keyframes(7, cam, seed=2, stride=30)
+    np.random.seed(1); torch.manual_seed(1)
+    for rng in ("philox", "torch"):
+        tr = HipTrainer("cuda", cfg, inv_bounds_transform=synthetic.bounds_transform(), rng=rng)
+        tr.frames = FrameData(frame_id=np.arange(7), depth_batch=_dev(depth), T_WC_batch=_dev(T),
+                              normal_batch=_dev(normal), frame_avg_losses=torch.rand(7, device="cuda") + 0.5)
+        first = None
+        for i in range(25):
+            losses, ms = tr.step()
+            assert set(losses.keys()) == {"sdf_loss", "grad_loss", "eikonal_loss", "total_loss"}
+            assert isinstance(losses["sdf_loss"], float) and torch.is_tensor(losses["total_loss"])
+            "{:.6f}".format(losses["total_loss"])
+            first = first or losses["total_loss"].item()
+        assert len(tr.active_idxs) == 5 and list(tr.active_idxs[-2:]) == [5, 6]
+        assert tr.active_pixels["indices_b"].dtype == torch.int64
+        assert ms > 0 and tr.tot_step_time > 0 and tr.steps_since_frame == 25
+        assert losses["total_loss"].item() < first          # it learns
+        sd = tr.sdf_map.state_dict()
+        assert "in_layer.0.weight" in sd and sd["cat_layer.0.weight"].shape == (256, 511)
+        assert set(tr.optimiser.state_dict()["state"][0].keys()) == {"step", "exp_avg", "exp_avg_sq"}
+        frozen = __import__("copy").deepcopy(tr.sdf_map)     # trainer.py:576
+        x = torch.rand(100, 3, device="cuda")
+        assert torch.equal(frozen(x), tr.sdf_map(x))
