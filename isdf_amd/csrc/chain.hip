@@ -56,6 +56,16 @@ __device__ __forceinline__ void lds_barrier() {
   asm volatile("" ::: "memory");
 }
 
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 nt_load16(const uint4* p) {
+  const u32x4 v = __builtin_nontemporal_load((const u32x4*)p);
+  return make_uint4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ void nt_store16(uint4 x, uint4* p) {
+  u32x4 v; v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w;
+  __builtin_nontemporal_store(v, (u32x4*)p);
+}
+
 __device__ __forceinline__ int swz(int row, int colbytes) { return colbytes ^ ((row & 15) << 4); }
 
 // C[FB*32 feats][PB*32 pts] += Wpacked[feat][k] * X[pt][k]  over KSTEPS*16 k.
@@ -241,7 +251,7 @@ __global__ __launch_bounds__(CHAIN_NW * 64, 4) void chain_kernel(const ChainPara
           const int f0 = w * (FB * 32) + fb * 32 + 16 * qp + 4 * hi;
           uint2 lo = *(const uint2*)(X + rowi * ROWB + swz(rowi, (colElemBase + f0) * 2));
           uint2 hi2 = *(const uint2*)(X + rowi * ROWB + swz(rowi, (colElemBase + f0 + 8) * 2));
-          *(uint4*)(dstTile + frag16_off<FB, PB>(w, fb, pb, qp, lane)) = make_uint4(lo.x, lo.y, hi2.x, hi2.y);
+          nt_store16(make_uint4(lo.x, lo.y, hi2.x, hi2.y), (uint4*)(dstTile + frag16_off<FB, PB>(w, fb, pb, qp, lane)));
         }
   };
   if (MODE == 2) {
@@ -281,7 +291,7 @@ __global__ __launch_bounds__(CHAIN_NW * 64, 4) void chain_kernel(const ChainPara
 #pragma unroll
       for (int qp = 0; qp < 2; ++qp)
 #pragma unroll
-        for (int pb = 0; pb < PB; ++pb) pr.v[fb][qp][pb] = base[chunkOf(fb, pb, qp)];
+        for (int pb = 0; pb < PB; ++pb) pr.v[fb][qp][pb] = nt_load16(base + chunkOf(fb, pb, qp));
   };
   auto load_tile8 = [&](const Pre& pr, int fb, int pb, int qp, float (&o)[8]) {
     const uint4 u = pr.v[fb][qp][pb];
@@ -292,7 +302,8 @@ __global__ __launch_bounds__(CHAIN_NW * 64, 4) void chain_kernel(const ChainPara
   };
   auto store_tile8 = [&](int64_t tensorOff, int fb, int pb, int qp, const float (&v)[8]) {
     const uint2 a = pack4<false>(v[0], v[1], v[2], v[3]), b = pack4<false>(v[4], v[5], v[6], v[7]);
-    ((uint4*)(spillTile + tensorOff) + laneChunk)[chunkOf(fb, pb, qp)] = make_uint4(a.x, a.y, b.x, b.y);
+    // streamed once: non-temporal so the spill stream does not evict the L2-resident weight copies
+    nt_store16(make_uint4(a.x, a.y, b.x, b.y), (uint4*)(spillTile + tensorOff) + laneChunk + chunkOf(fb, pb, qp));
   };
   auto put_x = [&](bool f16, int row, int f0, const float (&v)[8], int colElemBase) {
     uint2 a, b;
