@@ -201,6 +201,22 @@ int isdf_bounds_pc(const int32_t* n_valid, int32_t max_rays, int32_t S, const fl
 int isdf_frame_avg(const float* reduce_buf, int64_t n_params, int32_t n_frames,
                    float* loss_approx, float* frame_avg_loss, void* stream);
 
+/* ---- per-frame ingest and keyframe test ("next" tier) ------------
+ * isdf_estimate_normals: transform.pointcloud_from_depth_torch +
+ * estimate_pointcloud_normals (transform.py:169-196,215-270) as run by
+ * Trainer.get_data (trainer.py:553-557): depth [H,W] (0 = invalid) -> camera-frame
+ * unit normals [H,W,3] (NaN where the 8-neighbour stencil has no valid pair).   */
+int isdf_estimate_normals(const float* depth, int32_t H, int32_t W, float fx, float fy, float cx,
+                          float cy, float* normals, void* stream);
+
+/* isdf_render_depth: the keyframe test of Trainer.is_keyframe (trainer.py:597-609):
+ * per ray sort the S samples by z, render.sdf_render_depth (render.py:12-35), and
+ * count rays with |view - depth| / depth < kf_dist_th.  n_valid (device) or, when
+ * NULL, n_rays_host rays; depth_sample / below_count may be NULL (render only).  */
+int isdf_render_depth(const int32_t* n_valid, int64_t n_rays_host, int64_t max_rays, int32_t S,
+                      const float* z_vals, const float* sdf, const float* depth_sample,
+                      float kf_dist_th, float* view_depth, int32_t* below_count, void* stream);
+
 /* ---- fused flat AdamW + operand-copy refresh -------------------------------
  * Replaces torch.optim.AdamW.step (trainer.py:435-439,982): decoupled weight
  * decay on all parameters, bias-corrected moments.  grad_scale multiplies the

@@ -17,7 +17,7 @@ SYMBOLS = [
     "isdf_abi_version", "isdf_error_string", "isdf_param_count", "isdf_shadow_bytes",
     "isdf_workspace_bytes", "isdf_reduce_floats", "isdf_pack_weights", "isdf_sample_pixels",
     "isdf_sample_along_rays", "isdf_sdf_eval", "isdf_train_step", "isdf_bounds_pc",
-    "isdf_frame_avg", "isdf_adamw",
+    "isdf_frame_avg", "isdf_adamw", "isdf_estimate_normals", "isdf_render_depth",
 ]
 
 LS_SDF, LS_GRAD, LS_EIK, LS_TOTAL, LS_COUNT = 0, 1, 2, 3, 4
@@ -106,6 +106,8 @@ def lib():
     L.isdf_bounds_pc.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp, vp]
     L.isdf_frame_avg.argtypes = [vp, i64, i32, vp, vp, vp]
     L.isdf_adamw.argtypes = [P(NetCfg), vp, vp, vp, vp, vp, f32, f32, f32, f32, f32, f32, i32, vp, vp]
+    L.isdf_estimate_normals.argtypes = [vp, i32, i32, f32, f32, f32, f32, vp, vp]
+    L.isdf_render_depth.argtypes = [vp, i64, i64, i32, vp, vp, vp, f32, vp, vp, vp]
     for n in SYMBOLS[6:]:
         getattr(L, n).restype = C.c_int
     if L.isdf_abi_version() != ABI_VERSION:

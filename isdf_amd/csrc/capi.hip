@@ -22,6 +22,11 @@ int launch_finalize(const float* wg_loss, int64_t maxTiles, const int32_t* n_val
 int launch_frame_avg(const float* bl, const float* bc, int F, float* la, float* fa, hipStream_t st);
 int launch_bounds_pc(const int32_t* n_valid, int max_rays, int S, const float* pc, const float* z, const float* depth,
                      float* bounds, float* gv, hipStream_t st);
+int launch_normals(const float* depth, int H, int W, float fx, float fy, float cx, float cy, float* normals,
+                   hipStream_t st);
+int launch_render_depth(const int32_t* n_valid, int64_t n_host, int64_t max_rays, int S, const float* z,
+                        const float* sdf, const float* depth_sample, float th, float* view, int32_t* below,
+                        hipStream_t st);
 }  // namespace isdf
 
 extern "C" {
@@ -182,6 +187,21 @@ int isdf_frame_avg(const float* reduce_buf, int64_t n_params, int32_t n_frames, 
   if (!reduce_buf || !loss_approx || !frame_avg_loss || n_frames < 1 || n_params < 0) return ISDF_EINVAL;
   const float* bl = reduce_buf + n_params + 8;
   return launch_frame_avg(bl, bl + (int64_t)n_frames * 64, n_frames, loss_approx, frame_avg_loss, (hipStream_t)stream);
+}
+
+int isdf_estimate_normals(const float* depth, int32_t H, int32_t W, float fx, float fy, float cx, float cy,
+                          float* normals, void* stream) {
+  if (!depth || !normals || H < 1 || W < 1 || fx == 0.f || fy == 0.f) return ISDF_EINVAL;
+  return launch_normals(depth, H, W, fx, fy, cx, cy, normals, (hipStream_t)stream);
+}
+
+int isdf_render_depth(const int32_t* n_valid, int64_t n_rays_host, int64_t max_rays, int32_t S, const float* z_vals,
+                      const float* sdf, const float* depth_sample, float kf_dist_th, float* view_depth,
+                      int32_t* below_count, void* stream) {
+  if (!z_vals || !sdf || !view_depth || S < 1 || max_rays < 1) return ISDF_EINVAL;
+  if (!n_valid && (n_rays_host < 0 || n_rays_host > max_rays)) return ISDF_EINVAL;
+  return launch_render_depth(n_valid, n_rays_host, max_rays, S, z_vals, sdf, depth_sample, kf_dist_th, view_depth,
+                             below_count, (hipStream_t)stream);
 }
 
 int isdf_adamw(const isdf_net_cfg* net, float* params, float* exp_avg, float* exp_avg_sq, const float* grad_sum,

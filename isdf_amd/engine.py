@@ -313,6 +313,25 @@ class Engine:
                                            _ffi.ptr(fa), _stream()), "isdf_frame_avg")
         return la, fa
 
+    # ---- per-frame ingest / keyframe test -------------------------------
+    def estimate_normals(self, depth, sc: "SampleConfig"):
+        """depth [H,W] -> camera-frame normals [H,W,3] (trainer.py:553-557)."""
+        d = depth.to(device=self.device, dtype=torch.float32).contiguous()
+        out = torch.empty(d.shape[0], d.shape[1], 3, dtype=torch.float32, device=self.device)
+        _ffi.check(self.lib.isdf_estimate_normals(_ffi.ptr(d), d.shape[0], d.shape[1], sc.fx, sc.fy, sc.cx, sc.cy,
+                                                  _ffi.ptr(out), _stream()), "isdf_estimate_normals")
+        return out
+
+    def render_depth(self, z_vals, sdf, depth_sample=None, kf_dist_th=0.1, n_valid=None):
+        """(view_depth [R], below_count int32[1]) of Trainer.is_keyframe (trainer.py:597-609)."""
+        R, S = z_vals.shape
+        view = torch.zeros(R, dtype=torch.float32, device=self.device)
+        below = torch.zeros(1, dtype=torch.int32, device=self.device)
+        _ffi.check(self.lib.isdf_render_depth(_ffi.ptr(n_valid), R, R, S, _ffi.ptr(z_vals.contiguous()),
+                                              _ffi.ptr(sdf.contiguous()), _ffi.ptr(depth_sample), float(kf_dist_th),
+                                              _ffi.ptr(view), _ffi.ptr(below), _stream()), "isdf_render_depth")
+        return view, below
+
     # ---- AdamW ----------------------------------------------------------------------
     def adamw(self, lr=0.0013, weight_decay=0.012, betas=(0.9, 0.999), eps=1e-8, grad_scale=1.0,
               use_device_count=True):

@@ -185,6 +185,7 @@ class HipTrainer:
         self.hidden_layers_block, self.hidden_feature_size = m["hidden_layers_block"], m["hidden_feature_size"]
         self.frac_time_perception = m["frac_time_perception"]
         self.iters_per_kf, self.iters_per_frame = m["iters_per_kf"], m["iters_per_frame"]
+        self.kf_dist_th, self.kf_pixel_ratio = m.get("kf_dist_th", 0.1), m.get("kf_pixel_ratio", 0.65)
         self.scale_input = m["embedding"]["scale_input"]
         self.n_embed_funcs = m["embedding"]["n_embed_funcs"]
         lo = c["loss"]
@@ -240,6 +241,57 @@ class HipTrainer:
         self.last_is_keyframe = False
         self.optim_frames = self.iters_per_frame
         self.noise_std = self.noise_frame
+
+    # ---- per-frame ingest (trainer.py:530-562) -----------------------------------------
+    def make_frame(self, frame_id, depth, T_WC, im=None):
+        """`Trainer.get_data` for one frame already in memory: device tensors + normals from
+        the HIP stencil kernel (reference: pointcloud_from_depth_torch + estimate_pointcloud_normals,
+        trainer.py:553-557).  depth [H,W] metres (0 = invalid), T_WC [4,4]."""
+        depth = torch.as_tensor(depth, dtype=torch.float32).to(self.device)[None, ...]
+        T = torch.as_tensor(T_WC, dtype=torch.float32).to(self.device)[None, ...]
+        normals = None
+        if self.do_normal:
+            normals = self.engine.estimate_normals(depth[0], self._sample_cfg())[None, ...]
+        return FrameData(frame_id=np.array([frame_id]), depth_batch=depth, T_WC_batch=T, normal_batch=normals,
+                         im_batch=im)
+
+    # ---- keyframe test (trainer.py:586-650) ------------------------------------------------
+    def is_keyframe(self, T_WC, depth_gt):
+        sample_pts = self.sample_points(depth_gt, T_WC, n_rays=self.n_rays_is_kf, dist_behind_surf=0.8)
+        s = sample_pts["_raw"]
+        pc = s["pc"]
+        noise = None
+        if self.noise_std is not None:
+            noise = torch.randn(pc.shape[:-1], device=self.device) * self.noise_std
+        sdf = self.frozen_sdf_map.engine.sdf_eval(pc, noise=noise)           # frozen net, no grad (trainer.py:594-595)
+        view, below = self.engine.render_depth(s["z_vals"], sdf, s["depth_sample"], self.kf_dist_th,
+                                               n_valid=s["n_valid"])
+        n = int(s["n_valid"].item())
+        below_th_prop = float(below.item()) / max(n, 1)
+        is_keyframe = below_th_prop < self.kf_pixel_ratio
+        print("Proportion of loss below threshold", below_th_prop, "for KF should be less than",
+              self.kf_pixel_ratio, " ---> is keyframe:", is_keyframe)
+        return is_keyframe
+
+    def check_keyframe_latest(self):
+        """returns whether or not to add a new frame (trainer.py:622-650)."""
+        add_new_frame = False
+        if self.last_is_keyframe:
+            add_new_frame = True
+        else:
+            T_WC = self.frames.T_WC_batch[-1].unsqueeze(0)
+            depth_gt = self.frames.depth_batch[-1].unsqueeze(0)
+            self.last_is_keyframe = self.is_keyframe(T_WC, depth_gt)
+            time_since_kf = self.tot_step_time - self.frames.frame_id[-2] / 30.
+            if time_since_kf > 5.:
+                print("More than 5 seconds since last kf, so add new")
+                self.last_is_keyframe = True
+            if self.last_is_keyframe:
+                self.optim_frames = self.iters_per_kf
+                self.noise_std = self.noise_kf
+            else:
+                add_new_frame = True
+        return add_new_frame
 
     def select_keyframes(self):
         """trainer.py:652-674: last two keyframes + (window-2) drawn without

@@ -612,3 +612,72 @@ def train_step(params, state, cfg, lc, frames, cam, sample_cfg, draws, optim_cfg
     out.update(terms)
     out.update(pc=pc, z_vals=z_vals, grads=grads, loss_approx=la, frame_avg_loss=fa)
     return out
+
+
+# ----------------------------------------------------------------------------
+# Per-frame ingest and keyframe test ("next" tier)
+# ----------------------------------------------------------------------------
+
+def pointcloud_from_depth(depth, fx, fy, cx, cy):
+    """`transform.pointcloud_from_depth_torch` (`transform.py:169-196`), 'z' depth:
+    (z (c-cx)/fx, z (r-cy)/fy, z); NaN depth stays NaN, 0 depth gives the origin."""
+    H, W = depth.shape
+    c = np.arange(W, dtype=np.float32)[None, :]
+    r = np.arange(H, dtype=np.float32)[:, None]
+    z = depth.astype(np.float32)
+    x = z * (c - np.float32(cx)) / np.float32(fx)
+    y = z * (r - np.float32(cy)) / np.float32(fy)
+    return np.stack((x, y, z + 0 * x), axis=-1).astype(np.float32)
+
+
+def estimate_pointcloud_normals(points):
+    """`transform.estimate_pointcloud_normals` (`transform.py:215-270`): for each
+    pixel the neighbour pair (k, k+2 mod 8) at stride 2 with the smallest summed
+    edge length (NaN -> inf, first minimum wins), cross product, normalise."""
+    H, W = points.shape[:2]
+    d = 2
+    P = np.full((H + 2 * d, W + 2 * d, 3), np.nan, np.float32)
+    P[d:-d, d:-d] = points
+    look = [(-d, 0), (-d, d), (0, d), (d, d), (d, 0), (d, -d), (0, -d), (-d, -d)]
+    sh = lambda k: P[d + look[k][0]:d + look[k][0] + H, d + look[k][1]:d + look[k][1] + W]
+    p1 = points
+    best = None
+    nrm = None
+    for k in range(8):
+        p2, p3 = sh(k), sh((k + 2) % 8)
+        diff = np.linalg.norm(p2 - p1, axis=-1) + np.linalg.norm(p3 - p1, axis=-1)
+        diff = np.where(np.isnan(diff), np.float32(np.inf), diff)
+        n = np.cross(p2 - p1, p3 - p1)
+        if best is None:
+            best, nrm = diff, n
+        else:
+            take = diff < best
+            nrm = np.where(take[..., None], n, nrm)
+            best = np.where(take, diff, best)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        return (nrm / np.linalg.norm(nrm, axis=-1, keepdims=True)).astype(np.float32)
+
+
+def sdf_render_depth(z_vals, sdf):
+    """`render.sdf_render_depth` (`render.py:12-35`) on z-sorted samples: depth =
+    z + sdf at the FIRST sample with sdf < 0 (sample 0 if none is negative), and 0
+    where that sample is the last one."""
+    n = sdf.shape[1]
+    inside = sdf < 0
+    mul = inside * np.arange(n, 0, -1)[None, :]
+    ix = mul.argmax(axis=1)
+    ar = np.arange(z_vals.shape[0])
+    depths = z_vals[ar, ix] + sdf[ar, ix]
+    depths[ix == n - 1] = 0.0
+    return depths
+
+
+def keyframe_ratio(z_vals, sdf, depth_sample, kf_dist_th):
+    """`Trainer.is_keyframe` (`trainer.py:597-609`): sort by z, render, fraction of rays whose
+    relative depth error is below kf_dist_th."""
+    order = np.argsort(z_vals, axis=-1, kind="stable")
+    zs = np.take_along_axis(z_vals, order, -1)
+    ss = np.take_along_axis(sdf, order, -1)
+    view = sdf_render_depth(zs, ss)
+    loss = np.abs(view - depth_sample) / depth_sample
+    return float((loss < kf_dist_th).sum() / loss.shape[0]), view

@@ -82,6 +82,47 @@ def run_hip(seed, depth, normal, T, cam, steps_per_kf):
         float(losses["total_loss"]), t_train / 1e3
 
 
+def run_hip_reference_schedule(seed, cam, n_steps=1200, virtual_step_ms=20.0, n_frames=600, quiet=True):
+    """The reference driver's frame scheduling (train.py:86-136) on the synthetic 30 fps stream:
+    after `optim_frames` steps on the latest frame, `check_keyframe_latest` (keyframe test on the
+    frozen net, trainer.py:586-650) decides whether it becomes a keyframe; the next frame id is
+    int(tot_step_time * fps) (trainer.py:100).  The virtual clock advances by `virtual_step_ms` per
+    step (pinned) instead of the measured step time so the schedule is reproducible."""
+    import contextlib, io
+    from isdf_amd.trainer import HipTrainer
+    np.random.seed(seed); torch.manual_seed(seed)
+    tr = HipTrainer("cuda", config(cam), inv_bounds_transform=synthetic.bounds_transform(), rng="philox", seed=seed)
+    traj = synthetic.trajectory(n_frames)
+    rng = np.random.RandomState(seed)
+    seen = {}
+
+    def frame(i):
+        if i not in seen:
+            seen[i] = synthetic.render_depth(traj[i], cam, rng, noise_std=0.01)
+        return tr.make_frame(i, seen[i], traj[i])
+    fps, t, kf_ids = 30, 0, []
+    sink = io.StringIO()
+    with (contextlib.redirect_stdout(sink) if quiet else contextlib.nullcontext()):
+        for t in range(n_steps):
+            finish_optim = tr.steps_since_frame == tr.optim_frames
+            if finish_optim or t == 0:
+                add_new_frame = True if t == 0 else tr.check_keyframe_latest()
+                if add_new_frame:
+                    new_id = int(tr.tot_step_time * fps)
+                    if new_id >= n_frames:
+                        break
+                    tr.add_frame(frame(new_id))
+                    if t == 0:
+                        tr.last_is_keyframe = True
+                        tr.optim_frames = 200
+            losses, ms = tr.step()
+            tr.tot_step_time += (virtual_step_ms - ms) / 1000.0 / tr.frac_time_perception   # pin the clock
+    ids = [int(i) for i in tr.frames.frame_id]
+    depth = np.stack([seen[i] for i in ids]); T = np.stack([traj[i] for i in ids])
+    fn = lambda p: tr.sdf_map(torch.from_numpy(p.astype(np.float32)).to(tr.device)).cpu().numpy()
+    return fn, float(losses["total_loss"]), depth, T, ids, t + 1
+
+
 def run_port(seed, depth, normal, T, cam, steps_per_kf):
     from oracle import torch_port as tp
     np.random.seed(seed); torch.manual_seed(seed)
@@ -120,9 +161,27 @@ def main():
     ap.add_argument("--keyframes", type=int, default=12)
     ap.add_argument("--steps-per-kf", type=int, default=60)
     ap.add_argument("--out", default=None)
+    ap.add_argument("--reference-schedule", action="store_true",
+                    help="hip only: reference driver frame scheduling + keyframe test instead of the pinned schedule")
+    ap.add_argument("--steps", type=int, default=1200)
+    ap.add_argument("--virtual-step-ms", type=float, default=20.0)
     a = ap.parse_args()
     cam = dict(synthetic.SCANNET_CAM)
     res = []
+    if a.reference_schedule:
+        for seed in a.seeds:
+            fn, last, depth, T, ids, n = run_hip_reference_schedule(seed, cam, a.steps, a.virtual_step_ms)
+            pts, surf = eval_points(depth, T, cam, np.random.RandomState(1000 + seed), n_per_frame=8000)
+            r = dict(backend="hip", schedule="reference", seed=seed, steps=n, keyframe_ids=ids,
+                     l1_visible_m=round(float(np.abs(fn(pts) - synthetic.gt_sdf(pts)).mean()), 5),
+                     l1_surface_m=round(float(np.abs(fn(surf) - synthetic.gt_sdf(surf)).mean()), 5),
+                     final_total_loss=round(last, 5))
+            print(json.dumps(r), flush=True)
+            res.append(r)
+        if a.out:
+            with open(a.out, "w") as f:
+                json.dump(dict(runs=res), f, indent=1)
+        return
     for seed in a.seeds:
         depth, normal, T = synthetic.keyframes(a.keyframes, cam, seed=seed, stride=48, noise_std=0.01)
         fn, last_loss, t = (run_hip if a.backend == "hip" else run_port)(seed, depth, normal, T, cam, a.steps_per_kf)

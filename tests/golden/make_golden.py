@@ -319,9 +319,39 @@ def run_step_case(mods, name, net, lossc, samplec, K, cam, seed, noise_std, n_st
     print("wrote", path)
 
 
+def run_ingest_case(mods, name, seed):
+    """reference per-frame ingest (normals) and keyframe depth render on small seeded inputs"""
+    trainer, sample, embedding, fc_map, loss, transform, FrameData = mods
+    from isdf.modules import render
+    rng = np.random.RandomState(seed)
+    H, W = 60, 80
+    cam = dict(fx=75.0, fy=75.0, cx=39.5, cy=29.5)
+    v, u = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+    depth = (2.0 + 0.8 * np.sin(0.13 * u) * np.cos(0.09 * v) + 0.02 * rng.standard_normal((H, W))).astype(np.float32)
+    depth[rng.uniform(size=(H, W)) < 0.05] = 0.0
+    depth[10:14, 20:30] = 0.0
+    d_t = torch.from_numpy(depth)
+    pc = transform.pointcloud_from_depth_torch(d_t, cam["fx"], cam["fy"], cam["cx"], cam["cy"])
+    normals = transform.estimate_pointcloud_normals(pc)
+    R, S = 120, 27
+    z = np.sort(rng.uniform(0.1, 4.0, (R, S)).astype(np.float32), axis=1)
+    sdf = (rng.uniform(0.5, 3.5, (R, 1)) - z + 0.05 * rng.standard_normal((R, S))).astype(np.float32)
+    sdf[:7] = np.abs(sdf[:7]) + 0.01           # rays with no crossing
+    sdf[7:12, :-1] = np.abs(sdf[7:12, :-1]) + 0.01; sdf[7:12, -1] = -0.2   # crossing only at the last sample
+    rd = render.sdf_render_depth(torch.from_numpy(z), torch.from_numpy(sdf))
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, depth=depth, cam=np.array([H, W, cam["fx"], cam["fy"], cam["cx"], cam["cy"]], np.float64),
+                        pc=t2n(pc), normals=t2n(normals), z_sorted=z, sdf_sorted=sdf, render_depth=t2n(rd))
+    print("wrote", path, "nan normals", int(torch.isnan(normals[..., 0]).sum()))
+
+
 def main():
     torch.set_num_threads(4)
     mods = import_reference()
+    only = sys.argv[1] if len(sys.argv) > 1 else None
+    if only == "ingest":
+        run_ingest_case(mods, "ingest_small", 31)
+        return
     cam_s = dict(H=48, W=64, fx=60.0, fy=60.0, cx=31.5, cy=23.5)
     small = dict(H=64, B=1, n_freqs=6, scale_input=0.05937489, scale_output=0.14)
     full = dict(H=256, B=2, n_freqs=6, scale_input=0.05937489, scale_output=0.14)
@@ -343,6 +373,8 @@ def main():
     # 6. K=3 <= window: all frames every step
     run_step_case(mods, "step_small_k3", small, LOSS_DEFAULT, dict(SAMPLE_DEFAULT, n_rays=30), 3,
                   cam_s, 22, 0.04, 2, 5)
+    # 7. next tier: per-frame normal estimation, keyframe depth render
+    run_ingest_case(mods, "ingest_small", 31)
 
 
 if __name__ == "__main__":

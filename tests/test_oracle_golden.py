@@ -152,3 +152,22 @@ def test_structural_known_answers():
     p = orc.init_params(256, 2, 6, np.random.RandomState(0))
     assert sum(v.size for v in p.values()) == 460033
     assert len(p) == 14
+
+
+def test_ingest_normals_and_render_depth_match_reference():
+    """SURVEY 8f tier: point cloud + 8-neighbour normals (transform.py:169-270) and the
+    keyframe test's depth render (render.py:12-35) against reference-run fixtures."""
+    g = gu.load("ingest_small")
+    H, W, fx, fy, cx, cy = g["cam"]
+    pc = orc.pointcloud_from_depth(g["depth"], fx, fy, cx, cy)
+    np.testing.assert_allclose(pc, g["pc"], rtol=0, atol=1e-6)
+    n = orc.estimate_pointcloud_normals(pc)
+    assert np.array_equal(np.isnan(n[..., 0]), np.isnan(g["normals"][..., 0]))
+    ok = ~np.isnan(g["normals"][..., 0])
+    # a few pixels sit on exact ties of the neighbour-pair score: require 99.9 % agreement
+    close = np.abs(n[ok] - g["normals"][ok]).max(-1) < 1e-4
+    assert close.mean() > 0.999, close.mean()
+    rd = orc.sdf_render_depth(g["z_sorted"], g["sdf_sorted"])
+    assert np.array_equal(rd, g["render_depth"])
+    assert (rd[:7] == g["z_sorted"][:7, 0] + g["sdf_sorted"][:7, 0]).all()   # no crossing -> sample 0 (reference quirk)
+    assert (rd[7:12] == 0).all()                                              # crossing at the last sample -> 0
