@@ -224,6 +224,12 @@ def main():
     ls = eng.loss_sums().cpu().numpy()
     final_loss = float(ls[3] / max(ls[4], 1))
 
+    traffic, traffic_src = None, None
+    tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
+    if os.path.exists(tpath) and args.rays_per_frame == 200:     # PMC passes cannot run inside the timed region:
+        with open(tpath) as f:                                    # the committed rocprofv3 --pmc measurement of this
+            tj = json.load(f)                                     # command (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)
+        traffic, traffic_src = tj["chain_kernel"]["hbm_bytes"], tj["source"]
     if rank == 0:
         flops_chain = 8.0 * M_MAC * P      # fwd 2M + input-grad 2M + its adjoint 2M + reverse sweep 2M
         res = {
@@ -251,7 +257,9 @@ def main():
                           "reduce+finalize": round(t_red * 1e3, 4)},
             "roofline": {"bound": "mfma", "kernel": "chain_kernel (fused PE+MLP fwd / input-grad / adjoint / reverse)",
                          "achieved": round(flops_chain / t_chain / 1e12, 3), "peak": MFMA_PEAK / 1e12,
-                         "unit": "TFLOP/s", "frac": round(flops_chain / t_chain / MFMA_PEAK, 5), "traffic": None,
+                         "unit": "TFLOP/s", "frac": round(flops_chain / t_chain / MFMA_PEAK, 5), "traffic": traffic,
+                         "traffic_unit": "HBM bytes per launch (rocprofv3 --pmc, separate passes)", "traffic_source": traffic_src,
+                         "hbm_GBps_at_that_traffic": None if traffic is None else round(traffic / t_chain / 1e9, 1),
                          "algorithmic_flop_per_launch": flops_chain,
                          "whole_step_frac_of_mfma_peak": round(12.0 * M_MAC * P * K / elapsed / MFMA_PEAK, 5)},
         }
