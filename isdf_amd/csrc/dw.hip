@@ -22,7 +22,7 @@ template <int HD> struct DwTile {
   static constexpr int BM = DW_PTS;
   static constexpr int ROWB = HD * 2 + 64;        // padded LDS row (bytes)
   static constexpr int TEN = BM * ROWB;           // one operand tile in LDS
-  static constexpr int LDS_BYTES = 2 * TEN;
+  static constexpr int LDS_BYTES = 4 * TEN;       // two operand tiles x two stage buffers
   static constexpr int CH = (BM * HD * 2) / (512 * 16);  // uint4 per thread per tensor
 };
 
@@ -70,9 +70,10 @@ __global__ __launch_bounds__(512, 2) void dw_kernel(const DwParams p) {
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
   const int nStages = split < nTiles ? 2 * ((nTiles - split + DW_SPLITK - 1) / DW_SPLITK) : 0;
-  uint4 regA[CH], regB[CH];
-  int curHalf = 0;
-  auto issue = [&](int st) {
+  // Two register sets so TWO stages of global loads are in flight while one is computed
+  // (HBM-bound kernel: 64 KB per stage and CU; one stage in flight left ~40 % of the bandwidth unused).
+  uint4 regA0[CH], regB0[CH], regA1[CH], regB1[CH];
+  auto issue = [&](int st, uint4 (&ra)[CH], uint4 (&rb)[CH]) {
     const int u = split + (st >> 1) * DW_SPLITK;      // half-tile index
     const int t = u / HALVES, half = u % HALVES;
     const uint4* ta = (const uint4*)(p.spill + ((st & 1) ? offP : offZ) + (int64_t)t * TILE_PTS * HD);
@@ -81,25 +82,29 @@ __global__ __launch_bounds__(512, 2) void dw_kernel(const DwParams p) {
     for (int c = 0; c < CH; ++c) {
       int pt, f0;
       const int idx = frag16_half<HD>(c * 512 + tid, half, pt, f0);
-      regA[c] = ta[idx];
-      regB[c] = tb[idx];
+      ra[c] = ta[idx];
+      rb[c] = tb[idx];
     }
   };
-  auto commit = [&]() {
+  auto commit = [&](const uint4 (&ra)[CH], const uint4 (&rb)[CH], int buf) {
+    char* sb = smem + buf * 2 * T::TEN;
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
       int pt, f0;
-      frag16_half<HD>(c * 512 + tid, curHalf, pt, f0);
-      char* ra = smem + pt * ROWB + f0 * 2;
-      *(uint2*)(ra) = make_uint2(regA[c].x, regA[c].y);
-      *(uint2*)(ra + 16) = make_uint2(regA[c].z, regA[c].w);
-      char* rb = smem + T::TEN + pt * ROWB + f0 * 2;
-      *(uint2*)(rb) = make_uint2(regB[c].x, regB[c].y);
-      *(uint2*)(rb + 16) = make_uint2(regB[c].z, regB[c].w);
+      frag16_half<HD>(c * 512 + tid, 0, pt, f0);
+      char* pa = sb + pt * ROWB + f0 * 2;
+      *(uint2*)(pa) = make_uint2(ra[c].x, ra[c].y);
+      *(uint2*)(pa + 16) = make_uint2(ra[c].z, ra[c].w);
+      char* pb = sb + T::TEN + pt * ROWB + f0 * 2;
+      *(uint2*)(pb) = make_uint2(rb[c].x, rb[c].y);
+      *(uint2*)(pb + 16) = make_uint2(rb[c].z, rb[c].w);
     }
   };
 
-  if (nStages > 0) { issue(0); commit(); }
+  if (nStages > 0) { issue(0, regA0, regB0); }
+  if (nStages > 1) { issue(1, regA1, regB1); }
+  if (nStages > 0) commit(regA0, regB0, 0);
+  if (nStages > 2) issue(2, regA0, regB0);
   __syncthreads();
 
   // per-lane transpose-read addressing: in each 16-lane group source lane s
@@ -118,25 +123,35 @@ __global__ __launch_bounds__(512, 2) void dw_kernel(const DwParams p) {
     r[4] = hi4[0]; r[5] = hi4[1]; r[6] = hi4[2]; r[7] = hi4[3];
     return r;
   };
-
-  for (int st = 0; st < nStages; ++st) {
-    if (st + 1 < nStages) issue(st + 1);
+  auto compute = [&](int buf) {
+    const char* sb = smem + buf * 2 * T::TEN;
 #pragma unroll
     for (int ks = 0; ks < BM / 16; ++ks) {
       bf16x8 a[2], b[4];
 #pragma unroll
-      for (int ob = 0; ob < 2; ++ob) a[ob] = trload(smem, ks * 16, wo * 64 + ob * 32);
+      for (int ob = 0; ob < 2; ++ob) a[ob] = trload(sb, ks * 16, wo * 64 + ob * 32);
 #pragma unroll
-      for (int ib = 0; ib < 4; ++ib) b[ib] = trload(smem + T::TEN, ks * 16, wi * 128 + ib * 32);
+      for (int ib = 0; ib < 4; ++ib) b[ib] = trload(sb + T::TEN, ks * 16, wi * 128 + ib * 32);
 #pragma unroll
       for (int ob = 0; ob < 2; ++ob)
 #pragma unroll
         for (int ib = 0; ib < 4; ++ib)
           acc[ob][ib] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ob], b[ib], acc[ob][ib], 0, 0, 0);
     }
+  };
+
+  // Stage st sits in LDS buffer (st&1).  Each iteration first writes stage st+1 (loads issued two
+  // stages ago) into the OTHER LDS buffer, re-issues that register set for stage st+3, then runs the
+  // MFMAs of stage st: the LDS commit of one wave overlaps the MFMAs of the others, one barrier per stage.
+  for (int st = 0; st < nStages; st += 2) {
+    if (st + 1 < nStages) { commit(regA1, regB1, 1); if (st + 3 < nStages) issue(st + 3, regA1, regB1); }
+    compute(0);
     __syncthreads();
-    if (st + 1 < nStages) commit();
-    __syncthreads();
+    if (st + 1 < nStages) {
+      if (st + 2 < nStages) { commit(regA0, regB0, 0); if (st + 4 < nStages) issue(st + 4, regA0, regB0); }
+      compute(1);
+      __syncthreads();
+    }
   }
 
   // partial slab [o][i]
