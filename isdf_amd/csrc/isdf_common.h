@@ -60,7 +60,6 @@ struct WorkspaceLayout {
   int64_t nTiles;
   SpillLayout sp;
   int64_t offSpill;      // bytes
-  int64_t offRayLoss;    // float [maxRays]
   int64_t offWgLoss;     // float [nTiles][8]
   int64_t offDwPart;     // float [units][DW_SPLITK][HD*HD]
   int64_t offVecPart;    // float [nTiles][vecStride]: per-workgroup bias / out-layer gradient partials
@@ -126,7 +125,7 @@ inline void make_workspace(const NetLayout& l, int64_t maxPts, int64_t maxRays, 
   s.totalElems = o;
   int64_t b = 0;
   w->offSpill = b; b += o * 2; b = (b + 255) / 256 * 256;
-  (void)maxRays; w->offRayLoss = b;
+  (void)maxRays;
   w->offWgLoss = b; b += (train ? w->nTiles * 8 : 0) * 4; b = (b + 255) / 256 * 256;
   w->offDwPart = b; b += train ? (int64_t)dw_units(l) * DW_SPLITK * l.HD * l.HD * 4 : 0; b = (b + 255) / 256 * 256;
   w->vecStride = round_up(l.L * l.HD + 2 * l.HD + 8, 64);   // [db_0..db_{L-1} | dwout(adjoint) | dwout(reverse) | dbout]

@@ -304,6 +304,41 @@ class HipTrainer:
         last = n_frames - 1
         return [*rand_ints, last - 1, last]
 
+    # ---- checkpoint / resume ---------------------------------------------
+    def state_dict(self):
+        """Everything needed for a true resume.  The reference saves only model + optimiser
+        (train.py:207-219) and restores only the model (trainer.py:441-444); keyframes, RNG
+        position and the virtual clock are lost there."""
+        fr = self.frames
+        return {
+            "model_state_dict": {k: v.detach().clone() for k, v in self.sdf_map.state_dict().items()},
+            "optimizer_state_dict": self.optimiser.state_dict(),
+            "frames": {k: (None if getattr(fr, k) is None else
+                           (getattr(fr, k).copy() if isinstance(getattr(fr, k), np.ndarray) else getattr(fr, k).clone()))
+                       for k in ("frame_id", "depth_batch", "T_WC_batch", "normal_batch", "frame_avg_losses")},
+            "clock": dict(tot_step_time=self.tot_step_time, steps_since_frame=self.steps_since_frame,
+                          last_is_keyframe=self.last_is_keyframe, optim_frames=self.optim_frames,
+                          noise_std=self.noise_std, step_count=self._step_count),
+            "rng": dict(draw_count=getattr(self, "_draw_count", 0), noise_count=getattr(self, "_noise_count", 0),
+                        seed=self.seed, numpy=np.random.get_state(), torch=torch.get_rng_state(),
+                        torch_cuda=torch.cuda.get_rng_state(self.device)),
+        }
+
+    def load_state_dict(self, sd):
+        self.sdf_map.load_state_dict(sd["model_state_dict"])
+        self.optimiser.load_state_dict(sd["optimizer_state_dict"])
+        f = sd["frames"]
+        self.frames = FrameData(frame_id=f["frame_id"], depth_batch=f["depth_batch"], T_WC_batch=f["T_WC_batch"],
+                                normal_batch=f["normal_batch"], frame_avg_losses=f["frame_avg_losses"])
+        c = sd["clock"]
+        self.tot_step_time, self.steps_since_frame = c["tot_step_time"], c["steps_since_frame"]
+        self.last_is_keyframe, self.optim_frames = c["last_is_keyframe"], c["optim_frames"]
+        self.noise_std, self._step_count = c["noise_std"], c["step_count"]
+        r = sd["rng"]
+        self._draw_count, self._noise_count, self.seed = r["draw_count"], r["noise_count"], r["seed"]
+        np.random.set_state(r["numpy"]); torch.set_rng_state(r["torch"])
+        torch.cuda.set_rng_state(r["torch_cuda"], self.device)
+
     # ---- sampling (trainer.py:683-766) ---------------------------------------------
     def _draws_torch(self, F, sc, n_valid_fn):
         """Reference draw order/shapes/devices: randint(h), randint(w) on the

@@ -370,3 +370,36 @@ def test_reference_driver_schedule_runs_end_to_end():
     pts, surf = ae.eval_points(depth, T, cam, np.random.RandomState(0), n_per_frame=4000)
     l1s = float(np.abs(fn(surf) - synthetic.gt_sdf(surf)).mean())
     assert np.isfinite(last) and l1s < 0.10, (last, l1s)     # the surface is being learnt
+
+
+def test_checkpoint_resume_is_exact():
+    """Full resume (model, AdamW moments + step, keyframes, RNG counters, virtual clock): a restored
+    trainer continues bit-identically (the reference restores only the weights, trainer.py:441-444)."""
+    import io
+    from isdf_amd.trainer import HipTrainer, FrameData
+    from isdf_amd import synthetic
+    import bench
+    cam = dict(synthetic.SCANNET_CAM)
+    cfg = bench.reference_config()
+    cfg["dataset"]["camera"] = {"w": cam["W"], "h": cam["H"], "fx": cam["fx"], "fy": cam["fy"], "cx": cam["cx"], "cy": cam["cy"]}
+    depth, normal, T = synthetic.keyframes(7, cam, seed=4, stride=30)
+
+    def fresh():
+        np.random.seed(3); torch.manual_seed(3)
+        tr = HipTrainer("cuda", cfg, inv_bounds_transform=synthetic.bounds_transform(), rng="philox", seed=3)
+        tr.frames = FrameData(frame_id=np.arange(7), depth_batch=_dev(depth), T_WC_batch=_dev(T),
+                              normal_batch=_dev(normal), frame_avg_losses=torch.rand(7, device="cuda") + 0.5)
+        return tr
+    a = fresh()
+    for _ in range(10):
+        a.step()
+    buf = io.BytesIO()
+    torch.save(a.state_dict(), buf)                  # goes through torch.save like train.py:207-219
+    ref = [a.step()[0]["total_loss"].item() for _ in range(5)]
+    ref_idx = list(a.active_idxs)
+    b = fresh()
+    buf.seek(0)
+    b.load_state_dict(torch.load(buf, weights_only=False))
+    got = [b.step()[0]["total_loss"].item() for _ in range(5)]
+    assert got == ref and list(b.active_idxs) == ref_idx
+    assert torch.equal(a.engine.params, b.engine.params) and torch.equal(a.engine.exp_avg_sq, b.engine.exp_avg_sq)
