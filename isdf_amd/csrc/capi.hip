@@ -37,7 +37,7 @@ const char* isdf_error_string(int code) {
   switch (code) {
     case ISDF_OK: return "ok";
     case ISDF_EINVAL: return "invalid argument";
-    case ISDF_EUNSUPPORTED: return "unsupported configuration (kernels are built for hidden=256, n_freqs<=6)";
+    case ISDF_EUNSUPPORTED: return "unsupported configuration (kernels are built for hidden 256 with n_freqs<=6 and hidden 512 with 7<=n_freqs<=12)";
     case ISDF_EWORKSPACE: return "workspace too small";
     case ISDF_EHIP: return "HIP runtime error";
   }

@@ -168,7 +168,7 @@ __device__ __forceinline__ float softplus_s1(float z, float& s1) {   // also sig
 __device__ __forceinline__ float s1_from_a(float a) { return 1.f - __builtin_amdgcn_exp2f(-kC1 * a); }
 
 template <int HD, int EP, bool F16, int MODE>
-__global__ __launch_bounds__(CHAIN_NW * 64, 4) void chain_kernel(const ChainParams p) {
+__global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 ? 4 : 2)) void chain_kernel(const ChainParams p) {
   typedef Tile<HD, EP> T;
   static_assert(HD == EP, "tile kernels assume padded embedding width == hidden width");
   constexpr int BM = T::BM, FB = T::FB, PB = T::PB, ROWB = T::ROWB;
@@ -703,20 +703,19 @@ __global__ __launch_bounds__(CHAIN_NW * 64, 4) void chain_kernel(const ChainPara
 }
 
 // ---------------------------------------------------------------------------
+template <int HD, bool F16, int MODE>
+static int launch_one(const ChainParams& p, int64_t nTiles, hipStream_t st) {
+  typedef Tile<HD, HD> T;
+  auto k = chain_kernel<HD, HD, F16, MODE>;
+  if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES) != hipSuccess) return ISDF_EHIP;
+  hipLaunchKernelGGL(k, dim3((unsigned)nTiles), dim3(CHAIN_NW * 64), T::LDS_BYTES, st, p);
+  return hipGetLastError() == hipSuccess ? ISDF_OK : ISDF_EHIP;
+}
+
 template <int MODE>
 static int launch_mode(const ChainParams& p, int64_t nTiles, hipStream_t st) {
-  typedef Tile<256, 256> T;
-  dim3 grid((unsigned)nTiles), block(CHAIN_NW * 64);
-  if (p.lay.fwd_f16) {
-    auto k = chain_kernel<256, 256, true, MODE>;
-    if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES) != hipSuccess) return ISDF_EHIP;
-    hipLaunchKernelGGL(k, grid, block, T::LDS_BYTES, st, p);
-  } else {
-    auto k = chain_kernel<256, 256, false, MODE>;
-    if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES) != hipSuccess) return ISDF_EHIP;
-    hipLaunchKernelGGL(k, grid, block, T::LDS_BYTES, st, p);
-  }
-  return hipGetLastError() == hipSuccess ? ISDF_OK : ISDF_EHIP;
+  if (p.lay.HD == 256) return p.lay.fwd_f16 ? launch_one<256, true, MODE>(p, nTiles, st) : launch_one<256, false, MODE>(p, nTiles, st);
+  return p.lay.fwd_f16 ? launch_one<512, true, MODE>(p, nTiles, st) : launch_one<512, false, MODE>(p, nTiles, st);
 }
 
 int launch_chain(const ChainParams& p, int mode, int64_t nTiles, hipStream_t st) {

@@ -20,24 +20,25 @@ namespace isdf {
 
 template <int HD> struct DwTile {
   static constexpr int BM = DW_PTS;
-  static constexpr int ROWB = HD * 2 + 64;        // padded LDS row (bytes)
-  static constexpr int TEN = BM * ROWB;           // one operand tile in LDS
-  static constexpr int LDS_BYTES = 4 * TEN;       // two operand tiles x two stage buffers
-  static constexpr int CH = (BM * HD * 2) / (512 * 16);  // uint4 per thread per tensor
+  static constexpr int ROWB = DW_BLK * 2 + 64;    // padded LDS row (bytes) of a 256-column operand slice
+  static constexpr int TEN = BM * ROWB;           // one operand slice in LDS
+  static constexpr int LDS_BYTES = 4 * TEN;       // two operand slices x two stage buffers
+  static constexpr int CH = (BM * DW_BLK * 2) / (512 * 16);  // uint4 per thread per tensor
 };
 
-// Piece c (16 B = 8 elems) of the `half`-th 64-point half of a chain tile in
-// frag16 order (chain.hip): returns the uint4 index inside the tile and the
-// (point-in-half, first feature): elems 0..3 at features f0.., elems 4..7 at f0+8..
-template <int HD> __device__ __forceinline__ int frag16_half(int c, int half, int& pt, int& f0) {
-  constexpr int FB = HD / (CHAIN_NW * 32), PB = TILE_PTS / 32, HB = DW_PTS / 32;   // HB point-blocks per half
+// Piece c (16 B = 8 elems) of the 64-point half `half`, 256-feature slice `sl` of a chain tile
+// stored in frag16 order (chain.hip).  A slice is 8 consecutive 32-feature blocks; block g of the
+// tile is (wave g / FB, fb g % FB), so the tile piece index is ((g*PB + pb)*2 + qp)*64 + lane.
+// Returns that index; (pt, f0) = point in the half and first feature in the slice:
+// elems 0..3 at features f0.., elems 4..7 at f0+8..
+__device__ __forceinline__ int frag16_piece(int c, int half, int sl, int& pt, int& f0) {
+  constexpr int PB = TILE_PTS / 32, HB = DW_PTS / 32;
   const int lane = c & 63; int r = c >> 6;
   const int qp = r & 1; r >>= 1;
-  const int pbh = r % HB; r /= HB;
-  const int fb = r % FB; const int w = r / FB;
+  const int pbh = r % HB; const int blk = r / HB;   // blk 0..7
   pt = pbh * 32 + (lane & 31);
-  f0 = w * (FB * 32) + fb * 32 + 16 * qp + 4 * (lane >> 5);
-  return ((((w * FB + fb) * PB + half * HB + pbh) * 2 + qp) * 64 + lane);
+  f0 = blk * 32 + 16 * qp + 4 * (lane >> 5);
+  return ((((sl * 8 + blk) * PB + half * HB + pbh) * 2 + qp) * 64 + lane);
 }
 
 template <int HD>
@@ -49,8 +50,13 @@ __global__ __launch_bounds__(512, 2) void dw_kernel(const DwParams p) {
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int wo = w >> 1, wi = w & 1;
   const int unit = blockIdx.x / DW_SPLITK, split = blockIdx.x % DW_SPLITK;
-  const int li = unit < L.L ? unit : L.cat;
-  const bool embHalf = unit == L.L;
+  const DwUnit du = dw_unit(L, unit);
+  const int li = du.li;
+  // input-side operand: columns [256*ib, +256) of the padded layer input.  Layer 0 reads the
+  // embedding; the cat layer reads [a | emb]; the rest read the previous activation.
+  const bool fromEmb = li == 0 || (li == L.cat && du.ib * DW_BLK >= HD);
+  const int slB = (li == L.cat && fromEmb) ? du.ib - HD / DW_BLK : du.ib;
+  const int slA = du.ob;
 
   const int64_t P = p.n_valid ? (int64_t)(*p.n_valid) * p.S : p.n_points_host;
   constexpr int HALVES = TILE_PTS / DW_PTS;
@@ -58,8 +64,8 @@ __global__ __launch_bounds__(512, 2) void dw_kernel(const DwParams p) {
 
   // stage q of tile t: q=0 -> (ZB[li], I), q=1 -> (P[li], GB)
   const int64_t offZ = p.sp.ZB[li], offP = p.sp.P[li];
-  const int64_t offI = embHalf ? p.sp.A[0] : p.sp.A[li];
-  const int64_t offG = embHalf ? p.sp.GB[0] : p.sp.GB[li];
+  const int64_t offI = fromEmb ? p.sp.A[0] : p.sp.A[li];
+  const int64_t offG = fromEmb ? p.sp.GB[0] : p.sp.GB[li];
 
   f32x16 acc[2][4];
 #pragma unroll
@@ -81,9 +87,8 @@ __global__ __launch_bounds__(512, 2) void dw_kernel(const DwParams p) {
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
       int pt, f0;
-      const int idx = frag16_half<HD>(c * 512 + tid, half, pt, f0);
-      ra[c] = ta[idx];
-      rb[c] = tb[idx];
+      ra[c] = ta[frag16_piece(c * 512 + tid, half, slA, pt, f0)];
+      rb[c] = tb[frag16_piece(c * 512 + tid, half, slB, pt, f0)];
     }
   };
   auto commit = [&](const uint4 (&ra)[CH], const uint4 (&rb)[CH], int buf) {
@@ -91,7 +96,7 @@ __global__ __launch_bounds__(512, 2) void dw_kernel(const DwParams p) {
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
       int pt, f0;
-      frag16_half<HD>(c * 512 + tid, 0, pt, f0);
+      frag16_piece(c * 512 + tid, 0, 0, pt, f0);
       char* pa = sb + pt * ROWB + f0 * 2;
       *(uint2*)(pa) = make_uint2(ra[c].x, ra[c].y);
       *(uint2*)(pa + 16) = make_uint2(ra[c].z, ra[c].w);
@@ -155,7 +160,7 @@ __global__ __launch_bounds__(512, 2) void dw_kernel(const DwParams p) {
   }
 
   // partial slab [o][i]
-  float* slab = p.dwPart + ((int64_t)unit * DW_SPLITK + split) * HD * HD;
+  float* slab = p.dwPart + ((int64_t)unit * DW_SPLITK + split) * DW_BLK * DW_BLK;
 #pragma unroll
   for (int ob = 0; ob < 2; ++ob)
 #pragma unroll
@@ -164,7 +169,7 @@ __global__ __launch_bounds__(512, 2) void dw_kernel(const DwParams p) {
       for (int r = 0; r < 16; ++r) {
         const int o = wo * 64 + ob * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
         const int i = wi * 128 + ib * 32 + (lane & 31);
-        slab[o * HD + i] = acc[ob][ib][r];
+        slab[o * DW_BLK + i] = acc[ob][ib][r];
       }
 }
 
@@ -174,22 +179,25 @@ __global__ void dw_reduce_kernel(const ReduceParams p) {
   const NetLayout& L = p.lay;
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int HD = L.HD;
-  const int64_t perUnit = (int64_t)HD * HD;
-  const int64_t nW = (int64_t)(L.L + 1) * perUnit;
-  if (idx < nW) {
-    const int unit = (int)(idx / perUnit);
-    const int rem = (int)(idx - unit * perUnit);
-    const int o = rem / HD, i = rem - o * HD;
-    const int li = unit < L.L ? unit : L.cat;
-    const bool embHalf = unit == L.L;
-    const int width = (li == 0 || embHalf) ? L.E : HD;
-    if (i >= width) return;
-    float s = 0.f;
-    const float* src = p.dwPart + (int64_t)unit * DW_SPLITK * perUnit + rem;
+  constexpr int64_t perUnit = (int64_t)DW_BLK * DW_BLK;
+  const int unit = (int)(idx / perUnit);
+  if (unit >= dw_units(L)) return;
+  const DwUnit du = dw_unit(L, unit);
+  const int rem = (int)(idx - unit * perUnit);
+  const int o = du.ob * DW_BLK + rem / DW_BLK;
+  const int ip = du.ib * DW_BLK + rem % DW_BLK;          // padded input column
+  const int li = du.li;
+  int col;                                               // column in the fp32 weight [HD x K_li]
+  if (li == 0) { if (ip >= L.E) return; col = ip; }
+  else if (li == L.cat) {
+    if (ip < HD) col = ip;
+    else { if (ip - HD >= L.E) return; col = ip; }       // [a | emb]: emb column e sits at HD + e
+  } else col = ip;
+  float s = 0.f;
+  const float* src = p.dwPart + (int64_t)unit * DW_SPLITK * perUnit + rem;
 #pragma unroll 4
-    for (int k = 0; k < DW_SPLITK; ++k) s += src[(int64_t)k * perUnit];
-    p.grad[L.offW[li] + (int64_t)o * L.K[li] + (embHalf ? HD : 0) + i] = s;
-  }
+  for (int k = 0; k < DW_SPLITK; ++k) s += src[(int64_t)k * perUnit];
+  p.grad[L.offW[li] + (int64_t)o * L.K[li] + col] = s;
 }
 
 // biases (L*HD), w_out (HD), b_out (1): sum the per-workgroup partials.  256
@@ -242,15 +250,22 @@ __global__ __launch_bounds__(1024) void vec_reduce_kernel(const ReduceParams p) 
 int launch_dw(const DwParams& p, hipStream_t st) {
   if (!layout_supported(p.lay)) return ISDF_EUNSUPPORTED;
   typedef DwTile<256> T;
-  auto k = dw_kernel<256>;
-  if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES) != hipSuccess) return ISDF_EHIP;
-  hipLaunchKernelGGL(k, dim3(dw_units(p.lay) * DW_SPLITK), dim3(512), T::LDS_BYTES, st, p);
+  const dim3 grid(dw_units(p.lay) * DW_SPLITK), block(512);
+  if (p.lay.HD == 256) {
+    auto k = dw_kernel<256>;
+    if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES) != hipSuccess) return ISDF_EHIP;
+    hipLaunchKernelGGL(k, grid, block, T::LDS_BYTES, st, p);
+  } else {
+    auto k = dw_kernel<512>;
+    if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES) != hipSuccess) return ISDF_EHIP;
+    hipLaunchKernelGGL(k, grid, block, T::LDS_BYTES, st, p);
+  }
   return hipGetLastError() == hipSuccess ? ISDF_OK : ISDF_EHIP;
 }
 
 int launch_dw_reduce(const ReduceParams& p, hipStream_t st) {
   const NetLayout& L = p.lay;
-  const int64_t total = (int64_t)dw_units(L) * L.HD * L.HD;
+  const int64_t total = (int64_t)dw_units(L) * DW_BLK * DW_BLK;
   hipLaunchKernelGGL(dw_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, p);
   const int nVec = L.L * L.HD + L.HD + 1;
   hipLaunchKernelGGL(vec_reduce_kernel, dim3((unsigned)((nVec + 63) / 64)), dim3(1024), 0, st, p);

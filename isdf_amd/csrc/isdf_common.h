@@ -106,9 +106,28 @@ inline int make_layout(const isdf_net_cfg* c, NetLayout* l) {
 
 // The tile kernels are built for these shapes (the reference default net:
 // replicaCAD.json:57-58,65 -> Hd 256, E 255).  Other shapes: ISDF_EUNSUPPORTED.
-inline bool layout_supported(const NetLayout& l) { return l.HD == 256 && l.EP == 256; }
+inline bool layout_supported(const NetLayout& l) { return (l.HD == 256 || l.HD == 512) && l.EP == l.HD; }
 
-inline int dw_units(const NetLayout& l) { return l.L + 1; }  // one per layer + cat's embedding half
+// dW is computed in 256x256 "units": (layer li, output block ob, padded-input block ib).
+constexpr int DW_BLK = 256;
+struct DwUnit { int li, ob, ib; };
+__host__ __device__ inline int dw_kpad(const NetLayout& l, int li) {
+  return li == 0 ? l.EP : (li == l.cat ? l.HD + l.EP : l.HD);
+}
+__host__ __device__ inline int dw_units(const NetLayout& l) {
+  int n = 0;
+  for (int li = 0; li < l.L; ++li) n += (l.HD / DW_BLK) * (dw_kpad(l, li) / DW_BLK);
+  return n;
+}
+__host__ __device__ inline DwUnit dw_unit(const NetLayout& l, int u) {
+  const int nOb = l.HD / DW_BLK;
+  for (int li = 0; li < l.L; ++li) {
+    const int n = nOb * (dw_kpad(l, li) / DW_BLK);
+    if (u < n) return DwUnit{li, u % nOb, u / nOb};
+    u -= n;
+  }
+  return DwUnit{0, 0, 0};
+}
 
 inline void make_workspace(const NetLayout& l, int64_t maxPts, int64_t maxRays, bool train, WorkspaceLayout* w) {
   w->nTiles = (maxPts + TILE_PTS - 1) / TILE_PTS;
@@ -127,7 +146,7 @@ inline void make_workspace(const NetLayout& l, int64_t maxPts, int64_t maxRays, 
   w->offSpill = b; b += o * 2; b = (b + 255) / 256 * 256;
   (void)maxRays;
   w->offWgLoss = b; b += (train ? w->nTiles * 8 : 0) * 4; b = (b + 255) / 256 * 256;
-  w->offDwPart = b; b += train ? (int64_t)dw_units(l) * DW_SPLITK * l.HD * l.HD * 4 : 0; b = (b + 255) / 256 * 256;
+  w->offDwPart = b; b += train ? (int64_t)dw_units(l) * DW_SPLITK * DW_BLK * DW_BLK * 4 : 0; b = (b + 255) / 256 * 256;
   w->vecStride = round_up(l.L * l.HD + 2 * l.HD + 8, 64);   // [db_0..db_{L-1} | dwout(adjoint) | dwout(reverse) | dbout]
   w->offVecPart = b; b += train ? w->nTiles * (int64_t)w->vecStride * 4 : 0; b = (b + 255) / 256 * 256;
   w->offTotLoss = b; b += train ? maxPts * 4 : 0; b = (b + 255) / 256 * 256;

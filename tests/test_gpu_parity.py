@@ -403,3 +403,42 @@ def test_checkpoint_resume_is_exact():
     got = [b.step()[0]["total_loss"].item() for _ in range(5)]
     assert got == ref and list(b.active_idxs) == ref_idx
     assert torch.equal(a.engine.params, b.engine.params) and torch.equal(a.engine.exp_avg_sq, b.engine.exp_avg_sq)
+
+
+def test_wide_net_8x512_L10_matches_oracle():
+    """BASELINE configs[4] network: hidden 512, 3 blocks (8 hidden layers), n_freqs 10 (E = 423).
+    Same sampler draws as the default-net fixture; forward, input gradient, losses and all 18
+    gradient tensors against the oracle."""
+    from isdf_amd.engine import Engine, NetConfig
+    g = gu.load("eval_full_ray")
+    params = orc.init_params(512, 3, 10, np.random.RandomState(77))
+    net = NetConfig(hidden=512, blocks=3, n_freqs=10, scale_input=0.05937489, scale_output=0.14,
+                    transform=g["bounds_T"])
+    eng = Engine(net, "cuda")
+    assert eng.n_params == sum(v.size for v in params.values()) == 2272769      # SURVEY 8e
+    eng.load_params(params)
+    cfg = orc.NetCfg(512, 3, 10, 0.05937489, 0.14, g["bounds_T"])
+    x = g["pc"].reshape(-1, 3)
+    sdf, grad = eng.sdf_eval(_dev(x), want_grad=True)
+    ref, refg = orc.sdf_forward_grad(params, cfg, x)
+    assert gu.rel_err(sdf.cpu().numpy(), ref) < 2e-3, gu.rel_err(sdf.cpu().numpy(), ref)
+    assert gu.rel_err(grad.cpu().numpy(), refg) < 1e-2
+    lc, sc = _cfgs(g)
+    s_ = _sample_hip(eng, g, sc)
+    R = g["depth_sample"].shape[0]
+    noise = g["draw_noise"].reshape(R, -1) * np.float32(0.08)
+    eng.train_step(s_, lc, sc, noise=_dev(noise))
+    terms, grads = orc.loss_and_grads(params, cfg, gu.loss_of(g), g["pc"], g["z_vals"], g["depth_sample"],
+                                      g["dirs_C_sample"], g["T_WC_sample"], g["norm_sample"], noise=noise)
+    ls = eng.loss_sums().cpu().numpy()
+    N = R * g["z_vals"].shape[1]
+    assert ls[4] == N
+    for k, name in [(0, "sdf_loss"), (1, "grad_loss"), (2, "eikonal_loss"), (3, "total_loss")]:
+        assert abs(ls[k] / N - terms[name]) < 2e-3 * abs(terms[name]), (name, ls[k] / N, terms[name])
+    for k in grads:
+        got = (eng.grad_view(k).cpu().numpy().astype(np.float64) / N).reshape(-1)
+        ref_ = grads[k].astype(np.float64).reshape(-1)
+        cos = got @ ref_ / (np.linalg.norm(got) * np.linalg.norm(ref_))
+        assert cos > 0.999 and gu.rel_err(got, ref_) < 2e-2, (k, cos, gu.rel_err(got, ref_))
+    eng.adamw()
+    torch.cuda.synchronize()
