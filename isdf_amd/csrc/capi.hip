@@ -149,6 +149,7 @@ int isdf_train_step(const isdf_net_cfg* net, const isdf_loss_cfg* loss, const fl
   p.tot_ws = totLoss; p.wg_loss = wgLoss; p.vec_part = vecPart; p.vecStride = w.vecStride;
   p.spill = (uint16_t*)(ws + w.offSpill); p.sp = w.sp;
   if (const char* e = getenv("ISDF_DEBUG_ALIAS_SPILL")) p.dbg_alias = atoi(e);   // timing experiments only
+  if (const char* e = getenv("ISDF_DEBUG_STAGGER")) p.dbg_stagger = atoi(e);
   if (getenv("ISDF_DEBUG_TIMELINE")) p.dbg_times = (unsigned long long*)(ws + w.totalBytes - 4096);
   hipEvent_t* ev = (hipEvent_t*)o->prof_events;
   if (ev && hipEventRecord(ev[0], st) != hipSuccess) return ISDF_EHIP;

@@ -69,58 +69,46 @@ __device__ __forceinline__ void nt_store16(uint4 x, uint4* p) {
 __device__ __forceinline__ int swz(int row, int colbytes) { return colbytes ^ ((row & 15) << 4); }
 
 // C[FB*32 feats][PB*32 pts] += Wpacked[feat][k] * X[pt][k]  over KSTEPS*16 k.
-// Weight fragments come straight from L2 (~500-800 cycles away): the loop is a
-// real (not unrolled) loop over stages of KS k-steps whose next-stage fragments
-// are requested before the current stage's MFMAs.  NOTE (measured):
-// the `cur = nxt` copy makes the compiler wait for the prefetch at the end of
-// every iteration, so the overlap is partial; a ping-pong variant with pinned
-// issue order overlaps properly but costs ~90 more spilled VGPRs in the train
-// kernel at the 128-register budget and was slower end-to-end -- the GEMM phase
-// is bound by the per-CU L2->L1 weight stream (~50 B/clk/CU) either way.
+// Measured: a workgroup's time is a serial latency chain, and a staged
+// weight loop pays one dependent L2/MALL round trip per stage (8 per K=256 unit).  So the
+// wave requests its WHOLE weight slice for a chunk of CK k-steps up front (64 VGPRs:
+// one round trip per chunk; K=256 is one chunk for 256-wide nets), one scheduling
+// barrier keeps the load block ahead of the MFMAs, and the k-steps are fully unrolled.
+// `lateHook` (the epilogue's spill prefetch) is issued right after the last MFMA: issuing it
+// mid-GEMM overlapped more latency but pushed the train kernel 130 VGPRs over its budget.
 template <bool F16, int KSTEPS, int FBN, int PBN, int ROWB, typename Hook>
 __device__ __forceinline__ void gemm(f32x16 (&acc)[FBN][PBN], const uint4* __restrict__ wp,
                                      int rbStride, const char* xl, int colByteBase, int lane, Hook&& lateHook) {
-  constexpr int KS = 2;
-  static_assert(KSTEPS % KS == 0, "K must be a multiple of 64");
-  constexpr int NST = KSTEPS / KS;
+  constexpr int CK = 8 / FBN;                  // k-steps per chunk: CK*FBN uint4 = 32 VGPRs
+  static_assert(KSTEPS % CK == 0, "K must be a multiple of the chunk");
+  constexpr int NCH = KSTEPS / CK;
   const int j = lane & 31, hi = lane >> 5;
   const int sw = (j & 15) << 4;
   const uint4* wl = wp + lane;
-  uint4 cur[KS][FBN], nxt[KS][FBN];
-#pragma unroll
-  for (int s = 0; s < KS; ++s)
-#pragma unroll
-    for (int fb = 0; fb < FBN; ++fb) cur[s][fb] = wl[fb * rbStride + s * 64];
 #pragma unroll 1
-  for (int st = 0; st < NST; ++st) {
-    if (st + 1 < NST) {
+  for (int ch = 0; ch < NCH; ++ch) {
+    uint4 wb[CK][FBN];
 #pragma unroll
-      for (int s = 0; s < KS; ++s)
+    for (int s = 0; s < CK; ++s)
 #pragma unroll
-        for (int fb = 0; fb < FBN; ++fb) nxt[s][fb] = wl[fb * rbStride + ((st + 1) * KS + s) * 64];
-    }
-    // after the LAST weight stage has been requested: memory returns in order, so
-    // anything issued here (the epilogue's spill prefetch) cannot stall the weight stream
-    if (st == NST - 2) lateHook();
+      for (int fb = 0; fb < FBN; ++fb) wb[s][fb] = wl[fb * rbStride + (ch * CK + s) * 64];
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int s = 0; s < KS; ++s) {
+    for (int s = 0; s < CK; ++s) {
       typename Op<F16>::v8 b[PBN];
 #pragma unroll
       for (int pb = 0; pb < PBN; ++pb) {
-        const int cb = (colByteBase + (st * KS + s) * 32 + hi * 16) ^ sw;
+        const int cb = (colByteBase + (ch * CK + s) * 32 + hi * 16) ^ sw;
         b[pb] = __builtin_bit_cast(typename Op<F16>::v8, *(const uint4*)(xl + (pb * 32 + j) * ROWB + cb));
       }
 #pragma unroll
       for (int fb = 0; fb < FBN; ++fb)
 #pragma unroll
         for (int pb = 0; pb < PBN; ++pb)
-          acc[fb][pb] = Op<F16>::mfma(__builtin_bit_cast(typename Op<F16>::v8, cur[s][fb]), b[pb], acc[fb][pb]);
+          acc[fb][pb] = Op<F16>::mfma(__builtin_bit_cast(typename Op<F16>::v8, wb[s][fb]), b[pb], acc[fb][pb]);
     }
-#pragma unroll
-    for (int s = 0; s < KS; ++s)
-#pragma unroll
-      for (int fb = 0; fb < FBN; ++fb) cur[s][fb] = nxt[s][fb];
   }
+  lateHook();   // after the last MFMA: the weight registers are dead, so the prefetch adds no pressure
 }
 
 template <int FBN, int PBN> __device__ __forceinline__ void zero_acc(f32x16 (&acc)[FBN][PBN]) {
@@ -187,6 +175,10 @@ __global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 ? 4 : 2)) void chain_kern
   if (n0 >= P) return;
   const int nf = L.n_freqs;
   const float so = L.scale_output;
+  if (p.dbg_stagger && (blockIdx.x & 1)) {   // experiment: de-phase odd tiles (L2-bound vs HBM-bound sweeps)
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    while (__builtin_amdgcn_s_memtime() - t0 < (unsigned long long)p.dbg_stagger * 1000ull) __builtin_amdgcn_s_sleep(64);
+  }
   int tsn = 0;
   auto TS = [&]() {   // debug timeline: wave 0 of workgroup 100 stamps phase boundaries
     if (p.dbg_times && blockIdx.x == 100 && tid == 0) p.dbg_times[tsn] = __builtin_amdgcn_s_memtime();

@@ -26,6 +26,7 @@ struct ChainParams {
   int32_t vecStride;
   uint16_t* spill; SpillLayout sp;
   int32_t dbg_alias;          // timing experiments only (ISDF_DEBUG_ALIAS_SPILL): alias tiles' spills
+  int32_t dbg_stagger;        // experiment: odd tiles start this many kilo-cycles late (ISDF_DEBUG_STAGGER)
   unsigned long long* dbg_times;  // optional [256] s_memtime stamps of one workgroup (ISDF_DEBUG_TIMELINE)
 };
 
