@@ -130,9 +130,22 @@ __device__ __forceinline__ int frag16_off(int w, int fb, int pb, int qp, int lan
 // (layer, feature) has exactly ONE owner half-wave per workgroup, so the
 // per-workgroup partial needs no atomics (same-address global atomics from 422
 // workgroups serialise at ~12 ns each and dominated the first version).
+template <int CTRL> __device__ __forceinline__ float dpp_mov(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float half_wave_sum(float v) {
+  // butterfly over 32 lanes on the VALU: quad_perm xor1, xor2, row_half_mirror (8), row_mirror (16 lanes),
+  // then one swizzle for the 16<->16 exchange (__shfl_xor = 5 dependent ds_bpermute round trips:
+  // the reverse-sweep epilogues took ~15 k cycles with it, ~8 k with this)
+  v += dpp_mov<0xB1>(v);      // quad_perm [1,0,3,2]
+  v += dpp_mov<0x4E>(v);      // quad_perm [2,3,0,1]
+  v += dpp_mov<0x141>(v);     // row_half_mirror: quads 0<->1, 2<->3 (values are quad-uniform)
+  v += dpp_mov<0x140>(v);     // row_mirror: lower 8 <-> upper 8 of each 16-lane row
+  v += __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x401F));   // xor 16 within 32 lanes
+  return v;
+}
 __device__ __forceinline__ void half_wave_store(float v, float* dst, int lane) {
-#pragma unroll
-  for (int m = 16; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  v = half_wave_sum(v);
   if ((lane & 31) == 0) *dst = v;
 }
 
@@ -659,7 +672,9 @@ __global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 ? 4 : 2)) void chain_kern
       if (!top) {
         zero_acc(acc);
         gemm<false, HD / 16, FB, PB, ROWB>(acc, wptr(setBwdB, L.bwdMat[li + 1], HD), (HD / 16) * 64, X, 0, lane, pf);
+        TS();
         lds_barrier();
+        TS();
       } else {
         pf();
       }
@@ -689,7 +704,9 @@ __global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 ? 4 : 2)) void chain_kern
           bsum[e] = 0.f; wsum[e] = 0.f;
         }
       });
+      TS();
       lds_barrier();
+      TS();
     }
   }
 }
