@@ -14,7 +14,7 @@ LIB = os.path.join(HERE, "libisdf_hip.so")
 SOURCES = ["chain.hip", "dw.hip", "sampler.hip", "optim.hip", "ingest.hip", "capi.hip"]
 HEADERS = ["isdf_common.h", "chain_params.h", os.path.join("..", "..", "include", "isdf_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-command-line-argument",
-         "-fno-gpu-rdc"]
+         "-fno-gpu-rdc"] + os.environ.get("ISDF_EXTRA_HIPCC_FLAGS", "").split()
 
 
 def _hipcc():

@@ -25,6 +25,12 @@
 
 namespace isdf {
 
+#ifndef GEMM_ROLLING_REFILL
+#define GEMM_ROLLING_REFILL 0
+#endif
+#ifndef GEMM_LDS_DEPTH
+#define GEMM_LDS_DEPTH 1   // k-steps of activation-operand LDS reads in flight ahead of the MFMAs
+#endif
 constexpr float kHalfPi = 1.5707963267948966f;
 constexpr float kBeta = 100.f;
 
@@ -56,14 +62,47 @@ __device__ __forceinline__ void lds_barrier() {
   asm volatile("" ::: "memory");
 }
 
+// All global traffic of the hot loops goes through buffer descriptors: address = SGPR descriptor + SGPR offset +
+// ONE per-lane VGPR (lane*16) + immediate.  With flat 64-bit addresses the compiler kept a VGPR pair per matrix /
+// spill tensor alive across the layer loops, spilled them, and reloaded them inside the MFMA stream behind
+// s_waitcnt vmcnt(0).
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ uint4 nt_load16(const uint4* p) {
-  const u32x4 v = __builtin_nontemporal_load((const u32x4*)p);
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+__device__ __forceinline__ rsrc_t make_rsrc(const void* base, uint32_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, bytes, 0x00020000);
+}
+constexpr int kAuxNT = 2;   // non-temporal: the spill stream must not evict the L2-resident weight copies
+template <int AUX> __device__ __forceinline__ uint4 bload16(rsrc_t r, int voff, int soff) {
+  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, AUX);
   return make_uint4(v[0], v[1], v[2], v[3]);
 }
-__device__ __forceinline__ void nt_store16(uint4 x, uint4* p) {
+// 16-byte non-temporal store of frag16 piece `c` (byte c*1024 past soff; c&3 goes into the immediate).
+// Hand-issued: with an SGPR soffset the compiler inserts NO wait state between a buffer_store_dwordx4 and a
+// following VALU write of its data registers (it assumes that form is exempt from the >64-bit store-data hazard).
+// On gfx950 it is not: a v_pk_mul_f32 scheduled right behind the store corrupted bytes 4-5 of lanes 12-15 of
+// every 16 in memory (found as NaN weight gradients; the same code through global_store_dwordx4 was clean).
+// srd = {base_lo, base_hi, bytes, 0x00020000} in SGPRs.  The compiler's vmcnt bookkeeping does not see this
+// store; an uncounted store can only make its later counted waits stricter, never too weak.
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ i32x4 make_srd(const void* base, uint32_t bytes) {
+  const unsigned long long b = (unsigned long long)base;
+  i32x4 d;
+  d[0] = __builtin_amdgcn_readfirstlane((int)(uint32_t)b);
+  d[1] = __builtin_amdgcn_readfirstlane((int)(uint32_t)(b >> 32)) & 0xffff;
+  d[2] = (int)bytes; d[3] = 0x00020000;
+  return d;
+}
+#define ISDF_BSTORE16_NT(IMM) \
+  asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen offset:" #IMM " nt\n\ts_nop 1" ::"v"(v), "v"(voff), "s"(srd), "s"(soff) : "memory")
+__device__ __forceinline__ void bstore16_nt(uint4 x, i32x4 srd, int voff, int soff, int c) {
   u32x4 v; v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w;
-  __builtin_nontemporal_store(v, (u32x4*)p);
+  soff += (c >> 2) * 4096;
+  switch (c & 3) {
+    case 0: ISDF_BSTORE16_NT(0); break;
+    case 1: ISDF_BSTORE16_NT(1024); break;
+    case 2: ISDF_BSTORE16_NT(2048); break;
+    default: ISDF_BSTORE16_NT(3072); break;
+  }
 }
 
 __device__ __forceinline__ int swz(int row, int colbytes) { return colbytes ^ ((row & 15) << 4); }
@@ -76,38 +115,88 @@ __device__ __forceinline__ int swz(int row, int colbytes) { return colbytes ^ ((
 // barrier keeps the load block ahead of the MFMAs, and the k-steps are fully unrolled.
 // `lateHook` (the epilogue's spill prefetch) is issued right after the last MFMA: issuing it
 // mid-GEMM overlapped more latency but pushed the train kernel 130 VGPRs over its budget.
+template <int FBN> struct WChunk { uint4 v[8 / FBN][FBN]; };   // one chunk of packed weight fragments (32 VGPRs)
+struct WRef { int soff; int rb; };   // byte offset of a wave's slice of a packed matrix in the shadow buffer + row-block stride (bytes)
+
+// request chunk 0 of a matrix (the whole 8-k-step slice up front: one L2 round trip per chunk).
+// Measured: issuing this at the END of the previous epilogue, ahead of the barrier, is 13 us SLOWER for the whole
+// kernel (and costs 32 spilled VGPRs); so is re-requesting each fragment register right after its MFMAs
+// (GEMM_ROLLING_REFILL, +4 us) and reading the activation operand two k-steps ahead (GEMM_LDS_DEPTH 2, +3 us).
+template <int FBN>
+__device__ __forceinline__ void preload_w(WChunk<FBN>& wq, rsrc_t rw, WRef r, int lane16) {
+  constexpr int CK = 8 / FBN;
+#pragma unroll
+  for (int s = 0; s < CK; ++s)
+#pragma unroll
+    for (int fb = 0; fb < FBN; ++fb)
+      wq.v[s][fb] = bload16<0>(rw, lane16 + (s & 3) * 1024, r.soff + fb * r.rb + (s >> 2) * 4096);
+}
+
 template <bool F16, int KSTEPS, int FBN, int PBN, int ROWB, typename Hook>
-__device__ __forceinline__ void gemm(f32x16 (&acc)[FBN][PBN], const uint4* __restrict__ wp,
-                                     int rbStride, const char* xl, int colByteBase, int lane, Hook&& lateHook) {
+__device__ __forceinline__ void gemm(f32x16 (&acc)[FBN][PBN], WChunk<FBN>& wq, rsrc_t rw, WRef wr, const char* xl,
+                                     int colByteBase, int lane, Hook&& lateHook) {
   constexpr int CK = 8 / FBN;                  // k-steps per chunk: CK*FBN uint4 = 32 VGPRs
   static_assert(KSTEPS % CK == 0, "K must be a multiple of the chunk");
+  static_assert((ROWB & 1023) == 0, "row base must leave the swizzle bits clear");
   constexpr int NCH = KSTEPS / CK;
+  typedef typename Op<F16>::v8 v8;
   const int j = lane & 31, hi = lane >> 5;
-  const int sw = (j & 15) << 4;
-  const uint4* wl = wp + lane;
-#pragma unroll 1
-  for (int ch = 0; ch < NCH; ++ch) {
-    uint4 wb[CK][FBN];
+  // LDS address of (row j, k-step ks) = rowbase + ((ks*32 + hi*16) ^ sw): the swizzle only touches bits 4-7 and
+  // the row base has them clear, so it is ONE xor of a per-lane base with the constant (ks&7)*32, the rest
+  // (point block, region, ks>>3) being immediate offsets.
+  const int xlane = j * ROWB + ((hi * 16) ^ ((j & 15) << 4));   // byte offset from the tile base (kept an offset so the LDS address space survives)
+  const int lane16 = lane * 16;
+  preload_w(wq, rw, wr, lane16);
+  // One chunk: the activation operand is read GEMM_LDS_DEPTH k-steps ahead of the MFMAs that consume it, and
+  // (REFILL) each weight fragment register is re-requested for the next chunk as soon as its MFMAs have issued,
+  // so CK fragment loads stay in flight across the chunk boundary with no extra registers.
+  auto chunk = [&](int ch, auto refill) {
+    const int k0 = ch * CK;
+    int xch = (xlane ^ ((k0 & 7) * 32)) + (k0 >> 3) * 256 + colByteBase;
+    // opaque to the optimiser: otherwise the 8 per-k-step addresses (xch ^ s*32) are hoisted out of the layer loops as
+    // lane constants, spilled, and reloaded in the middle of the MFMA stream behind an s_waitcnt vmcnt(0)
+    asm volatile("" : "+v"(xch));
+    auto readb = [&](int s, v8 (&b)[PBN]) {
 #pragma unroll
-    for (int s = 0; s < CK; ++s)
+      for (int pb = 0; pb < PBN; ++pb)
+        b[pb] = __builtin_bit_cast(v8, *(const uint4*)(xl + ((xch ^ (s * 32)) + pb * 32 * ROWB)));
+    };
+    constexpr int D = GEMM_LDS_DEPTH < CK ? GEMM_LDS_DEPTH : CK - 1;
+    v8 b[D + 1][PBN];
 #pragma unroll
-      for (int fb = 0; fb < FBN; ++fb) wb[s][fb] = wl[fb * rbStride + (ch * CK + s) * 64];
+    for (int s = 0; s < D; ++s) readb(s, b[s]);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int s = 0; s < CK; ++s) {
-      typename Op<F16>::v8 b[PBN];
-#pragma unroll
-      for (int pb = 0; pb < PBN; ++pb) {
-        const int cb = (colByteBase + (ch * CK + s) * 32 + hi * 16) ^ sw;
-        b[pb] = __builtin_bit_cast(typename Op<F16>::v8, *(const uint4*)(xl + (pb * 32 + j) * ROWB + cb));
-      }
+      if (s + D < CK) readb(s + D, b[(s + D) % (D + 1)]);
 #pragma unroll
       for (int fb = 0; fb < FBN; ++fb)
 #pragma unroll
         for (int pb = 0; pb < PBN; ++pb)
-          acc[fb][pb] = Op<F16>::mfma(__builtin_bit_cast(typename Op<F16>::v8, wb[s][fb]), b[pb], acc[fb][pb]);
+          acc[fb][pb] = Op<F16>::mfma(__builtin_bit_cast(v8, wq.v[s][fb]), b[s % (D + 1)][pb], acc[fb][pb]);
+#if GEMM_ROLLING_REFILL
+      if (decltype(refill)::value) {
+#pragma unroll
+        for (int fb = 0; fb < FBN; ++fb)
+          wq.v[s][fb] = bload16<0>(rw, lane16 + (s & 3) * 1024, wr.soff + fb * wr.rb + (ch + 1) * CK * 1024 + (s >> 2) * 4096);
+      }
+#endif
+      __builtin_amdgcn_sched_barrier(0);
     }
-  }
+#if !GEMM_ROLLING_REFILL
+    if (decltype(refill)::value) {
+#pragma unroll
+      for (int s = 0; s < CK; ++s)
+#pragma unroll
+        for (int fb = 0; fb < FBN; ++fb)
+          wq.v[s][fb] = bload16<0>(rw, lane16 + (s & 3) * 1024, wr.soff + fb * wr.rb + (ch + 1) * CK * 1024 + (s >> 2) * 4096);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#endif
+  };
+#pragma unroll 1
+  for (int ch = 0; ch < NCH - 1; ++ch) chunk(ch, std::true_type{});
+  chunk(NCH - 1, std::false_type{});
   lateHook();   // after the last MFMA: the weight registers are dead, so the prefetch adds no pressure
 }
 
@@ -173,7 +262,7 @@ __global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 ? 4 : 2)) void chain_kern
   typedef Tile<HD, EP> T;
   static_assert(HD == EP, "tile kernels assume padded embedding width == hidden width");
   constexpr int BM = T::BM, FB = T::FB, PB = T::PB, ROWB = T::ROWB;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+  extern __shared__ __attribute__((aligned(1024))) char smem[];   // gemm() needs bits 4-9 of row bases clear
   char* X = smem;
   float* xs = (float*)(smem + T::OFF_XS);
   float* part = (float*)(smem + T::OFF_PART);
@@ -181,8 +270,22 @@ __global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 ? 4 : 2)) void chain_kern
   float* red = (float*)(smem + T::OFF_RED);
 
   const NetLayout& L = p.lay;
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int j = lane & 31, hi = lane >> 5;
+  const int tid = threadIdx.x;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: weight/spill offsets stay in SGPRs
+  static_assert(FB <= 2, "the LDS write addressing below assumes one or two feature blocks per wave");
+  // Lane ids and the LDS write base.  They are RE-DERIVED from an opaque copy of threadIdx at every phase
+  // (refresh()): derived lane constants otherwise stay live across the GEMMs, get spilled there and are
+  // reloaded behind s_waitcnt vmcnt(0) in the middle of the MFMA stream (the kernel runs at a 128-VGPR budget).
+  int lane, j, hi, lane16, xw;
+  auto refresh = [&] {
+    int t = tid;
+    asm volatile("" : "+v"(t));
+    lane = t & 63; j = lane & 31; hi = lane >> 5; lane16 = lane * 16;
+    // byte offset of (row j, feature block w*FB, qp 0, first half) in the swizzled X tile: the swizzle, the
+    // block-in-4 selector, qp (32 B) and the half (16 B) only meet in bits 4-7, so blocks differ by one XOR
+    xw = j * ROWB + 8 * hi + (((j & 15) << 4) ^ (((w * FB) & 3) * 64)) + ((w * FB) >> 2) * 256;
+  };
+  refresh();
   const int64_t P = p.n_valid ? (int64_t)(*p.n_valid) * p.S : p.n_points_host;
   const int64_t n0 = (int64_t)blockIdx.x * BM;
   if (n0 >= P) return;
@@ -198,14 +301,38 @@ __global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 ? 4 : 2)) void chain_kern
     ++tsn;
   };
   TS();
+  // debug: wall-clock (s_memrealtime, 100 MHz) start/end of every 4th workgroup -> slots 128..511
+  if (p.dbg_times && tid == 0 && (blockIdx.x & 3) == 0 && blockIdx.x < 4 * 190)
+    p.dbg_times[128 + blockIdx.x / 2] = __builtin_amdgcn_s_memrealtime();
 
-  const uint16_t* setFwdA = p.shadow + L.setFwdA;
-  const uint16_t* setFwdB = p.shadow + L.setFwdB;
-  const uint16_t* setBwdA = p.shadow + L.setBwdA;
-  const uint16_t* setBwdB = p.shadow + L.setBwdB;
-  uint16_t* spillTile = p.spill + (int64_t)(p.dbg_alias ? (blockIdx.x % p.dbg_alias) : blockIdx.x) * BM * HD;
+  // element offsets of the four shadow weight sets inside the shadow buffer
+  const int64_t setFwdA = L.setFwdA, setFwdB = L.setFwdB, setBwdA = L.setBwdA, setBwdB = L.setBwdB;
+  // this tile's block of the spill buffer ([tile][tensor][BM*HD] bf16)
+  uint16_t* spillTile = p.spill + (int64_t)(p.dbg_alias ? (blockIdx.x % p.dbg_alias) : blockIdx.x) * p.sp.tileStride;
+  const rsrc_t rsW = make_rsrc(p.shadow, 0x7fffffffu);
+  const rsrc_t rsS = make_rsrc(spillTile, (uint32_t)(p.sp.tileStride * 2));   // loads (compiler-tracked)
+  const i32x4 srdS = make_srd(spillTile, (uint32_t)(p.sp.tileStride * 2));     // stores (bstore16_nt)
+  const rsrc_t rsP = make_rsrc(p.params, 0x7fffffffu);
+  // byte offset of this wave's first piece of a spilled tensor (frag16 order, see frag16_off)
+  auto sbase = [&](int64_t tensorOff) { return (int)(tensorOff * 2) + w * (FB * PB * 2) * 1024; };
+  constexpr auto cidx = [](int fb, int pb, int qp) { return (fb * PB + pb) * 2 + qp; };   // piece-of-64-lanes index within the wave
   float* vecTile = MODE == 2 ? p.vec_part + (int64_t)blockIdx.x * p.vecStride : nullptr;
-  (void)setFwdB; (void)setBwdB; (void)spillTile;
+  const rsrc_t rsV = make_rsrc(vecTile, MODE == 2 ? (uint32_t)p.vecStride * 4u : 0u);
+  (void)setFwdB; (void)setBwdB; (void)rsS; (void)rsV; (void)srdS;
+  // feature index of (fb, qp) blocks: f0 = ubase(fb, qp) + 4*hi
+  auto ubase = [&](int fb, int qp) { return w * (FB * 32) + fb * 32 + 16 * qp; };
+  // 8 fp32 parameters params[off + f0 + {0..3, 8..11}]
+  auto ld_params8 = [&](int offUniform, float (&o)[8]) {
+    const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rsP, 16 * hi, offUniform * 4, 0);
+    const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(rsP, 16 * hi + 32, offUniform * 4, 0);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { o[e] = __uint_as_float(a[e]); o[4 + e] = __uint_as_float(b[e]); }
+  };
+  // per-workgroup partial of a bias / out-layer gradient entry: sum over the half-wave's 32 points
+  auto vec_store = [&](float v, int elemUniform) {
+    v = half_wave_sum(v);
+    if (j == 0) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsV, 16 * hi, elemUniform * 4, 0);
+  };
 
   // ------------------------------------------------------------------ PE stage
   // thread (pt, part): embedding.py:95-111.  Region 2 of X (cols HD..) gets the
@@ -244,7 +371,7 @@ __global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 ? 4 : 2)) void chain_kern
     }
   }
   lds_barrier();
-  auto spill_region = [&](int colElemBase, uint16_t* dstTile) {
+  auto spill_region = [&](int colElemBase, int64_t tensorOff) {
     // copy a bf16 [BM][HD] region of X to global in frag16 order (16 B per lane)
 #pragma unroll
     for (int fb = 0; fb < FB; ++fb)
@@ -252,24 +379,28 @@ __global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 ? 4 : 2)) void chain_kern
       for (int pb = 0; pb < PB; ++pb)
 #pragma unroll
         for (int qp = 0; qp < 2; ++qp) {
-          const int rowi = pb * 32 + j;
-          const int f0 = w * (FB * 32) + fb * 32 + 16 * qp + 4 * hi;
-          uint2 lo = *(const uint2*)(X + rowi * ROWB + swz(rowi, (colElemBase + f0) * 2));
-          uint2 hi2 = *(const uint2*)(X + rowi * ROWB + swz(rowi, (colElemBase + f0 + 8) * 2));
-          nt_store16(make_uint4(lo.x, lo.y, hi2.x, hi2.y), (uint4*)(dstTile + frag16_off<FB, PB>(w, fb, pb, qp, lane)));
+          const int lb = (xw ^ (64 * fb + 32 * qp)) + colElemBase * 2 + pb * 32 * ROWB;
+          uint2 lo = *(const uint2*)(X + lb);
+          uint2 hi2 = *(const uint2*)(X + (lb ^ 16));
+          bstore16_nt(make_uint4(lo.x, lo.y, hi2.x, hi2.y), srdS, lane16, sbase(tensorOff), cidx(fb, pb, qp));
         }
   };
+  refresh();
   if (MODE == 2) {
-    spill_region(0, spillTile + p.sp.A[0]);
+    spill_region(0, p.sp.A[0]);
     lds_barrier();
   }
 
   // ------------------------------------------------------------------ forward
   f32x16 acc[FB][PB];
   const int rbW = w * FB;  // first 32-row block of this wave
-  auto wptr = [&](const uint16_t* set, int64_t matOff, int kp) {
-    return (const uint4*)(set + matOff) + (int64_t)rbW * (kp / 16) * 64;
+  auto wptr = [&](int64_t set, int64_t matOff, int kp) {
+    return WRef{(int)((set + matOff) * 2) + rbW * (kp / 16) * 1024, (kp / 16) * 1024};
   };
+  auto fwdW = [&](int64_t set, int li) {   // forward-orientation matrix of layer li (K = EP | HD+EP | HD)
+    return wptr(set, L.fwdMat[li], li == 0 ? EP : (li == L.cat ? HD + EP : HD));
+  };
+  WChunk<FB> wq;   // the weight-fragment registers of the running gemm
   // iterate the wave's accumulator as (fb, pb, qp) blocks of 8 values:
   // values v[0..3] -> features f0..f0+3, v[4..7] -> f0+8..f0+11, point row = pb*32+j
   auto for_blocks2 = [&](auto&& fn, auto&& tail) {
@@ -277,26 +408,24 @@ __global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 ? 4 : 2)) void chain_kern
     for (int fb = 0; fb < FB; ++fb)
 #pragma unroll
       for (int qp = 0; qp < 2; ++qp) {
-        const int f0 = w * (FB * 32) + fb * 32 + 16 * qp + 4 * hi;
 #pragma unroll
-        for (int pb = 0; pb < PB; ++pb) fn(fb, pb, qp, f0, pb * 32 + j);
-        tail(f0);
+        for (int pb = 0; pb < PB; ++pb) fn(fb, pb, qp, pb * 32 + j);
+        tail(fb, qp);
       }
   };
-  auto for_blocks = [&](auto&& fn) { for_blocks2(fn, [](int) {}); };
+  auto for_blocks = [&](auto&& fn) { for_blocks2(fn, [](int, int) {}); };
   // A spilled tile is re-read by the same lanes that wrote it; the reads are
   // issued BEFORE the layer's GEMM (prefetch) and consumed in its epilogue.
   struct Pre { uint4 v[FB][2][PB]; };
-  const int laneChunk = frag16_off<FB, PB>(w, 0, 0, 0, lane) / 8;   // uint4 index of this lane's first piece
-  auto chunkOf = [](int fb, int pb, int qp) { return ((fb * PB + pb) * 2 + qp) * 64; };   // compile-time
   auto prefetch = [&](int64_t tensorOff, Pre& pr) {
-    const uint4* base = (const uint4*)(spillTile + tensorOff) + laneChunk;
+    const int sb = sbase(tensorOff);
 #pragma unroll
     for (int fb = 0; fb < FB; ++fb)
 #pragma unroll
       for (int qp = 0; qp < 2; ++qp)
 #pragma unroll
-        for (int pb = 0; pb < PB; ++pb) pr.v[fb][qp][pb] = nt_load16(base + chunkOf(fb, pb, qp));
+        for (int pb = 0; pb < PB; ++pb)
+          pr.v[fb][qp][pb] = bload16<kAuxNT>(rsS, lane16 + (cidx(fb, pb, qp) & 3) * 1024, sb + (cidx(fb, pb, qp) >> 2) * 4096);
   };
   auto load_tile8 = [&](const Pre& pr, int fb, int pb, int qp, float (&o)[8]) {
     const uint4 u = pr.v[fb][qp][pb];
@@ -307,15 +436,15 @@ __global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 ? 4 : 2)) void chain_kern
   };
   auto store_tile8 = [&](int64_t tensorOff, int fb, int pb, int qp, const float (&v)[8]) {
     const uint2 a = pack4<false>(v[0], v[1], v[2], v[3]), b = pack4<false>(v[4], v[5], v[6], v[7]);
-    // streamed once: non-temporal so the spill stream does not evict the L2-resident weight copies
-    nt_store16(make_uint4(a.x, a.y, b.x, b.y), (uint4*)(spillTile + tensorOff) + laneChunk + chunkOf(fb, pb, qp));
+    bstore16_nt(make_uint4(a.x, a.y, b.x, b.y), srdS, lane16, sbase(tensorOff), cidx(fb, pb, qp));
   };
-  auto put_x = [&](bool f16, int row, int f0, const float (&v)[8], int colElemBase) {
+  auto put_x = [&](bool f16, int fb, int pb, int qp, const float (&v)[8], int colElemBase) {
     uint2 a, b;
     if (f16) { a = pack4<true>(v[0], v[1], v[2], v[3]); b = pack4<true>(v[4], v[5], v[6], v[7]); }
     else { a = pack4<false>(v[0], v[1], v[2], v[3]); b = pack4<false>(v[4], v[5], v[6], v[7]); }
-    *(uint2*)(X + row * ROWB + swz(row, (colElemBase + f0) * 2)) = a;
-    *(uint2*)(X + row * ROWB + swz(row, (colElemBase + f0 + 8) * 2)) = b;
+    const int lb = (xw ^ (64 * fb + 32 * qp)) + colElemBase * 2 + pb * 32 * ROWB;   // see refresh()
+    *(uint2*)(X + lb) = a;           // features f0 .. f0+3
+    *(uint2*)(X + (lb ^ 16)) = b;    // features f0+8 .. f0+11
   };
 
   float rawp[PB];
@@ -324,39 +453,34 @@ __global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 ? 4 : 2)) void chain_kern
 
   for (int li = 0; li < L.L; ++li) {
     zero_acc(acc);
+    refresh();
     if (li == 0)
-      gemm<F16, EP / 16, FB, PB, ROWB>(acc, wptr(setFwdA, L.fwdMat[0], EP), (EP / 16) * 64, X, HD * 2, lane, [] {});
+      gemm<F16, EP / 16, FB, PB, ROWB>(acc, wq, rsW, fwdW(setFwdA, li), X, HD * 2, lane, [] {});
     else if (li == L.cat)
-      gemm<F16, (HD + EP) / 16, FB, PB, ROWB>(acc, wptr(setFwdA, L.fwdMat[li], HD + EP), ((HD + EP) / 16) * 64, X, 0, lane, [] {});
+      gemm<F16, (HD + EP) / 16, FB, PB, ROWB>(acc, wq, rsW, fwdW(setFwdA, li), X, 0, lane, [] {});
     else
-      gemm<F16, HD / 16, FB, PB, ROWB>(acc, wptr(setFwdA, L.fwdMat[li], HD), (HD / 16) * 64, X, 0, lane, [] {});
+      gemm<F16, HD / 16, FB, PB, ROWB>(acc, wq, rsW, fwdW(setFwdA, li), X, 0, lane, [] {});
     TS();
     lds_barrier();  // all waves finished reading region 1
     TS();
-    const float* bias = p.params + L.offB[li];
+    refresh();
     const bool last = li == L.L - 1;
-    const float* wout = p.params + L.offWout;
     if (!last) {
       float bv[8];
-      for_blocks2([&](int fb, int pb, int qp, int f0, int row) {
-        if (pb == 0) {
-          const float4 b0 = *(const float4*)(bias + f0), b1 = *(const float4*)(bias + f0 + 8);
-          bv[0] = b0.x; bv[1] = b0.y; bv[2] = b0.z; bv[3] = b0.w; bv[4] = b1.x; bv[5] = b1.y; bv[6] = b1.z; bv[7] = b1.w;
-        }
+      for_blocks2([&](int fb, int pb, int qp, int row) {
+        if (pb == 0) ld_params8(L.offB[li] + ubase(fb, qp), bv);
         float a[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) a[e] = softplus_f(acc[fb][pb][8 * qp + e] + bv[e]);
         if (MODE >= 1) store_tile8(p.sp.A[li + 1], fb, pb, qp, a);
-        put_x(F16, row, f0, a, 0);
-      }, [](int) {});
+        put_x(F16, fb, pb, qp, a, 0);
+      }, [](int, int) {});
     } else {
       float bv[8], wv[8];
-      for_blocks2([&](int fb, int pb, int qp, int f0, int row) {
+      for_blocks2([&](int fb, int pb, int qp, int row) {
         if (pb == 0) {
-          const float4 b0 = *(const float4*)(bias + f0), b1 = *(const float4*)(bias + f0 + 8);
-          const float4 w0 = *(const float4*)(wout + f0), w1 = *(const float4*)(wout + f0 + 8);
-          bv[0] = b0.x; bv[1] = b0.y; bv[2] = b0.z; bv[3] = b0.w; bv[4] = b1.x; bv[5] = b1.y; bv[6] = b1.z; bv[7] = b1.w;
-          wv[0] = w0.x; wv[1] = w0.y; wv[2] = w0.z; wv[3] = w0.w; wv[4] = w1.x; wv[5] = w1.y; wv[6] = w1.z; wv[7] = w1.w;
+          ld_params8(L.offB[li] + ubase(fb, qp), bv);
+          ld_params8(L.offWout + ubase(fb, qp), wv);
         }
         float a[8], pl[8];
 #pragma unroll
@@ -368,10 +492,10 @@ __global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 ? 4 : 2)) void chain_kern
         }
         if (MODE >= 1) {
           store_tile8(p.sp.A[li + 1], fb, pb, qp, a);
-          put_x(F16, row, f0, pl, 0);
+          put_x(F16, fb, pb, qp, pl, 0);
           if (MODE == 2) store_tile8(p.sp.P[li], fb, pb, qp, pl);
         }
-      }, [](int) {});
+      }, [](int, int) {});
     }
     if (last) {
 #pragma unroll
@@ -407,19 +531,21 @@ __global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 ? 4 : 2)) void chain_kern
   for (int li = L.L - 1; li >= 1; --li) {
     Pre preA;
     zero_acc(acc);
-    gemm<F16, HD / 16, FB, PB, ROWB>(acc, wptr(setBwdA, L.bwdMat[li], HD), (HD / 16) * 64, X, 0, lane,
+    refresh();
+    gemm<F16, HD / 16, FB, PB, ROWB>(acc, wq, rsW, wptr(setBwdA, L.bwdMat[li], HD), X, 0, lane,
                                      [&] { prefetch(p.sp.A[li], preA); });
     TS();
     lds_barrier();
     TS();
+    refresh();
     const bool toR2 = (li - 1 == L.cat);
-    for_blocks([&](int fb, int pb, int qp, int f0, int row) {
+    for_blocks([&](int fb, int pb, int qp, int row) {
       float a[8], pv[8];
       load_tile8(preA, fb, pb, qp, a);
 #pragma unroll
       for (int e = 0; e < 8; ++e) pv[e] = acc[fb][pb][8 * qp + e] * s1_from_a(a[e]);
-      put_x(F16, row, f0, pv, 0);
-      if (toR2) put_x(F16, row, f0, pv, HD);
+      put_x(F16, fb, pb, qp, pv, 0);
+      if (toR2) put_x(F16, fb, pb, qp, pv, HD);
       if (MODE == 2) store_tile8(p.sp.P[li - 1], fb, pb, qp, pv);
     });
     TS();
@@ -428,48 +554,68 @@ __global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 ? 4 : 2)) void chain_kern
   }
   // Eg = [W_in^T | W_cat[:,HD:]^T] [p_0 ; p_cat]   (rows = embedding features)
   zero_acc(acc);
-  gemm<F16, (2 * HD) / 16, FB, PB, ROWB>(acc, wptr(setBwdA, L.bwdG, 2 * HD), ((2 * HD) / 16) * 64, X, 0, lane, [] {});
-  // g_x' = J_pe^T Eg : contract the wave's 64 embedding rows against d emb / d x'
-  {
-    float g0[PB], g1[PB], g2[PB];
+  // the loss stage's per-ray inputs are requested behind the G gemm so that its single working wave
+  // does not start with a dependent HBM round trip
+  float li_bnd = 0.f, li_c[3] = {0.f, 0.f, 0.f}, li_dz[2] = {0.f, 0.f}, li_t[3] = {0.f, 0.f, 0.f}, li_n[3] = {0.f, 0.f, 0.f};
+  auto loss_inputs = [&] {
+    if (MODE != 2 || tid >= BM) return;
+    const int64_t n = n0 + tid;
+    if (n >= P) return;
+    const int64_t ray = n / p.S;
+    if (p.loss.bounds_method == 0) {  // loss.py:13-22
+      li_c[0] = p.dirsC[ray * 3]; li_c[1] = p.dirsC[ray * 3 + 1]; li_c[2] = p.dirsC[ray * 3 + 2];
+      li_dz[0] = p.depth[ray]; li_dz[1] = p.z_vals[n];
+      li_t[0] = p.dirsW[ray * 3]; li_t[1] = p.dirsW[ray * 3 + 1]; li_t[2] = p.dirsW[ray * 3 + 2];
+    } else {
+      li_bnd = p.pc_bounds[n];
+      li_t[0] = p.pc_grad_vec[n * 3]; li_t[1] = p.pc_grad_vec[n * 3 + 1]; li_t[2] = p.pc_grad_vec[n * 3 + 2];
+    }
+    if (p.normals) { li_n[0] = p.normals[ray * 3]; li_n[1] = p.normals[ray * 3 + 1]; li_n[2] = p.normals[ray * 3 + 2]; }
+  };
+  refresh();
+  gemm<F16, (2 * HD) / 16, FB, PB, ROWB>(acc, wq, rsW, wptr(setBwdA, L.bwdG, 2 * HD), X, 0, lane, loss_inputs);
+  // g_x' = J_pe^T Eg.  Eg goes through the (now idle) X tile as fp32 [BM][HD] so the contraction can run in
+  // the PE stage's (point, direction-slice) mapping: 2*nf sin/cos per direction per thread and wave-uniform
+  // direction constants, instead of one cos + index arithmetic per accumulator element (which took
+  // ~45 k cycles per tile, profiles/r01_chain_timeline_final.txt stamp 45).
+  lds_barrier();   // every wave finished reading X for the G gemm
+  refresh();
 #pragma unroll
-    for (int pb = 0; pb < PB; ++pb) { g0[pb] = g1[pb] = g2[pb] = 0.f; }
-    const int half = N_DIRS * nf;
-#pragma unroll
-    for (int fb = 0; fb < FB; ++fb)
-#pragma unroll
-      for (int pb = 0; pb < PB; ++pb) {
-        const int row = pb * 32 + j;
-        const float y0 = xs[row * 4], y1 = xs[row * 4 + 1], y2 = xs[row * 4 + 2];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int f = w * (FB * 32) + fb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-          const float v = acc[fb][pb][r];
-          if (f < 3) {
-            g0[pb] += f == 0 ? v : 0.f; g1[pb] += f == 1 ? v : 0.f; g2[pb] += f == 2 ? v : 0.f;
-          } else if (f < L.E) {
-            const int t = f - 3;
-            const bool isCos = t >= half;
-            const int tt = isCos ? t - half : t;
-            const int d = tt / nf, fq = tt - d * nf;
-            const float fr = (float)(1 << fq);
-            const float dx = kDirs[0][d], dy = kDirs[1][d], dz = kDirs[2][d];
-            const float xb = (y0 * dx + y1 * dy + y2 * dz) * fr;
-            const float c = __cosf(isCos ? xb + kHalfPi : xb) * fr * v;
-            g0[pb] += c * dx; g1[pb] += c * dy; g2[pb] += c * dz;
-          }
-        }
-      }
-    lds_barrier();  // part[] reuse; X reads of the G gemm complete
+  for (int fb = 0; fb < FB; ++fb)
 #pragma unroll
     for (int pb = 0; pb < PB; ++pb) {
-      const float a0 = g0[pb] + __shfl_xor(g0[pb], 32, 64), a1 = g1[pb] + __shfl_xor(g1[pb], 32, 64),
-                  a2 = g2[pb] + __shfl_xor(g2[pb], 32, 64);
-      if (hi == 0) {
-        float* d = part + (w * BM + pb * 32 + j) * 4;
-        d[0] = a0; d[1] = a1; d[2] = a2;
+      const int row = pb * 32 + j;
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        const int f0 = w * (FB * 32) + fb * 32 + 8 * rq + 4 * hi;
+        *(float4*)(X + row * ROWB + swz(row, f0 * 4)) =
+            make_float4(acc[fb][pb][4 * rq], acc[fb][pb][4 * rq + 1], acc[fb][pb][4 * rq + 2], acc[fb][pb][4 * rq + 3]);
       }
     }
+  lds_barrier();
+  {
+    const int pt = tid & (BM - 1), prt = tid / BM;
+    constexpr int NPART = (T::NW * 64) / BM;
+    const float y0 = xs[pt * 4], y1 = xs[pt * 4 + 1], y2 = xs[pt * 4 + 2];
+    const char* row = X + pt * ROWB;
+    auto eg = [&](int feat) { return *(const float*)(row + swz(pt, feat * 4)); };
+    float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+    if (prt == 0) { g0 = eg(0); g1 = eg(1); g2 = eg(2); }
+    const int half = N_DIRS * nf;
+    for (int d = prt; d < N_DIRS; d += NPART) {
+      const float dx = kDirs[0][d], dy = kDirs[1][d], dz = kDirs[2][d];
+      const float proj = y0 * dx + y1 * dy + y2 * dz;
+      float fr = 1.f, c = 0.f;
+      for (int f = 0; f < nf; ++f) {
+        const float xb = proj * fr;
+        // d sin(xb)/d proj = cos(xb) fr ;  d sin(xb + pi/2)/d proj = cos(xb + pi/2) fr
+        c += (__cosf(xb) * eg(3 + d * nf + f) + __cosf(xb + kHalfPi) * eg(3 + half + d * nf + f)) * fr;
+        fr *= 2.f;
+      }
+      g0 += c * dx; g1 += c * dy; g2 += c * dz;
+    }
+    float* dst = part + (prt * BM + pt) * 4;
+    dst[0] = g0; dst[1] = g1; dst[2] = g2;
   }
   lds_barrier();
 
@@ -494,17 +640,13 @@ __global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 ? 4 : 2)) void chain_kern
       const isdf_loss_cfg& lc = p.loss;
       const int64_t ray = n / p.S;
       const int s = (int)(n - ray * p.S);
-      float bnd, tx, ty, tz;  // bound and target gradient direction
-      if (lc.bounds_method == 0) {  // loss.py:13-22
-        const float cx = p.dirsC[ray * 3], cy = p.dirsC[ray * 3 + 1], cz = p.dirsC[ray * 3 + 2];
-        bnd = sqrtf(cx * cx + cy * cy + cz * cz) * (p.depth[ray] - p.z_vals[n]);
-        tx = -p.dirsW[ray * 3]; ty = -p.dirsW[ray * 3 + 1]; tz = -p.dirsW[ray * 3 + 2];
-      } else {
-        bnd = p.pc_bounds[n];
-        tx = p.pc_grad_vec[n * 3]; ty = p.pc_grad_vec[n * 3 + 1]; tz = p.pc_grad_vec[n * 3 + 2];
+      float bnd = li_bnd, tx = li_t[0], ty = li_t[1], tz = li_t[2];   // bound and target gradient direction
+      if (lc.bounds_method == 0) {
+        bnd = sqrtf(li_c[0] * li_c[0] + li_c[1] * li_c[1] + li_c[2] * li_c[2]) * (li_dz[0] - li_dz[1]);
+        tx = -tx; ty = -ty; tz = -tz;
       }
       if (p.normals && (s == 0 || tx != tx)) {  // surface sample, or NaN target (trainer.py:823-824)
-        tx = p.normals[ray * 3]; ty = p.normals[ray * 3 + 1]; tz = p.normals[ray * 3 + 2];
+        tx = li_n[0]; ty = li_n[1]; tz = li_n[2];
       }
       // sdf loss (loss.py:122-164)
       const bool freeSp = bnd > lc.trunc_distance;
@@ -568,9 +710,8 @@ __global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 ? 4 : 2)) void chain_kern
     float v5[5] = {lsum[0], lsum[1], lsum[2], lsum[3], gbs[tid * 4 + 3]};
 #pragma unroll
     for (int k = 0; k < 5; ++k) {
-      float v = v5[k];
-#pragma unroll
-      for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+      float v = half_wave_sum(v5[k]);
+      v += __shfl_xor(v, 32, 64);
       if (lane == 0) red[w * 8 + k] = v;
     }
   }
@@ -588,6 +729,7 @@ __global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 ? 4 : 2)) void chain_kern
   }
 
   // ------------------------------------------------------------------ Ebar = J_pe gbar  -> region 2 (bf16)
+  if (tid < HD / 4) ((float4*)part)[tid] = ((const float4*)(p.params + L.offWout))[tid];   // w_out for the top epilogue
   {
     const int pt = tid & (BM - 1), prt = tid / BM;
     constexpr int NPART = (T::NW * 64) / BM;
@@ -613,27 +755,30 @@ __global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 ? 4 : 2)) void chain_kern
     }
   }
   lds_barrier();
-  spill_region(HD, spillTile + p.sp.GB[0]);
+  spill_region(HD, p.sp.GB[0]);
 
   // ------------------------------------------------------------------ adjoint of the first reverse sweep (upward)
-  for (int li = 0; li < L.L; ++li) {
-    Pre preA, preP;
-    auto pf = [&] { prefetch(p.sp.A[li + 1], preA); prefetch(p.sp.P[li], preP); };
+  // The top layer's epilogue also IS the top of the ordinary reverse sweep (zbar_L needs only a_L, the
+  // injection just computed and sbar*w_out), so INJ[L-1] never leaves registers and the reverse sweep
+  // starts at layer L-2 with its operand already in the X tile.
+  auto adj_gemm = [&](int li, auto&& pf) {
     zero_acc(acc);
+    refresh();
     if (li == 0)
-      gemm<false, EP / 16, FB, PB, ROWB>(acc, wptr(setFwdB, L.fwdMat[0], EP), (EP / 16) * 64, X, HD * 2, lane, pf);
+      gemm<false, EP / 16, FB, PB, ROWB>(acc, wq, rsW, fwdW(setFwdB, li), X, HD * 2, lane, pf);
     else if (li == L.cat)
-      gemm<false, (HD + EP) / 16, FB, PB, ROWB>(acc, wptr(setFwdB, L.fwdMat[li], HD + EP), ((HD + EP) / 16) * 64, X, 0, lane, pf);
+      gemm<false, (HD + EP) / 16, FB, PB, ROWB>(acc, wq, rsW, fwdW(setFwdB, li), X, 0, lane, pf);
     else
-      gemm<false, HD / 16, FB, PB, ROWB>(acc, wptr(setFwdB, L.fwdMat[li], HD), (HD / 16) * 64, X, 0, lane, pf);
+      gemm<false, HD / 16, FB, PB, ROWB>(acc, wq, rsW, fwdW(setFwdB, li), X, 0, lane, pf);
+  };
+  for (int li = 0; li < L.L - 1; ++li) {
+    Pre preA, preP;
+    adj_gemm(li, [&] { prefetch(p.sp.A[li + 1], preA); prefetch(p.sp.P[li], preP); });
     TS();
     lds_barrier();
     TS();
-    const bool last = li == L.L - 1;
-    float qsum[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) qsum[e] = 0.f;
-    for_blocks2([&](int fb, int pb, int qp, int f0, int row) {
+    refresh();
+    for_blocks([&](int fb, int pb, int qp, int row) {
       float a[8], pv[8], qb[8], inj[8];
       load_tile8(preA, fb, pb, qp, a);
       load_tile8(preP, fb, pb, qp, pv);
@@ -643,72 +788,100 @@ __global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 ? 4 : 2)) void chain_kern
         const float s1 = s1_from_a(a[e]);
         qb[e] = u * s1;
         inj[e] = kBeta * u * pv[e] * (1.f - s1);   // u * q * sigma''(z),  q*sigma' = p
-        if (last) qsum[e] += qb[e];
       }
       store_tile8(p.sp.INJ[li], fb, pb, qp, inj);
-      if (!last) {
-        put_x(false, row, f0, qb, 0);
-        store_tile8(p.sp.GB[li + 1], fb, pb, qp, qb);
-      }
-    }, [&](int f0) {
-      if (last) {  // d w_out += so * sum_pts qbar_L
+      put_x(false, fb, pb, qp, qb, 0);
+      store_tile8(p.sp.GB[li + 1], fb, pb, qp, qb);
+    });
+    TS();
+    lds_barrier();
+    TS();
+  }
+  {   // top layer (peeled: its three partial-sum streams must not raise the register pressure of the loop above)
+    const int li = L.L - 1;
+    Pre preA, preP;
+    adj_gemm(li, [&] { prefetch(p.sp.A[li + 1], preA); prefetch(p.sp.P[li], preP); });
+    TS();
+    lds_barrier();
+    TS();
+    refresh();
+    float qsum[8], bsum[8], wsum[8], wv[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          half_wave_store(so * qsum[e], vecTile + L.L * HD + f0 + (e & 3) + 8 * (e >> 2), lane);
-          qsum[e] = 0.f;
-        }
+    for (int e = 0; e < 8; ++e) { qsum[e] = 0.f; bsum[e] = 0.f; wsum[e] = 0.f; }
+    for_blocks2([&](int fb, int pb, int qp, int row) {
+      if (pb == 0) {   // w_out staged in LDS (part[]) by the Ebar stage
+        const int f0 = ubase(fb, qp) + 4 * hi;
+        const float4 w0 = *(const float4*)(part + f0), w1 = *(const float4*)(part + f0 + 8);
+        wv[0] = w0.x; wv[1] = w0.y; wv[2] = w0.z; wv[3] = w0.w; wv[4] = w1.x; wv[5] = w1.y; wv[6] = w1.z; wv[7] = w1.w;
+      }
+      float a[8], pv[8], zb[8];
+      load_tile8(preA, fb, pb, qp, a);
+      load_tile8(preP, fb, pb, qp, pv);
+      const float sb = gbs[row * 4 + 3];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float u = acc[fb][pb][8 * qp + e];
+        const float s1 = s1_from_a(a[e]);
+        qsum[e] += u * s1;
+        zb[e] = sb * wv[e] * s1 + kBeta * u * pv[e] * (1.f - s1);
+        bsum[e] += zb[e];
+        wsum[e] += sb * a[e];
+      }
+      store_tile8(p.sp.ZB[li], fb, pb, qp, zb);
+      if (li > 0) put_x(false, fb, pb, qp, zb, 0);
+    }, [&](int fb, int qp) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int f = ubase(fb, qp) + (e & 3) + 8 * (e >> 2);   // + 4*hi in the lane offset
+        vec_store(so * qsum[e], L.L * HD + f);        // d w_out += so * sum_pts qbar_L
+        vec_store(wsum[e], L.L * HD + HD + f);        // d w_out += sum_pts sbar*so * a_L
+        vec_store(bsum[e], li * HD + f);
+        qsum[e] = 0.f; bsum[e] = 0.f; wsum[e] = 0.f;
       }
     });
+    TS();
     lds_barrier();
+    TS();
   }
 
   // ------------------------------------------------------------------ ordinary reverse sweep with injection
-  {
-    const float* wout = p.params + L.offWout;
-    for (int li = L.L - 1; li >= 0; --li) {
-      const bool top = li == L.L - 1;
-      Pre preA, preI;
-      auto pf = [&] { prefetch(p.sp.A[li + 1], preA); prefetch(p.sp.INJ[li], preI); };
-      if (!top) {
-        zero_acc(acc);
-        gemm<false, HD / 16, FB, PB, ROWB>(acc, wptr(setBwdB, L.bwdMat[li + 1], HD), (HD / 16) * 64, X, 0, lane, pf);
-        TS();
-        lds_barrier();
-        TS();
-      } else {
-        pf();
+  for (int li = L.L - 2; li >= 0; --li) {
+    Pre preA, preI;
+    auto pf = [&] { prefetch(p.sp.A[li + 1], preA); prefetch(p.sp.INJ[li], preI); };
+    zero_acc(acc);
+    refresh();
+    gemm<false, HD / 16, FB, PB, ROWB>(acc, wq, rsW, wptr(setBwdB, L.bwdMat[li + 1], HD), X, 0, lane, pf);
+    TS();
+    lds_barrier();
+    TS();
+    refresh();
+    float bsum[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bsum[e] = 0.f;
+    for_blocks2([&](int fb, int pb, int qp, int row) {
+      float a[8], inj[8], zb[8];
+      load_tile8(preA, fb, pb, qp, a);
+      load_tile8(preI, fb, pb, qp, inj);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        zb[e] = acc[fb][pb][8 * qp + e] * s1_from_a(a[e]) + inj[e];
+        bsum[e] += zb[e];
       }
-      float bsum[8], wsum[8];
+      store_tile8(p.sp.ZB[li], fb, pb, qp, zb);
+      if (li > 0) put_x(false, fb, pb, qp, zb, 0);
+    }, [&](int fb, int qp) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) { bsum[e] = 0.f; wsum[e] = 0.f; }
-      for_blocks2([&](int fb, int pb, int qp, int f0, int row) {
-        float a[8], inj[8], zb[8];
-        load_tile8(preA, fb, pb, qp, a);
-        load_tile8(preI, fb, pb, qp, inj);
-        const float sb = gbs[row * 4 + 3];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float ab = top ? sb * wout[f0 + (e & 3) + 8 * (e >> 2)] : acc[fb][pb][8 * qp + e];
-          zb[e] = ab * s1_from_a(a[e]) + inj[e];
-          bsum[e] += zb[e];
-          if (top) wsum[e] += sb * a[e];
-        }
-        store_tile8(p.sp.ZB[li], fb, pb, qp, zb);
-        if (li > 0) put_x(false, row, f0, zb, 0);
-      }, [&](int f0) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const int f = f0 + (e & 3) + 8 * (e >> 2);
-          half_wave_store(bsum[e], vecTile + li * HD + f, lane);
-          if (top) half_wave_store(wsum[e], vecTile + L.L * HD + HD + f, lane);
-          bsum[e] = 0.f; wsum[e] = 0.f;
-        }
-      });
-      TS();
-      lds_barrier();
-      TS();
-    }
+      for (int e = 0; e < 8; ++e) {
+        vec_store(bsum[e], li * HD + ubase(fb, qp) + (e & 3) + 8 * (e >> 2));
+        bsum[e] = 0.f;
+      }
+    });
+    TS();
+    lds_barrier();
+    TS();
   }
+  if (p.dbg_times && tid == 0 && (blockIdx.x & 3) == 0 && blockIdx.x < 4 * 190)
+    p.dbg_times[129 + blockIdx.x / 2] = __builtin_amdgcn_s_memrealtime();
 }
 
 // ---------------------------------------------------------------------------

@@ -82,8 +82,8 @@ __global__ __launch_bounds__(512, 2) void dw_kernel(const DwParams p) {
   auto issue = [&](int st, uint4 (&ra)[CH], uint4 (&rb)[CH]) {
     const int u = split + (st >> 1) * DW_SPLITK;      // half-tile index
     const int t = u / HALVES, half = u % HALVES;
-    const uint4* ta = (const uint4*)(p.spill + ((st & 1) ? offP : offZ) + (int64_t)t * TILE_PTS * HD);
-    const uint4* tb = (const uint4*)(p.spill + ((st & 1) ? offG : offI) + (int64_t)t * TILE_PTS * HD);
+    const uint4* ta = (const uint4*)(p.spill + ((st & 1) ? offP : offZ) + (int64_t)t * p.sp.tileStride);
+    const uint4* tb = (const uint4*)(p.spill + ((st & 1) ? offG : offI) + (int64_t)t * p.sp.tileStride);
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
       int pt, f0;

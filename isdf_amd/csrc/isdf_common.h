@@ -47,7 +47,8 @@ struct NetLayout {
 // tensor = nTiles * TILE_PTS * HD 16-bit elements in "frag16" order (see
 // chain.hip): bf16 always.
 struct SpillLayout {
-  int64_t tensorElems;   // per tensor
+  int64_t tensorElems;   // per tensor per tile (TILE_PTS * HD); the buffer is [tile][tensor][tensorElems]
+  int64_t tileStride;    // elements between consecutive tiles (= tensor count * tensorElems)
   int64_t A[MAXL + 1];   // A[0] = embedding, A[li+1] = activation after layer li
   int64_t P[MAXL];       // d sdf / d z_li
   int64_t GB[MAXL];      // GB[0] = Ebar, GB[li] = adjoint entering layer li (li >= 1)
@@ -132,7 +133,7 @@ __host__ __device__ inline DwUnit dw_unit(const NetLayout& l, int u) {
 inline void make_workspace(const NetLayout& l, int64_t maxPts, int64_t maxRays, bool train, WorkspaceLayout* w) {
   w->nTiles = (maxPts + TILE_PTS - 1) / TILE_PTS;
   SpillLayout& s = w->sp;
-  s.tensorElems = w->nTiles * TILE_PTS * (int64_t)l.HD;
+  s.tensorElems = TILE_PTS * (int64_t)l.HD;   // offsets below are WITHIN a tile's block
   int64_t o = 0;
   for (int i = 0; i <= l.L; ++i) { s.A[i] = o; o += s.tensorElems; }
   if (train) {
@@ -141,7 +142,9 @@ inline void make_workspace(const NetLayout& l, int64_t maxPts, int64_t maxRays, 
     for (int i = 0; i < l.L; ++i) { s.INJ[i] = o; o += s.tensorElems; }
     for (int i = 0; i < l.L; ++i) { s.ZB[i] = o; o += s.tensorElems; }
   }
-  s.totalElems = o;
+  s.tileStride = o;
+  s.totalElems = o * w->nTiles;
+  o = s.totalElems;
   int64_t b = 0;
   w->offSpill = b; b += o * 2; b = (b + 255) / 256 * 256;
   (void)maxRays;

@@ -18,10 +18,22 @@ noise = torch.zeros(s["max_rays"], sc.S, device="cuda")
 for _ in range(3):
     eng.train_step(s, lc, sc, noise=noise)
 torch.cuda.synchronize()
-ts = eng._ws[-4096:].view(torch.int64).cpu().numpy()
-ts = ts[ts > 0]
+raw = eng._ws[-4096:].view(torch.int64).cpu().numpy()
+ts = raw[:128]; ts = ts[ts > 0]
 t0 = ts[0]
-print("n stamps", len(ts), "(s_memtime ticks; 100 MHz constant clock => x10 ns)")
+print("n stamps", len(ts), "(s_memtime ticks = shader clock cycles)")
 prev = t0
 for i, t in enumerate(ts):
     print("%3d  t=%8d  d=%7d" % (i, t - t0, t - prev)); prev = t
+# wall-clock start/end (100 MHz s_memrealtime) of every 4th workgroup
+se = raw[128:128 + 2 * 190].reshape(-1, 2)
+se = se[(se[:, 0] > 0) & (se[:, 1] > 0)]
+if len(se):
+    b = se[:, 0].min()
+    st, en = (se[:, 0] - b) / 100.0, (se[:, 1] - b) / 100.0
+    print("workgroups sampled %d: start us min/med/max %.1f %.1f %.1f  end us min/med/max %.1f %.1f %.1f  duration us min/med/max %.1f %.1f %.1f"
+          % (len(se), st.min(), float(sorted(st)[len(st) // 2]), st.max(), en.min(), float(sorted(en)[len(en) // 2]), en.max(),
+             (en - st).min(), float(sorted(en - st)[len(st) // 2]), (en - st).max()))
+    k = list(se[:, 0]).index(se[:, 0].min())
+    for i in range(0, len(se), max(1, len(se) // 24)):
+        print("  wg %4d  start %7.1f  end %7.1f" % (4 * i, st[i], en[i]))
