@@ -189,11 +189,14 @@ def main():
     def one_step(i, ev=None):
         s = eng.sample(tr.frames.depth_batch, tr.frames.T_WC_batch, tr.frames.normal_batch, fidx, fidx, sc,
                        seed=dp.rank_seed(1, rank), offset=i)
+        og = tr.optimiser.param_groups[0]
+        fused = None if group is not None else dict(lr=og["lr"], weight_decay=og["weight_decay"], betas=og["betas"],
+                                                    eps=og["eps"])
         eng.train_step(s, lc, sc, prof_events=ev, noise_std=tr.noise_std, noise_seed=1 + rank,
-                       noise_offset=i)                              # in-kernel N(0,1)*noise_std (fc_map.py:106-108)
-        if group is not None:
+                       noise_offset=i, optim=fused)                 # in-kernel N(0,1)*noise_std (fc_map.py:106-108)
+        if group is not None:   # data parallel: all-reduce the summed gradient, then AdamW + repack
             dp.allreduce_(eng.reduce_buf, group)
-        tr.optimiser.step()
+            tr.optimiser.step()
         la, fa = eng.frame_avg(F)
         tr.frames.frame_avg_losses[fidx.long()] = fa            # trainer.py:979
         return s
@@ -262,7 +265,7 @@ def main():
             "valid_points_per_step": round(P, 1),
             "final_total_loss": round(final_loss, 5),
             "kernel_ms": {"chain": round(t_chain * 1e3, 4), "dw": round(t_dw * 1e3, 4),
-                          "reduce+finalize": round(t_red * 1e3, 4)},
+                          "tail(reduce,adamw,pack,finalize)" if group is None else "reduce+finalize": round(t_red * 1e3, 4)},
             "roofline": {"bound": "mfma", "kernel": "chain_kernel (fused PE+MLP fwd / input-grad / adjoint / reverse)",
                          "achieved": round(flops_chain / t_chain / 1e12, 3), "peak": MFMA_PEAK / 1e12,
                          "unit": "TFLOP/s", "frac": round(flops_chain / t_chain / MFMA_PEAK, 5), "traffic": traffic,

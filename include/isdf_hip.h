@@ -191,6 +191,30 @@ int isdf_train_step(const isdf_net_cfg* net, const isdf_loss_cfg* loss, const fl
                     const void* shadow, const isdf_step_args* a, const isdf_step_out* o,
                     void* workspace, int64_t workspace_bytes, void* stream);
 
+/* Single-GPU form of the same step with the optimiser fused in: what
+ * `total_loss.backward(); self.optimiser.step(); self.optimiser.zero_grad()` do in
+ * Trainer.step (isdf/modules/trainer.py:981-983) as ONE call.  After the dW kernel a single
+ * launch sums the gradient, applies AdamW to params / exp_avg / exp_avg_sq in place,
+ * refreshes the packed operand copies in `shadow`, and finalises the loss sums and block
+ * bins.  reduce_buf is written exactly as by isdf_train_step (the gradient is the SUM over
+ * points; AdamW divides by the point count).  Bit-identical to isdf_train_step followed by
+ * isdf_adamw(count_ptr = &loss_sums[ISDF_LS_COUNT]).  Data-parallel runs use the two-call
+ * form because the gradient all-reduce sits between the reduction and the update.          */
+typedef struct isdf_optim_args {
+  float* params;        /* [n_params] fp32 master weights, updated in place               */
+  float* exp_avg;       /* [n_params] AdamW first moment                                   */
+  float* exp_avg_sq;    /* [n_params] AdamW second moment                                  */
+  void* shadow;         /* packed operand copies (isdf_shadow_bytes), refreshed in place   */
+  float lr, beta1, beta2, eps, weight_decay;
+  float grad_scale;     /* multiplies the mean gradient (1.0 for the reference's loss)     */
+  int32_t step;         /* 1-based optimiser step (bias correction)                        */
+  int32_t reserved;
+} isdf_optim_args;
+
+int isdf_train_step_adamw(const isdf_net_cfg* net, const isdf_loss_cfg* loss, const isdf_step_args* a,
+                          const isdf_step_out* o, const isdf_optim_args* opt, void* workspace,
+                          int64_t workspace_bytes, void* stream);
+
 /* nearest-surface-point bounds (bounds_method "pc", loss.py:56-89) */
 int isdf_bounds_pc(const int32_t* n_valid, int32_t max_rays, int32_t S, const float* pc,
                    const float* z_vals, const float* depth_sample, float* bounds,

@@ -16,7 +16,7 @@ ABI_VERSION = 1
 SYMBOLS = [
     "isdf_abi_version", "isdf_error_string", "isdf_param_count", "isdf_shadow_bytes",
     "isdf_workspace_bytes", "isdf_reduce_floats", "isdf_pack_weights", "isdf_sample_pixels",
-    "isdf_sample_along_rays", "isdf_sdf_eval", "isdf_train_step", "isdf_bounds_pc",
+    "isdf_sample_along_rays", "isdf_sdf_eval", "isdf_train_step", "isdf_train_step_adamw", "isdf_bounds_pc",
     "isdf_frame_avg", "isdf_adamw", "isdf_estimate_normals", "isdf_render_depth",
 ]
 
@@ -71,6 +71,13 @@ class StepOut(C.Structure):
                 ("tot_loss_mat", C.c_void_p), ("prof_events", C.POINTER(C.c_void_p))]
 
 
+class OptimArgs(C.Structure):
+    _fields_ = [("params", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p), ("shadow", C.c_void_p),
+                ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
+                ("weight_decay", C.c_float), ("grad_scale", C.c_float), ("step", C.c_int32), ("reserved", C.c_int32)]
+
+
+
 class IsdfError(RuntimeError):
     pass
 
@@ -103,6 +110,7 @@ def lib():
     L.isdf_sample_along_rays.argtypes = [P(SampleArgs), P(SampleOut), vp]
     L.isdf_sdf_eval.argtypes = [P(NetCfg), vp, vp, vp, i64, vp, vp, vp, vp, i64, vp]
     L.isdf_train_step.argtypes = [P(NetCfg), P(LossCfg), vp, vp, P(StepArgs), P(StepOut), vp, i64, vp]
+    L.isdf_train_step_adamw.argtypes = [P(NetCfg), P(LossCfg), P(StepArgs), P(StepOut), P(OptimArgs), vp, i64, vp]
     L.isdf_bounds_pc.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp, vp]
     L.isdf_frame_avg.argtypes = [vp, i64, i32, vp, vp, vp]
     L.isdf_adamw.argtypes = [P(NetCfg), vp, vp, vp, vp, vp, f32, f32, f32, f32, f32, f32, i32, vp, vp]

@@ -19,6 +19,11 @@ int launch_pack(const NetLayout& L, const float* params, uint16_t* shadow, hipSt
 int launch_finalize(const float* wg_loss, int64_t maxTiles, const int32_t* n_valid, int S, const float* tot_ws,
                     const int64_t* ib, const int64_t* ih, const int64_t* iw, int F, int H, int W, float* loss_sums,
                     float* bl, float* bc, hipStream_t st);
+int launch_step_tail(const NetLayout& L, const float* dwPart, const float* vecPart, int vecStride, float* grad,
+                     float* params, float* m, float* v, uint16_t* shadow, float grad_scale, float lr, float b1, float b2,
+                     float eps, float wd, int step, const float* wg_loss, int64_t maxTiles, const int32_t* n_valid, int S,
+                     const float* tot_ws, const int64_t* ib, const int64_t* ih, const int64_t* iw, int F, int H, int W,
+                     float* loss_sums, float* bl, float* bc, hipStream_t st);
 int launch_frame_avg(const float* bl, const float* bc, int F, float* la, float* fa, hipStream_t st);
 int launch_bounds_pc(const int32_t* n_valid, int max_rays, int S, const float* pc, const float* z, const float* depth,
                      float* bounds, float* gv, hipStream_t st);
@@ -113,9 +118,9 @@ int isdf_sdf_eval(const isdf_net_cfg* net, const float* params, const void* shad
   return launch_chain(p, mode, w.nTiles, (hipStream_t)stream);
 }
 
-int isdf_train_step(const isdf_net_cfg* net, const isdf_loss_cfg* loss, const float* params, const void* shadow,
-                    const isdf_step_args* a, const isdf_step_out* o, void* workspace, int64_t workspace_bytes,
-                    void* stream) {
+static int train_step_impl(const isdf_net_cfg* net, const isdf_loss_cfg* loss, const float* params, const void* shadow,
+                           const isdf_step_args* a, const isdf_step_out* o, void* workspace, int64_t workspace_bytes,
+                           void* stream, const isdf_optim_args* opt) {
   NetLayout l; int rc = make_layout(net, &l);
   if (rc) return rc;
   if (!layout_supported(l)) return ISDF_EUNSUPPORTED;
@@ -162,19 +167,41 @@ int isdf_train_step(const isdf_net_cfg* net, const isdf_loss_cfg* loss, const fl
   rc = launch_dw(d, st);
   if (rc) return rc;
   if (ev && hipEventRecord(ev[2], st) != hipSuccess) return ISDF_EHIP;
+  float* lossSums = o->reduce_buf + l.n_params;
+  float* blockLoss = lossSums + 8;
+  float* blockCnt = blockLoss + (int64_t)a->n_frames * 64;
+  if (opt) {   // single-GPU tail: slab reduction + AdamW + operand repack + loss/bin finalisation in one launch
+    rc = launch_step_tail(l, dwPart, vecPart, w.vecStride, o->reduce_buf, opt->params, opt->exp_avg, opt->exp_avg_sq,
+                          (uint16_t*)opt->shadow, opt->grad_scale, opt->lr, opt->beta1, opt->beta2, opt->eps,
+                          opt->weight_decay, opt->step, wgLoss, w.nTiles, a->n_valid, a->S, totLoss, a->indices_b,
+                          a->indices_h, a->indices_w, a->n_frames, a->H, a->W, lossSums, blockLoss, blockCnt, st);
+    if (rc) return rc;
+    if (ev && hipEventRecord(ev[3], st) != hipSuccess) return ISDF_EHIP;
+    return ISDF_OK;
+  }
   ReduceParams rp = {};
   rp.lay = l; rp.dwPart = dwPart; rp.vecPart = vecPart; rp.vecStride = w.vecStride; rp.n_valid = a->n_valid;
   rp.S = a->S; rp.grad = o->reduce_buf;
   rc = launch_dw_reduce(rp, st);
   if (rc) return rc;
-  float* lossSums = o->reduce_buf + l.n_params;
-  float* blockLoss = lossSums + 8;
-  float* blockCnt = blockLoss + (int64_t)a->n_frames * 64;
   rc = launch_finalize(wgLoss, w.nTiles, a->n_valid, a->S, totLoss, a->indices_b, a->indices_h, a->indices_w,
                        a->n_frames, a->H, a->W, lossSums, blockLoss, blockCnt, st);
   if (rc) return rc;
   if (ev && hipEventRecord(ev[3], st) != hipSuccess) return ISDF_EHIP;
   return ISDF_OK;
+}
+
+int isdf_train_step(const isdf_net_cfg* net, const isdf_loss_cfg* loss, const float* params,
+                    const void* shadow, const isdf_step_args* a, const isdf_step_out* o,
+                    void* workspace, int64_t workspace_bytes, void* stream) {
+  return train_step_impl(net, loss, params, shadow, a, o, workspace, workspace_bytes, stream, nullptr);
+}
+
+int isdf_train_step_adamw(const isdf_net_cfg* net, const isdf_loss_cfg* loss, const isdf_step_args* a,
+                          const isdf_step_out* o, const isdf_optim_args* opt, void* workspace,
+                          int64_t workspace_bytes, void* stream) {
+  if (!opt || !opt->params || !opt->exp_avg || !opt->exp_avg_sq || !opt->shadow || opt->step < 1) return ISDF_EINVAL;
+  return train_step_impl(net, loss, opt->params, opt->shadow, a, o, workspace, workspace_bytes, stream, opt);
 }
 
 int isdf_bounds_pc(const int32_t* n_valid, int32_t max_rays, int32_t S, const float* pc, const float* z_vals,

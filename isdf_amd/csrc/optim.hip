@@ -9,21 +9,28 @@
 namespace isdf {
 
 // ---- AdamW (decoupled weight decay, bias-corrected) --------------------------
+struct AdamwCoef { float lr, b1, b2, eps, wd, bc1, bc2_sqrt; };
+__device__ __forceinline__ float adamw_update(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
+                                              int64_t i, float gsum, float gs, const AdamwCoef& c) {
+  // no FMA contraction: the stand-alone kernel and the fused step tail must round identically
+#pragma clang fp contract(off)
+  const float gi = gsum * gs;
+  float pi = p[i] * (1.f - c.lr * c.wd);
+  const float mi = c.b1 * m[i] + (1.f - c.b1) * gi;
+  const float vi = c.b2 * v[i] + (1.f - c.b2) * gi * gi;
+  const float denom = sqrtf(vi) / c.bc2_sqrt + c.eps;
+  pi -= (c.lr / c.bc1) * (mi / denom);
+  p[i] = pi; m[i] = mi; v[i] = vi;
+  return pi;
+}
 __global__ void adamw_kernel(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
                              const float* __restrict__ g, const float* __restrict__ count_ptr,
-                             float grad_scale, float lr, float b1, float b2, float eps, float wd,
-                             float bc1, float bc2_sqrt, int64_t n) {
+                             float grad_scale, AdamwCoef c, int64_t n) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   float gs = grad_scale;
   if (count_ptr) gs /= *count_ptr;
-  const float gi = g[i] * gs;
-  float pi = p[i] * (1.f - lr * wd);
-  const float mi = b1 * m[i] + (1.f - b1) * gi;
-  const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
-  const float denom = sqrtf(vi) / bc2_sqrt + eps;
-  pi -= (lr / bc1) * (mi / denom);
-  p[i] = pi; m[i] = mi; v[i] = vi;
+  adamw_update(p, m, v, i, g[i], gs, c);
 }
 
 // ---- packed MFMA-operand copies ------------------------------------------------
@@ -96,21 +103,25 @@ __global__ void pack_kernel(NetLayout L, const float* __restrict__ P, uint16_t* 
 // ray is dropped if a later ray has its key, and the survivors are binned with
 // LDS atomics; each frame's 64 bins are then written once (no global atomics).
 constexpr int FIN_CAP = 12288;   // rays per frame staged in LDS (48 KB)
-__global__ __launch_bounds__(1024) void finalize_kernel(const float* __restrict__ wg_loss, int64_t maxTiles,
-                                                        const int32_t* __restrict__ n_valid, int S,
-                                                        const float* __restrict__ tot_ws,
-                                                        const int64_t* __restrict__ ib, const int64_t* __restrict__ ih,
-                                                        const int64_t* __restrict__ iw, int n_frames, int H, int W,
-                                                        float* __restrict__ loss_sums, float* __restrict__ block_loss,
-                                                        float* __restrict__ block_cnt) {
-  __shared__ float sh[16][8];
-  __shared__ float binS[64], binC[64];
-  __shared__ int range[2];
-  __shared__ uint32_t keys[FIN_CAP];
+struct FinalizeArgs {
+  const float* wg_loss; int64_t maxTiles; const int32_t* n_valid; int S; const float* tot_ws;
+  const int64_t *ib, *ih, *iw; int n_frames, H, W;
+  float *loss_sums, *block_loss, *block_cnt;
+};
+struct FinalizeLds { float sh[16][8]; float binS[64], binC[64]; int range[2]; uint32_t keys[FIN_CAP]; };
+
+__device__ __forceinline__ void finalize_block(int block, const FinalizeArgs& a, FinalizeLds& lds) {
+  const float* __restrict__ wg_loss = a.wg_loss; const int64_t maxTiles = a.maxTiles; const int S = a.S;
+  const float* __restrict__ tot_ws = a.tot_ws;
+  const int64_t* __restrict__ ib = a.ib; const int64_t* __restrict__ ih = a.ih; const int64_t* __restrict__ iw = a.iw;
+  const int H = a.H, W = a.W;
+  float* __restrict__ loss_sums = a.loss_sums; float* __restrict__ block_loss = a.block_loss;
+  float* __restrict__ block_cnt = a.block_cnt;
+  auto& sh = lds.sh; auto& binS = lds.binS; auto& binC = lds.binC; auto& range = lds.range; auto& keys = lds.keys;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int64_t R = *n_valid;
+  const int64_t R = *a.n_valid;
   const int64_t P = R * S;
-  if (blockIdx.x == 0) {
+  if (block == 0) {
     const int64_t nTiles = (P + TILE_PTS - 1) / TILE_PTS;
     float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
     for (int64_t t = tid; t < nTiles && t < maxTiles; t += 1024)
@@ -131,7 +142,7 @@ __global__ __launch_bounds__(1024) void finalize_kernel(const float* __restrict_
     }
     return;
   }
-  const int f = blockIdx.x - 1;
+  const int f = block - 1;
   if (tid < 2) {  // lower_bound(indices_b, f + tid): rays are sorted by frame
     int64_t lo = 0, hi = R;
     const int64_t key = f + tid;
@@ -161,6 +172,118 @@ __global__ __launch_bounds__(1024) void finalize_kernel(const float* __restrict_
   }
   __syncthreads();
   if (tid < 64) { block_loss[f * 64 + tid] = binS[tid]; block_cnt[f * 64 + tid] = binC[tid]; }
+}
+__global__ __launch_bounds__(1024) void finalize_kernel(const FinalizeArgs a) {
+  __shared__ FinalizeLds lds;
+  finalize_block(blockIdx.x, a, lds);
+}
+
+// ---- fused step tail (single-GPU path) ------------------------------------------
+// One launch after the dW kernel: [weights: sum the K-split dW slabs -> gradient -> AdamW -> the four packed
+// 16-bit operand copies] | [biases / out layer: sum the per-tile partials -> gradient -> AdamW] | [loss sums and
+// per-frame block bins].  Replaces dw_reduce + vec_reduce + finalize + adamw + pack (5 launches, ~36 us of a
+// 347 us step) for world_size 1; the data-parallel path keeps them apart because the all-reduce of the
+// gradient sits between the reduction and the update.  Same summation order and AdamW arithmetic as the
+// separate kernels, so both paths produce bit-identical parameters.
+struct TailParams {
+  NetLayout lay;
+  const float* dwPart; const float* vecPart; int32_t vecStride;
+  float* grad;                       // [n_params] summed gradient (still written: reduce_buf contract)
+  float *params, *m, *v; uint16_t* shadow;
+  AdamwCoef c; float grad_scale;     // gradient = sum * grad_scale / (n_valid * S)
+  FinalizeArgs fin;
+  int nW, nV;                        // blocks of the weight and the vector sections
+};
+
+__device__ __forceinline__ void shadow_put(const NetLayout& L, uint16_t* sh, bool fwdSet, int64_t elem, float val) {
+  const uint32_t h = pack4<true>(val, 0.f, 0.f, 0.f).x & 0xffffu, b = pack4<false>(val, 0.f, 0.f, 0.f).x & 0xffffu;
+  sh[(fwdSet ? L.setFwdA : L.setBwdA) + elem] = (uint16_t)(L.fwd_f16 ? h : b);
+  sh[(fwdSet ? L.setFwdB : L.setBwdB) + elem] = (uint16_t)b;
+}
+// element offset of (row, k) inside a packed [rows/32][Kp/16][64][8] matrix (see pack_kernel)
+__device__ __forceinline__ int64_t packed_elem(int row, int k, int Kp) {
+  return ((((int64_t)(row >> 5) * (Kp >> 4) + (k >> 4)) * 64 + (row & 31) + 32 * ((k & 15) >> 3)) << 3) + (k & 7);
+}
+
+__global__ __launch_bounds__(1024) void step_tail_kernel(const TailParams p) {
+  __shared__ FinalizeLds lds;
+  const NetLayout& L = p.lay;
+  const int HD = L.HD;
+  const int b = blockIdx.x;
+  if (b >= p.nW + p.nV) { finalize_block(b - p.nW - p.nV, p.fin, lds); return; }
+  const int64_t P = (int64_t)(*p.fin.n_valid) * p.fin.S;
+  const float gs = p.grad_scale / (float)P;
+  if (b < p.nW) {
+    // ---- weights (dw_reduce_kernel's mapping: one thread per element of a 256x256 dW unit)
+    const int64_t idx = (int64_t)b * 1024 + threadIdx.x;
+    constexpr int64_t perUnit = (int64_t)DW_BLK * DW_BLK;
+    const int unit = (int)(idx / perUnit);
+    if (unit >= dw_units(L)) return;
+    const DwUnit du = dw_unit(L, unit);
+    const int rem = (int)(idx - unit * perUnit);
+    const int o = du.ob * DW_BLK + rem / DW_BLK;
+    const int ip = du.ib * DW_BLK + rem % DW_BLK;          // padded input column
+    const int li = du.li;
+    if (li == 0 && ip >= L.E) return;
+    if (li == L.cat && ip >= HD && ip - HD >= L.E) return;
+    const int col = ip;                                    // column in the fp32 weight [HD x K_li]
+    float s = 0.f;
+    const float* src = p.dwPart + (int64_t)unit * DW_SPLITK * perUnit + rem;
+#pragma unroll 4
+    for (int k = 0; k < DW_SPLITK; ++k) s += src[(int64_t)k * perUnit];
+    const int64_t pi = L.offW[li] + (int64_t)o * L.K[li] + col;
+    p.grad[pi] = s;
+    const float w = adamw_update(p.params, p.m, p.v, pi, s, gs, p.c);
+    // packed operand copies (pack_kernel's sources, inverted): forward orientation ...
+    const int KpF = li == 0 ? L.EP : (li == L.cat ? HD + L.EP : HD);
+    shadow_put(L, p.shadow, true, L.fwdMat[li] + packed_elem(o, col, KpF), w);
+    // ... W^T restricted to the first HD inputs (layers >= 1) ...
+    if (li >= 1 && col < HD) shadow_put(L, p.shadow, false, L.bwdMat[li] + packed_elem(col, o, HD), w);
+    // ... and the embedding-gradient matrix [W_in^T | W_cat[:, HD:]^T]
+    if (li == 0) shadow_put(L, p.shadow, false, L.bwdG + packed_elem(col, o, 2 * HD), w);
+    else if (li == L.cat && col >= HD) shadow_put(L, p.shadow, false, L.bwdG + packed_elem(col - HD, HD + o, 2 * HD), w);
+    return;
+  }
+  // ---- biases (L*HD), w_out (HD), b_out (1): vec_reduce_kernel's mapping, 64 parameters x 16 tile groups
+  float (*sh)[64] = (float (*)[64])lds.keys;
+  const int pi = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int v = (b - p.nW) * 64 + pi;
+  const int nVec = L.L * HD + HD + 1;
+  const int nTiles = (int)((P + TILE_PTS - 1) / TILE_PTS);
+  int slotA = 0, slotB = -1, dst = -1;
+  if (v < L.L * HD) { slotA = v; dst = L.offB[v / HD] + v % HD; }
+  else if (v < L.L * HD + HD) { slotA = v; slotB = v + HD; dst = L.offWout + (v - L.L * HD); }
+  else if (v < nVec) { slotA = L.L * HD + 2 * HD; dst = L.offBout; }
+  float s = 0.f, s2 = 0.f;
+  if (dst >= 0) {
+    int t = g;
+    for (; t + 48 < nTiles; t += 64) {      // 4 independent loads in flight per thread
+      const float* r0 = p.vecPart + (int64_t)t * p.vecStride;
+      const float a0 = r0[slotA], a1 = r0[(int64_t)16 * p.vecStride + slotA],
+                  a2 = r0[(int64_t)32 * p.vecStride + slotA], a3 = r0[(int64_t)48 * p.vecStride + slotA];
+      s += (a0 + a1) + (a2 + a3);
+      if (slotB >= 0) {
+        const float b0 = r0[slotB], b1 = r0[(int64_t)16 * p.vecStride + slotB],
+                    b2 = r0[(int64_t)32 * p.vecStride + slotB], b3 = r0[(int64_t)48 * p.vecStride + slotB];
+        s2 += (b0 + b1) + (b2 + b3);
+      }
+    }
+    for (; t < nTiles; t += 16) {
+      const float* row = p.vecPart + (int64_t)t * p.vecStride;
+      s += row[slotA];
+      if (slotB >= 0) s2 += row[slotB];
+    }
+    s += s2;
+  }
+  sh[g][pi] = s;
+  __syncthreads();
+  if (g == 0 && dst >= 0) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += sh[k][pi];
+    p.grad[dst] = t;
+    adamw_update(p.params, p.m, p.v, dst, t, gs, p.c);
+  }
 }
 
 __global__ void frame_avg_kernel(const float* __restrict__ block_loss, const float* __restrict__ block_cnt,
@@ -214,10 +337,8 @@ __global__ __launch_bounds__(256) void bounds_pc_kernel(const int32_t* __restric
 // ---- launchers -------------------------------------------------------------------
 int launch_adamw(float* p, float* m, float* v, const float* g, const float* cnt, float gs, float lr,
                  float b1, float b2, float eps, float wd, int step, int64_t n, hipStream_t st) {
-  const float bc1 = 1.f - powf(b1, (float)step);
-  const float bc2s = sqrtf(1.f - powf(b2, (float)step));
-  hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p, m, v, g, cnt, gs, lr,
-                     b1, b2, eps, wd, bc1, bc2s, n);
+  const AdamwCoef c = {lr, b1, b2, eps, wd, 1.f - powf(b1, (float)step), sqrtf(1.f - powf(b2, (float)step))};
+  hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p, m, v, g, cnt, gs, c, n);
   return hipGetLastError() == hipSuccess ? ISDF_OK : ISDF_EHIP;
 }
 int launch_pack(const NetLayout& L, const float* params, uint16_t* shadow, hipStream_t st) {
@@ -225,11 +346,33 @@ int launch_pack(const NetLayout& L, const float* params, uint16_t* shadow, hipSt
   hipLaunchKernelGGL(pack_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, st, L, params, shadow);
   return hipGetLastError() == hipSuccess ? ISDF_OK : ISDF_EHIP;
 }
+static FinalizeArgs finalize_args(const float* wg_loss, int64_t maxTiles, const int32_t* n_valid, int S, const float* tot_ws,
+                                  const int64_t* ib, const int64_t* ih, const int64_t* iw, int F, int H, int W,
+                                  float* loss_sums, float* bl, float* bc) {
+  FinalizeArgs a = {wg_loss, maxTiles, n_valid, S, tot_ws, ib, ih, iw, F, H, W, loss_sums, bl, bc};
+  return a;
+}
 int launch_finalize(const float* wg_loss, int64_t maxTiles, const int32_t* n_valid, int S, const float* tot_ws,
                     const int64_t* ib, const int64_t* ih, const int64_t* iw, int F, int H, int W, float* loss_sums,
                     float* bl, float* bc, hipStream_t st) {
-  hipLaunchKernelGGL(finalize_kernel, dim3(1 + F), dim3(1024), 0, st, wg_loss, maxTiles, n_valid, S, tot_ws, ib, ih,
-                     iw, F, H, W, loss_sums, bl, bc);
+  hipLaunchKernelGGL(finalize_kernel, dim3(1 + F), dim3(1024), 0, st,
+                     finalize_args(wg_loss, maxTiles, n_valid, S, tot_ws, ib, ih, iw, F, H, W, loss_sums, bl, bc));
+  return hipGetLastError() == hipSuccess ? ISDF_OK : ISDF_EHIP;
+}
+int launch_step_tail(const NetLayout& L, const float* dwPart, const float* vecPart, int vecStride, float* grad,
+                     float* params, float* m, float* v, uint16_t* shadow, float grad_scale, float lr, float b1, float b2,
+                     float eps, float wd, int step, const float* wg_loss, int64_t maxTiles, const int32_t* n_valid, int S,
+                     const float* tot_ws, const int64_t* ib, const int64_t* ih, const int64_t* iw, int F, int H, int W,
+                     float* loss_sums, float* bl, float* bc, hipStream_t st) {
+  TailParams p = {};
+  p.lay = L; p.dwPart = dwPart; p.vecPart = vecPart; p.vecStride = vecStride; p.grad = grad;
+  p.params = params; p.m = m; p.v = v; p.shadow = shadow; p.grad_scale = grad_scale;
+  p.c = AdamwCoef{lr, b1, b2, eps, wd, 1.f - powf(b1, (float)step), sqrtf(1.f - powf(b2, (float)step))};
+  p.fin = finalize_args(wg_loss, maxTiles, n_valid, S, tot_ws, ib, ih, iw, F, H, W, loss_sums, bl, bc);
+  const int64_t total = (int64_t)dw_units(L) * DW_BLK * DW_BLK;
+  p.nW = (int)((total + 1023) / 1024);
+  p.nV = (L.L * L.HD + L.HD + 1 + 63) / 64;
+  hipLaunchKernelGGL(step_tail_kernel, dim3((unsigned)(p.nW + p.nV + 1 + F)), dim3(1024), 0, st, p);
   return hipGetLastError() == hipSuccess ? ISDF_OK : ISDF_EHIP;
 }
 int launch_frame_avg(const float* bl, const float* bc, int F, float* la, float* fa, hipStream_t st) {

@@ -244,9 +244,12 @@ class Engine:
 
     # ---- training step ----------------------------------------------------------
     def train_step(self, smp, lc: LossConfig, sc: SampleConfig, noise=None, debug=False, prof_events=None,
-                   noise_std=0.0, noise_seed=0, noise_offset=0):
+                   noise_std=0.0, noise_seed=0, noise_offset=0, optim=None):
         """Everything between sampling and the optimiser.  Fills self.reduce_buf with
-        [grad sums | loss sums(8) | block_loss | block_cnt]; returns debug tensors."""
+        [grad sums | loss sums(8) | block_loss | block_cnt]; returns debug tensors.
+
+        optim: None, or a dict(lr, weight_decay, betas, eps, grad_scale) -> the single-GPU fused form
+        (isdf_train_step_adamw): the AdamW update and the operand repack happen inside the same call."""
         dev = self.device
         F, R0, S = smp["n_frames"], smp["max_rays"], smp["S"]
         nred = int(self.lib.isdf_reduce_floats(C.byref(self.cnet), F))
@@ -293,9 +296,22 @@ class Engine:
                                                  dbg["tot_loss_mat"].data_ptr())
             if lc.bounds_method == "pc":
                 dbg["pc_bounds"], dbg["pc_grad_vec"] = keep[-2].view(R0, S), keep[-1].view(R0, S, 3)
-        _ffi.check(self.lib.isdf_train_step(C.byref(self.cnet), C.byref(closs), _ffi.ptr(self.params),
-                                            _ffi.ptr(self.shadow), C.byref(a), C.byref(o), _ffi.ptr(ws),
-                                            ws.numel(), _stream()), "isdf_train_step")
+        if optim is not None:
+            self.opt_step += 1
+            betas = optim.get("betas", (0.9, 0.999))
+            q = _ffi.OptimArgs()
+            q.params, q.exp_avg, q.exp_avg_sq = self.params.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr()
+            q.shadow = self.shadow.data_ptr()
+            q.lr, q.weight_decay = float(optim.get("lr", 0.0013)), float(optim.get("weight_decay", 0.012))
+            q.beta1, q.beta2, q.eps = float(betas[0]), float(betas[1]), float(optim.get("eps", 1e-8))
+            q.grad_scale, q.step = float(optim.get("grad_scale", 1.0)), int(self.opt_step)
+            _ffi.check(self.lib.isdf_train_step_adamw(C.byref(self.cnet), C.byref(closs), C.byref(a), C.byref(o),
+                                                      C.byref(q), _ffi.ptr(ws), ws.numel(), _stream()),
+                       "isdf_train_step_adamw")
+        else:
+            _ffi.check(self.lib.isdf_train_step(C.byref(self.cnet), C.byref(closs), _ffi.ptr(self.params),
+                                                _ffi.ptr(self.shadow), C.byref(a), C.byref(o), _ffi.ptr(ws),
+                                                ws.numel(), _stream()), "isdf_train_step")
         dbg["_keep"] = keep
         return dbg
 

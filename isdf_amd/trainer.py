@@ -393,7 +393,9 @@ class HipTrainer:
         return out
 
     # ---- loss + backward (trainer.py:768-868, 981) -----------------------------------
-    def sdf_eval_and_loss(self, sample, do_avg_loss=True):
+    def sdf_eval_and_loss(self, sample, do_avg_loss=True, fused_optim=False):
+        """fused_optim: also apply the optimiser step inside the same native call (single-GPU fast path,
+        isdf_train_step_adamw); the caller must then NOT call self.optimiser.step()."""
         s, sc = sample["_raw"], sample["_sc"]
         noise = None
         if self.noise_std is not None:   # fc_map.py:106-108 (drawn even for 0, SURVEY q3)
@@ -406,6 +408,11 @@ class HipTrainer:
             rank = 0 if self.dist_group is None else torch.distributed.get_rank(self.dist_group)
             kw = dict(noise_std=self.noise_std, noise_seed=dp.rank_seed(self.seed, rank),
                       noise_offset=self._noise_count)
+        if fused_optim:
+            if self.dist_group is not None:
+                raise ValueError("fused_optim is the single-GPU path: the gradient all-reduce sits before the update")
+            g = self.optimiser.param_groups[0]
+            kw["optim"] = dict(lr=g["lr"], weight_decay=g["weight_decay"], betas=g["betas"], eps=g["eps"])
         self.engine.train_step(s, self._loss_cfg(), sc, noise=noise, **kw)
         if self.dist_group is not None:   # sums over ranks; AdamW divides by the reduced count
             dp.allreduce_(self.engine.reduce_buf, self.dist_group)
@@ -438,9 +445,11 @@ class HipTrainer:
                                         _idx=(fidx, nidx))
         self.active_pixels = {k: sample_pts[k] for k in ("indices_b", "indices_h", "indices_w")}
 
-        total_loss, losses, active_loss_approx, frame_avg_loss = self.sdf_eval_and_loss(sample_pts, True)
+        fused = self.dist_group is None and getattr(self, "fuse_optimiser", True)
+        total_loss, losses, active_loss_approx, frame_avg_loss = self.sdf_eval_and_loss(sample_pts, True, fused)
         self.frames.frame_avg_losses[fidx.long()] = frame_avg_loss
-        self.optimiser.step()                           # backward is fused into sdf_eval_and_loss
+        if not fused:
+            self.optimiser.step()                       # backward is fused into sdf_eval_and_loss
         self._step_count += 1
 
         torch.cuda.synchronize()                       # metrics.end_timing (metrics.py:25-38)

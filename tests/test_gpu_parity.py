@@ -223,6 +223,35 @@ def test_adamw_matches_oracle_given_identical_grads():
         assert np.abs(got - params[k]).max() <= 1e-6 * max(1.0, np.abs(params[k]).max()), k
 
 
+def test_fused_adamw_step_is_bit_identical_to_two_call_path():
+    """isdf_train_step_adamw (single-GPU tail: slab reduction + AdamW + operand repack + finalisation in one
+    launch) must leave exactly the state isdf_train_step followed by isdf_adamw leaves: fp32 parameters,
+    both moments, all four packed 16-bit operand sets, and the reduce buffer."""
+    g = gu.load("eval_full_ray")
+    lc, sc = _cfgs(g)
+    F = g["depth_batch"].shape[0]
+    idx = torch.arange(F, dtype=torch.int32, device="cuda")
+    engs = [_engine(g), _engine(g)]
+    for it in range(3):
+        states = []
+        for fused, eng in zip((False, True), engs):
+            s = eng.sample(_dev(g["depth_batch"]), _dev(g["T_WC_batch"]), _dev(g["normal_batch"]), idx, idx, sc,
+                           seed=7, offset=it)
+            kw = dict(noise_std=0.08, noise_seed=3, noise_offset=it)
+            if fused:
+                eng.train_step(s, lc, sc, optim=dict(lr=0.0013, weight_decay=0.012), **kw)
+            else:
+                eng.train_step(s, lc, sc, **kw)
+                eng.adamw(lr=0.0013, weight_decay=0.012)
+            torch.cuda.synchronize()
+            states.append(dict(params=eng.params.clone(), m=eng.exp_avg.clone(), v=eng.exp_avg_sq.clone(),
+                               shadow=eng.shadow.clone(), red=eng.reduce_buf.clone()))
+        for k in states[0]:
+            a, b = states[0][k], states[1][k]
+            assert torch.equal(a.view(torch.uint8), b.view(torch.uint8)), (it, k, int((a != b).sum()))
+    assert engs[0].opt_step == engs[1].opt_step == 3
+
+
 def test_three_full_steps_track_oracle():
     """sampler -> step -> AdamW x3 with injected draws.  AdamW's early updates are ~lr*sign(g), so an
     element whose gradient is ~0 may move by +-lr either way whatever the gradient accuracy: the drift
