@@ -27,8 +27,12 @@ from .modules import PositionalEncodingHIP, SDFMapHIP
 
 
 class FrameData:
-    """Keyframe store (`data_util.FrameData`): grows by concatenation, or
-    overwrites the last slot when the previous frame was not promoted."""
+    """Keyframe store (`data_util.FrameData`, isdf/datasets/data_util.py:11-81): same fields and the same
+    `add_frame_data(data, replace)` contract (append, or overwrite the last slot when the previous frame was
+    not promoted to a keyframe), but the device batches live in pre-allocated buffers that grow
+    geometrically instead of being re-built with `torch.cat` on every frame (data_util.py:84-102 copies the
+    whole keyframe set -- ~13 MB per keyframe at 680x1200 -- each time a frame arrives).
+    The public attributes stay plain tensors: views of the first len(self) rows of the backing buffers."""
 
     def __init__(self, frame_id=None, depth_batch=None, T_WC_batch=None, normal_batch=None,
                  frame_avg_losses=None, im_batch=None):
@@ -38,31 +42,56 @@ class FrameData:
         self.T_WC_batch = T_WC_batch
         self.normal_batch = normal_batch
         self.frame_avg_losses = frame_avg_losses
+        self._back = {}          # field name -> backing tensor (capacity >= len)
 
     def __len__(self):
         return 0 if self.frame_id is None else len(self.frame_id)
 
-    @staticmethod
-    def _expand(batch, data, replace):
+    def __deepcopy__(self, memo):   # snapshots carry only the live rows
+        import copy
+        out = FrameData()
+        for k in ("frame_id", "im_batch", "depth_batch", "T_WC_batch", "normal_batch", "frame_avg_losses"):
+            v = getattr(self, k)
+            setattr(out, k, None if v is None else (v.copy() if isinstance(v, np.ndarray) else v.clone()))
+        return out
+
+    def _expand(self, name, batch, data, replace):
         if data is None:
             return batch
         if batch is None:
-            return data
-        if not replace:
-            return np.concatenate((batch, data)) if isinstance(data, np.ndarray) else torch.cat((batch, data))
-        batch[-1] = data[0]
-        return batch
+            if isinstance(data, np.ndarray):
+                return data
+            batch = data[:0]
+        elif replace:
+            batch[-1] = data[0]
+            return batch
+        if isinstance(data, np.ndarray):     # frame ids: a few bytes
+            return np.concatenate((batch, data))
+        n, k = batch.shape[0], data.shape[0]
+        back = getattr(self, "_back", None)
+        if back is None:
+            back = self._back = {}
+        buf = back.get(name)
+        if (buf is None or buf.data_ptr() != batch.data_ptr() or buf.shape[0] < n + k or buf.dtype != data.dtype
+                or buf.device != data.device or buf.shape[1:] != data.shape[1:]):
+            cap = max(2 * (n + k), 8)        # geometric growth: amortised O(1) copies per keyframe
+            buf = torch.empty((cap,) + tuple(data.shape[1:]), dtype=data.dtype, device=data.device)
+            if n:
+                buf[:n] = batch
+            back[name] = buf
+        buf[n:n + k] = data
+        return buf[:n + k]
 
     def add_frame_data(self, data, replace):
         """data_util.py:45-78"""
         n_new = len(data)
-        self.frame_id = self._expand(self.frame_id, data.frame_id, replace)
-        self.im_batch = self._expand(self.im_batch, data.im_batch, replace)
-        self.depth_batch = self._expand(self.depth_batch, data.depth_batch, replace)
-        self.T_WC_batch = self._expand(self.T_WC_batch, data.T_WC_batch, replace)
-        self.normal_batch = self._expand(self.normal_batch, data.normal_batch, replace)
+        self.frame_id = self._expand("frame_id", self.frame_id, data.frame_id, replace)
+        self.im_batch = self._expand("im_batch", self.im_batch, data.im_batch, replace)
+        self.depth_batch = self._expand("depth_batch", self.depth_batch, data.depth_batch, replace)
+        self.T_WC_batch = self._expand("T_WC_batch", self.T_WC_batch, data.T_WC_batch, replace)
+        self.normal_batch = self._expand("normal_batch", self.normal_batch, data.normal_batch, replace)
         empty = torch.zeros([n_new], device=data.depth_batch.device)
-        self.frame_avg_losses = self._expand(self.frame_avg_losses, empty, replace)
+        self.frame_avg_losses = self._expand("frame_avg_losses", self.frame_avg_losses, empty, replace)
 
 
 class FlatAdamW:
