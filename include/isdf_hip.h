@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define ISDF_ABI_VERSION 1
+#define ISDF_ABI_VERSION 2
 
 enum {
   ISDF_OK = 0,
@@ -215,10 +215,15 @@ int isdf_train_step_adamw(const isdf_net_cfg* net, const isdf_loss_cfg* loss, co
                           const isdf_step_out* o, const isdf_optim_args* opt, void* workspace,
                           int64_t workspace_bytes, void* stream);
 
-/* nearest-surface-point bounds (bounds_method "pc", loss.py:56-89) */
+/* nearest-surface-point bounds (bounds_method "pc", loss.py:56-89): for every sample point the distance to
+ * the nearest SURFACE sample (sign from z vs depth) and the unit vector from it.  surf_pts == NULL: the
+ * surface set is this batch's own pc[:, 0, :] (what the single-process reference uses, loss.py:58-61).
+ * Data parallel: surf_pts [n_surf,3] is the all-gathered surface set of all ranks' rays, so each
+ * rank sees the surface the single-process run with the global batch would see; slots of dropped rays may
+ * hold any far-away sentinel (e.g. 1e18).                                                                    */
 int isdf_bounds_pc(const int32_t* n_valid, int32_t max_rays, int32_t S, const float* pc,
-                   const float* z_vals, const float* depth_sample, float* bounds,
-                   float* grad_vec, void* stream);
+                   const float* z_vals, const float* depth_sample, const float* surf_pts,
+                   int64_t n_surf, float* bounds, float* grad_vec, void* stream);
 
 /* per-frame 8x8 block-loss averages from the reduced bins (loss.py:208-240):
  * loss_approx [F,8,8], frame_avg_loss [F]                                      */

@@ -10,7 +10,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libisdf_hip.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 # every symbol include/isdf_hip.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
@@ -111,7 +111,7 @@ def lib():
     L.isdf_sdf_eval.argtypes = [P(NetCfg), vp, vp, vp, i64, vp, vp, vp, vp, i64, vp]
     L.isdf_train_step.argtypes = [P(NetCfg), P(LossCfg), vp, vp, P(StepArgs), P(StepOut), vp, i64, vp]
     L.isdf_train_step_adamw.argtypes = [P(NetCfg), P(LossCfg), P(StepArgs), P(StepOut), P(OptimArgs), vp, i64, vp]
-    L.isdf_bounds_pc.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp, vp]
+    L.isdf_bounds_pc.argtypes = [vp, i32, i32, vp, vp, vp, vp, i64, vp, vp, vp]
     L.isdf_frame_avg.argtypes = [vp, i64, i32, vp, vp, vp]
     L.isdf_adamw.argtypes = [P(NetCfg), vp, vp, vp, vp, vp, f32, f32, f32, f32, f32, f32, i32, vp, vp]
     L.isdf_estimate_normals.argtypes = [vp, i32, i32, f32, f32, f32, f32, vp, vp]

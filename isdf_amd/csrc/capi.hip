@@ -26,7 +26,7 @@ int launch_step_tail(const NetLayout& L, const float* dwPart, const float* vecPa
                      float* loss_sums, float* bl, float* bc, hipStream_t st);
 int launch_frame_avg(const float* bl, const float* bc, int F, float* la, float* fa, hipStream_t st);
 int launch_bounds_pc(const int32_t* n_valid, int max_rays, int S, const float* pc, const float* z, const float* depth,
-                     float* bounds, float* gv, hipStream_t st);
+                     const float* surf, int64_t n_surf, float* bounds, float* gv, hipStream_t st);
 int launch_normals(const float* depth, int H, int W, float fx, float fy, float cx, float cy, float* normals,
                    hipStream_t st);
 int launch_render_depth(const int32_t* n_valid, int64_t n_host, int64_t max_rays, int S, const float* z,
@@ -205,9 +205,12 @@ int isdf_train_step_adamw(const isdf_net_cfg* net, const isdf_loss_cfg* loss, co
 }
 
 int isdf_bounds_pc(const int32_t* n_valid, int32_t max_rays, int32_t S, const float* pc, const float* z_vals,
-                   const float* depth_sample, float* bounds, float* grad_vec, void* stream) {
+                   const float* depth_sample, const float* surf_pts, int64_t n_surf, float* bounds, float* grad_vec,
+                   void* stream) {
   if (!n_valid || !pc || !z_vals || !depth_sample || !bounds || !grad_vec || max_rays < 1 || S < 1) return ISDF_EINVAL;
-  return launch_bounds_pc(n_valid, max_rays, S, pc, z_vals, depth_sample, bounds, grad_vec, (hipStream_t)stream);
+  if (surf_pts && n_surf < 1) return ISDF_EINVAL;
+  return launch_bounds_pc(n_valid, max_rays, S, pc, z_vals, depth_sample, surf_pts, n_surf, bounds, grad_vec,
+                          (hipStream_t)stream);
 }
 
 int isdf_frame_avg(const float* reduce_buf, int64_t n_params, int32_t n_frames, float* loss_approx,

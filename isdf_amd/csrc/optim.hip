@@ -299,12 +299,19 @@ __global__ void frame_avg_kernel(const float* __restrict__ block_loss, const flo
 }
 
 // ---- bounds_pc: brute-force nearest surface point, LDS-tiled -------------------
+// surf == nullptr: the surface set is this batch's own surface samples pc[:, 0, :] (single process,
+// loss.py:58-61).  Data parallel: surf[n_surf][3] is the all-gathered surface set of every rank's rays
+// (SURVEY 8e); slots of invalid rays hold +inf-like sentinels and are never the nearest point.
 __global__ __launch_bounds__(256) void bounds_pc_kernel(const int32_t* __restrict__ n_valid, int S,
                                                         const float* __restrict__ pc, const float* __restrict__ z_vals,
-                                                        const float* __restrict__ depth, float* __restrict__ bounds,
+                                                        const float* __restrict__ depth, const float* __restrict__ surf,
+                                                        int64_t n_surf, float* __restrict__ bounds,
                                                         float* __restrict__ grad_vec) {
   __shared__ float sx[256], sy[256], sz[256];
-  const int64_t R = *n_valid, P = R * S;
+  const int64_t Rl = *n_valid, P = Rl * S;
+  const int64_t R = surf ? n_surf : Rl;                  // size of the surface set
+  const int64_t sstride = surf ? 3 : (int64_t)S * 3;
+  const float* sp = surf ? surf : pc;
   const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if ((int64_t)blockIdx.x * 256 >= P) return;
   float px = 0.f, py = 0.f, pz = 0.f;
@@ -313,7 +320,7 @@ __global__ __launch_bounds__(256) void bounds_pc_kernel(const int32_t* __restric
   for (int64_t r0 = 0; r0 < R; r0 += 256) {
     const int64_t r = r0 + threadIdx.x;
     __syncthreads();
-    if (r < R) { sx[threadIdx.x] = pc[r * S * 3]; sy[threadIdx.x] = pc[r * S * 3 + 1]; sz[threadIdx.x] = pc[r * S * 3 + 2]; }
+    if (r < R) { sx[threadIdx.x] = sp[r * sstride]; sy[threadIdx.x] = sp[r * sstride + 1]; sz[threadIdx.x] = sp[r * sstride + 2]; }
     __syncthreads();
     const int cnt = (int)((R - r0) < 256 ? (R - r0) : 256);
     for (int k = 0; k < cnt; ++k) {
@@ -327,7 +334,7 @@ __global__ __launch_bounds__(256) void bounds_pc_kernel(const int32_t* __restric
   const float dist = sqrtf(best);
   const bool behind = z_vals[n] > depth[ray];
   bounds[n] = behind ? -dist : dist;
-  float gx = px - pc[bi * S * 3], gy = py - pc[bi * S * 3 + 1], gz = pz - pc[bi * S * 3 + 2];
+  float gx = px - sp[bi * sstride], gy = py - sp[bi * sstride + 1], gz = pz - sp[bi * sstride + 2];
   const float nn = sqrtf(gx * gx + gy * gy + gz * gz);
   gx /= nn; gy /= nn; gz /= nn;            // 0/0 -> NaN like the reference (trainer.py:823-824 handles it)
   if (behind) { gx = -gx; gy = -gy; gz = -gz; }
@@ -380,10 +387,10 @@ int launch_frame_avg(const float* bl, const float* bc, int F, float* la, float* 
   return hipGetLastError() == hipSuccess ? ISDF_OK : ISDF_EHIP;
 }
 int launch_bounds_pc(const int32_t* n_valid, int max_rays, int S, const float* pc, const float* z, const float* depth,
-                     float* bounds, float* gv, hipStream_t st) {
+                     const float* surf, int64_t n_surf, float* bounds, float* gv, hipStream_t st) {
   const int64_t maxPts = (int64_t)max_rays * S;
   hipLaunchKernelGGL(bounds_pc_kernel, dim3((unsigned)((maxPts + 255) / 256)), dim3(256), 0, st, n_valid, S, pc, z,
-                     depth, bounds, gv);
+                     depth, surf, n_surf, bounds, gv);
   return hipGetLastError() == hipSuccess ? ISDF_OK : ISDF_EHIP;
 }
 

@@ -53,3 +53,23 @@ def finish(buf, n_params, n_frames):
 def rank_seed(seed, rank):
     """rank-distinct Philox key for the sampler (each rank draws its own rays)"""
     return int(seed) + 7919 * int(rank)
+
+
+FAR = 1.0e18   # coordinate of a "no surface point here" slot: never the nearest point, never overflows d^2 to inf*0
+
+
+def gather_surface_points(pc, n_valid, group=None):
+    """bounds_method "pc" under data parallelism: all-gather the surface sample (sample 0) of
+    every ray slot of every rank -> [world * max_rays, 3].  Ray slots past a rank's n_valid (invalid-depth
+    rays dropped by the sampler, sample.py:39-55) are replaced by FAR so that no device->host sync on the
+    valid count is needed; 12 KB per 1000 rays and rank."""
+    R0 = pc.shape[0]
+    surf = pc[:, 0, :].contiguous()
+    live = torch.arange(R0, device=pc.device) < n_valid.reshape(-1)[0]
+    surf = torch.where(live[:, None], surf, torch.full_like(surf, FAR))
+    if group is None and not (torch.distributed.is_available() and torch.distributed.is_initialized()):
+        return surf
+    world = torch.distributed.get_world_size(group)
+    out = torch.empty(world * R0, 3, dtype=surf.dtype, device=surf.device)
+    torch.distributed.all_gather_into_tensor(out, surf, group=group)
+    return out

@@ -244,12 +244,14 @@ class Engine:
 
     # ---- training step ----------------------------------------------------------
     def train_step(self, smp, lc: LossConfig, sc: SampleConfig, noise=None, debug=False, prof_events=None,
-                   noise_std=0.0, noise_seed=0, noise_offset=0, optim=None):
+                   noise_std=0.0, noise_seed=0, noise_offset=0, optim=None, surf_group=None):
         """Everything between sampling and the optimiser.  Fills self.reduce_buf with
         [grad sums | loss sums(8) | block_loss | block_cnt]; returns debug tensors.
 
         optim: None, or a dict(lr, weight_decay, betas, eps, grad_scale) -> the single-GPU fused form
-        (isdf_train_step_adamw): the AdamW update and the operand repack happen inside the same call."""
+        (isdf_train_step_adamw): the AdamW update and the operand repack happen inside the same call.
+        surf_group: process group; with bounds_method "pc" the nearest-surface search then runs against the
+        all-gathered surface samples of every rank."""
         dev = self.device
         F, R0, S = smp["n_frames"], smp["max_rays"], smp["S"]
         nred = int(self.lib.isdf_reduce_floats(C.byref(self.cnet), F))
@@ -279,8 +281,14 @@ class Engine:
         if lc.bounds_method == "pc":
             pb = torch.empty(R0 * S, dtype=torch.float32, device=dev)
             pg = torch.empty(R0 * S, 3, dtype=torch.float32, device=dev)
+            surf = None
+            if surf_group is not None:   # data parallel: the surface set is every rank's surface samples
+                from . import dp
+                surf = dp.gather_surface_points(smp["pc"], smp["n_valid"], surf_group)
+                keep.append(surf)
             _ffi.check(self.lib.isdf_bounds_pc(_ffi.ptr(smp["n_valid"]), R0, S, _ffi.ptr(smp["pc"]),
                                                _ffi.ptr(smp["z_vals"]), _ffi.ptr(smp["depth_sample"]),
+                                               _ffi.ptr(surf), 0 if surf is None else surf.shape[0],
                                                _ffi.ptr(pb), _ffi.ptr(pg), _stream()), "isdf_bounds_pc")
             a.pc_bounds, a.pc_grad_vec = pb.data_ptr(), pg.data_ptr()
             keep += [pb, pg]

@@ -442,6 +442,8 @@ class HipTrainer:
                 raise ValueError("fused_optim is the single-GPU path: the gradient all-reduce sits before the update")
             g = self.optimiser.param_groups[0]
             kw["optim"] = dict(lr=g["lr"], weight_decay=g["weight_decay"], betas=g["betas"], eps=g["eps"])
+        if self.dist_group is not None and self.bounds_method == "pc":
+            kw["surf_group"] = self.dist_group
         self.engine.train_step(s, self._loss_cfg(), sc, noise=noise, **kw)
         if self.dist_group is not None:   # sums over ranks; AdamW divides by the reduced count
             dp.allreduce_(self.engine.reduce_buf, self.dist_group)

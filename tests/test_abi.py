@@ -27,7 +27,10 @@ def test_header_symbols_all_exported(lib):
 
 
 def test_abi_version_and_errors(lib):
-    assert lib.isdf_abi_version() == 1
+    import re
+    from isdf_amd import _ffi
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "isdf_hip.h")).read()
+    assert lib.isdf_abi_version() == _ffi.ABI_VERSION == int(re.search(r"#define ISDF_ABI_VERSION (\d+)", hdr).group(1))
     assert lib.isdf_error_string(0) == b"ok"
     assert b"invalid" in lib.isdf_error_string(-1)
 

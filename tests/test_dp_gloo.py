@@ -95,3 +95,39 @@ def test_layout_matches_c_abi():
         assert dp.layout(n_params, F)["total"] == _ffi.lib().isdf_reduce_floats(C.byref(c), F)
     assert (dp.LS_SDF, dp.LS_GRAD, dp.LS_EIK, dp.LS_TOTAL, dp.LS_COUNT) == \
         (_ffi.LS_SDF, _ffi.LS_GRAD, _ffi.LS_EIK, _ffi.LS_TOTAL, _ffi.LS_COUNT)
+
+
+def _surf_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
+    g = gu.load("eval_small_ray")
+    pc = torch.from_numpy(g["pc"].astype(np.float32))
+    R0 = 40                                         # ray slots per rank; rank r has 25 + 10 r valid rays
+    nv = 25 + 10 * rank
+    mine = torch.zeros(R0, pc.shape[1], 3)
+    mine[:nv] = pc[rank * 40: rank * 40 + nv]
+    mine[nv:] = 123.0                               # stale slot contents must not leak into the surface set
+    out = dp.gather_surface_points(mine, torch.tensor([nv], dtype=torch.int32))
+    if rank == 1:
+        ret["surf"] = out.numpy()
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_surface_gather_for_bounds_pc():
+    """bounds_method "pc" under data parallelism: every rank must see the surface samples of ALL
+    ranks' valid rays, and the slots of dropped rays must never be a nearest point."""
+    port = _free_port()
+    mgr = mp.Manager(); ret = mgr.dict()
+    mp.spawn(_surf_worker, args=(2, port, ret), nprocs=2, join=True)
+    g = gu.load("eval_small_ray")
+    pc = g["pc"].astype(np.float32)
+    surf = ret["surf"]
+    assert surf.shape == (80, 3)
+    np.testing.assert_array_equal(surf[:25], pc[:25, 0]); np.testing.assert_array_equal(surf[40:75], pc[40:75, 0])
+    assert (surf[25:40] == dp.FAR).all() and (surf[75:] == dp.FAR).all()
+    # nearest-point search over the gathered set == the single-process search over the union of valid rays
+    live = np.r_[0:25, 40:75]
+    q = pc[:10].reshape(-1, 3)
+    d_all = np.linalg.norm(q[:, None, :].astype(np.float64) - surf[None].astype(np.float64), axis=-1)
+    d_ref = np.linalg.norm(q[:, None, :].astype(np.float64) - pc[live, 0][None].astype(np.float64), axis=-1)
+    np.testing.assert_array_equal(np.take(np.r_[0:25, 40:75], d_ref.argmin(1)), d_all.argmin(1))

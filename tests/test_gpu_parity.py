@@ -223,6 +223,40 @@ def test_adamw_matches_oracle_given_identical_grads():
         assert np.abs(got - params[k]).max() <= 1e-6 * max(1.0, np.abs(params[k]).max()), k
 
 
+def test_bounds_pc_against_gathered_surface_set():
+    """Data-parallel bounds_method "pc" (SURVEY 8e): a rank holding a shard of the rays, given the gathered
+    surface samples of all rays, must get the bounds the single-process run over all rays gets for them."""
+    import ctypes as C
+    from isdf_amd import _ffi, dp
+    g = gu.load("eval_full_ray")
+    pc, z, depth = g["pc"].astype(np.float32), g["z_vals"].astype(np.float32), g["depth_sample"].astype(np.float32)
+    R, S = z.shape
+    b_ref, g_ref = orc.bounds_pc(pc, z, depth)                  # single process, all rays
+    cut = R // 3
+    lib = _ffi.lib()
+    for rows in (np.arange(0, cut), np.arange(cut, R)):
+        n = len(rows)
+        R0 = n + 7                                              # some dead ray slots at the end
+        pcs = torch.full((R0, S, 3), 55.0, device="cuda"); pcs[:n] = _dev(pc[rows])
+        zs = torch.zeros(R0, S, device="cuda"); zs[:n] = _dev(z[rows])
+        ds = torch.zeros(R0, device="cuda"); ds[:n] = _dev(depth[rows])
+        nv = torch.tensor([n], dtype=torch.int32, device="cuda")
+        # what dp.gather_surface_points produces on this rank for a 2-rank group: [rank0 slots | rank1 slots]
+        parts = []
+        for rr in (np.arange(0, cut), np.arange(cut, R)):
+            t = torch.full((len(rr) + 7, 3), dp.FAR, device="cuda"); t[:len(rr)] = _dev(pc[rr, 0]); parts.append(t)
+        surf = torch.cat(parts).contiguous()
+        pb = torch.empty(R0 * S, device="cuda"); pg = torch.empty(R0 * S, 3, device="cuda")
+        _ffi.check(lib.isdf_bounds_pc(_ffi.ptr(nv), R0, S, _ffi.ptr(pcs), _ffi.ptr(zs), _ffi.ptr(ds), _ffi.ptr(surf),
+                                      surf.shape[0], _ffi.ptr(pb), _ffi.ptr(pg), None), "isdf_bounds_pc")
+        torch.cuda.synchronize()
+        got_b = pb.view(R0, S)[:n].cpu().numpy()
+        np.testing.assert_allclose(got_b, b_ref[rows], rtol=1e-5, atol=1e-6)
+        got_g = pg.view(R0, S, 3)[:n, 1:].cpu().numpy()
+        ok = np.isfinite(g_ref[rows]).all(-1)
+        np.testing.assert_allclose(got_g[ok], g_ref[rows][ok], rtol=0, atol=2e-4)
+
+
 def test_fused_adamw_step_is_bit_identical_to_two_call_path():
     """isdf_train_step_adamw (single-GPU tail: slab reduction + AdamW + operand repack + finalisation in one
     launch) must leave exactly the state isdf_train_step followed by isdf_adamw leaves: fp32 parameters,
