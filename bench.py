@@ -191,14 +191,15 @@ def main():
                        seed=dp.rank_seed(1, rank), offset=i)
         og = tr.optimiser.param_groups[0]
         fused = None if group is not None else dict(lr=og["lr"], weight_decay=og["weight_decay"], betas=og["betas"],
-                                                    eps=og["eps"])
+                                                    eps=og["eps"], frame_avg_out=tr.frames.frame_avg_losses,
+                                                    frame_avg_index=fidx)   # trainer.py:979 inside the tail
         eng.train_step(s, lc, sc, prof_events=ev, noise_std=tr.noise_std, noise_seed=1 + rank,
                        noise_offset=i, optim=fused)                 # in-kernel N(0,1)*noise_std (fc_map.py:106-108)
         if group is not None:   # data parallel: all-reduce the summed gradient, then AdamW + repack
             dp.allreduce_(eng.reduce_buf, group)
             tr.optimiser.step()
-        la, fa = eng.frame_avg(F)
-        tr.frames.frame_avg_losses[fidx.long()] = fa            # trainer.py:979
+            la, fa = eng.frame_avg(F)
+            tr.frames.frame_avg_losses[fidx.long()] = fa        # trainer.py:979
         return s
 
     for i in range(W):

@@ -209,6 +209,14 @@ typedef struct isdf_optim_args {
   float grad_scale;     /* multiplies the mean gradient (1.0 for the reference's loss)     */
   int32_t step;         /* 1-based optimiser step (bias correction)                        */
   int32_t reserved;
+  /* optional: loss.frame_avg (loss.py:208-240) of this step written by the same launch, i.e. what
+   * isdf_frame_avg would return: loss_approx [F,8,8] and frame_avg[frame_avg_index ?
+   * frame_avg_index[f] : f] -- pass the keyframe store's frame_avg_losses and the window's keyframe
+   * indices to get `self.frames.frame_avg_losses[idxs] = frame_avg_loss` (trainer.py:979) for free.
+   * Both or neither of loss_approx / frame_avg.                                                    */
+  float* loss_approx;
+  float* frame_avg;
+  const int32_t* frame_avg_index;
 } isdf_optim_args;
 
 int isdf_train_step_adamw(const isdf_net_cfg* net, const isdf_loss_cfg* loss, const isdf_step_args* a,

@@ -74,7 +74,8 @@ class StepOut(C.Structure):
 class OptimArgs(C.Structure):
     _fields_ = [("params", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p), ("shadow", C.c_void_p),
                 ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
-                ("weight_decay", C.c_float), ("grad_scale", C.c_float), ("step", C.c_int32), ("reserved", C.c_int32)]
+                ("weight_decay", C.c_float), ("grad_scale", C.c_float), ("step", C.c_int32), ("reserved", C.c_int32),
+                ("loss_approx", C.c_void_p), ("frame_avg", C.c_void_p), ("frame_avg_index", C.c_void_p)]
 
 
 

@@ -23,7 +23,8 @@ int launch_step_tail(const NetLayout& L, const float* dwPart, const float* vecPa
                      float* params, float* m, float* v, uint16_t* shadow, float grad_scale, float lr, float b1, float b2,
                      float eps, float wd, int step, const float* wg_loss, int64_t maxTiles, const int32_t* n_valid, int S,
                      const float* tot_ws, const int64_t* ib, const int64_t* ih, const int64_t* iw, int F, int H, int W,
-                     float* loss_sums, float* bl, float* bc, hipStream_t st);
+                     float* loss_sums, float* bl, float* bc, float* la_out, float* fa_out, const int32_t* fa_index,
+                     hipStream_t st);
 int launch_frame_avg(const float* bl, const float* bc, int F, float* la, float* fa, hipStream_t st);
 int launch_bounds_pc(const int32_t* n_valid, int max_rays, int S, const float* pc, const float* z, const float* depth,
                      const float* surf, int64_t n_surf, float* bounds, float* gv, hipStream_t st);
@@ -174,7 +175,8 @@ static int train_step_impl(const isdf_net_cfg* net, const isdf_loss_cfg* loss, c
     rc = launch_step_tail(l, dwPart, vecPart, w.vecStride, o->reduce_buf, opt->params, opt->exp_avg, opt->exp_avg_sq,
                           (uint16_t*)opt->shadow, opt->grad_scale, opt->lr, opt->beta1, opt->beta2, opt->eps,
                           opt->weight_decay, opt->step, wgLoss, w.nTiles, a->n_valid, a->S, totLoss, a->indices_b,
-                          a->indices_h, a->indices_w, a->n_frames, a->H, a->W, lossSums, blockLoss, blockCnt, st);
+                          a->indices_h, a->indices_w, a->n_frames, a->H, a->W, lossSums, blockLoss, blockCnt,
+                          opt->loss_approx, opt->frame_avg, opt->frame_avg_index, st);
     if (rc) return rc;
     if (ev && hipEventRecord(ev[3], st) != hipSuccess) return ISDF_EHIP;
     return ISDF_OK;

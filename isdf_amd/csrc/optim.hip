@@ -107,6 +107,9 @@ struct FinalizeArgs {
   const float* wg_loss; int64_t maxTiles; const int32_t* n_valid; int S; const float* tot_ws;
   const int64_t *ib, *ih, *iw; int n_frames, H, W;
   float *loss_sums, *block_loss, *block_cnt;
+  // optional (single-GPU tail only): the per-frame averages of loss.frame_avg written straight away --
+  // loss_approx [F,8,8] and frame_avg[fa_index ? fa_index[f] : f] (the keyframe store's frame_avg_losses)
+  float *la_out, *fa_out; const int32_t* fa_index;
 };
 struct FinalizeLds { float sh[16][8]; float binS[64], binC[64]; int range[2]; uint32_t keys[FIN_CAP]; };
 
@@ -171,7 +174,18 @@ __device__ __forceinline__ void finalize_block(int block, const FinalizeArgs& a,
     atomicAdd(&binC[bin], 1.f);
   }
   __syncthreads();
-  if (tid < 64) { block_loss[f * 64 + tid] = binS[tid]; block_cnt[f * 64 + tid] = binC[tid]; }
+  if (tid < 64) {
+    block_loss[f * 64 + tid] = binS[tid]; block_cnt[f * 64 + tid] = binC[tid];
+    if (a.la_out) {   // frame_avg_kernel's arithmetic, on the bins just built (loss.py:208-240)
+      float c = binC[tid];
+      c = c == 0.f ? 1.f : c;
+      float v = binS[tid] / c;
+      a.la_out[f * 64 + tid] = v;
+#pragma unroll
+      for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+      if (tid == 0) a.fa_out[a.fa_index ? a.fa_index[f] : f] = v / 64.f;
+    }
+  }
 }
 __global__ __launch_bounds__(1024) void finalize_kernel(const FinalizeArgs a) {
   __shared__ FinalizeLds lds;
@@ -356,7 +370,7 @@ int launch_pack(const NetLayout& L, const float* params, uint16_t* shadow, hipSt
 static FinalizeArgs finalize_args(const float* wg_loss, int64_t maxTiles, const int32_t* n_valid, int S, const float* tot_ws,
                                   const int64_t* ib, const int64_t* ih, const int64_t* iw, int F, int H, int W,
                                   float* loss_sums, float* bl, float* bc) {
-  FinalizeArgs a = {wg_loss, maxTiles, n_valid, S, tot_ws, ib, ih, iw, F, H, W, loss_sums, bl, bc};
+  FinalizeArgs a = {wg_loss, maxTiles, n_valid, S, tot_ws, ib, ih, iw, F, H, W, loss_sums, bl, bc, nullptr, nullptr, nullptr};
   return a;
 }
 int launch_finalize(const float* wg_loss, int64_t maxTiles, const int32_t* n_valid, int S, const float* tot_ws,
@@ -370,12 +384,14 @@ int launch_step_tail(const NetLayout& L, const float* dwPart, const float* vecPa
                      float* params, float* m, float* v, uint16_t* shadow, float grad_scale, float lr, float b1, float b2,
                      float eps, float wd, int step, const float* wg_loss, int64_t maxTiles, const int32_t* n_valid, int S,
                      const float* tot_ws, const int64_t* ib, const int64_t* ih, const int64_t* iw, int F, int H, int W,
-                     float* loss_sums, float* bl, float* bc, hipStream_t st) {
+                     float* loss_sums, float* bl, float* bc, float* la_out, float* fa_out, const int32_t* fa_index,
+                     hipStream_t st) {
   TailParams p = {};
   p.lay = L; p.dwPart = dwPart; p.vecPart = vecPart; p.vecStride = vecStride; p.grad = grad;
   p.params = params; p.m = m; p.v = v; p.shadow = shadow; p.grad_scale = grad_scale;
   p.c = AdamwCoef{lr, b1, b2, eps, wd, 1.f - powf(b1, (float)step), sqrtf(1.f - powf(b2, (float)step))};
   p.fin = finalize_args(wg_loss, maxTiles, n_valid, S, tot_ws, ib, ih, iw, F, H, W, loss_sums, bl, bc);
+  if (la_out && fa_out) { p.fin.la_out = la_out; p.fin.fa_out = fa_out; p.fin.fa_index = fa_index; }
   const int64_t total = (int64_t)dw_units(L) * DW_BLK * DW_BLK;
   p.nW = (int)((total + 1023) / 1024);
   p.nV = (L.L * L.HD + L.HD + 1 + 63) / 64;

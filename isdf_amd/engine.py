@@ -313,6 +313,15 @@ class Engine:
             q.lr, q.weight_decay = float(optim.get("lr", 0.0013)), float(optim.get("weight_decay", 0.012))
             q.beta1, q.beta2, q.eps = float(betas[0]), float(betas[1]), float(optim.get("eps", 1e-8))
             q.grad_scale, q.step = float(optim.get("grad_scale", 1.0)), int(self.opt_step)
+            if optim.get("frame_avg_out") is not None:   # loss.frame_avg fused into the same launch
+                la = torch.empty(F, 8, 8, dtype=torch.float32, device=dev)
+                fa_out, fa_idx = optim["frame_avg_out"], optim.get("frame_avg_index")
+                assert fa_out.dtype == torch.float32 and fa_out.is_contiguous()
+                assert fa_idx is None or (fa_idx.dtype == torch.int32 and fa_idx.numel() == F)
+                q.loss_approx, q.frame_avg = la.data_ptr(), fa_out.data_ptr()
+                q.frame_avg_index = None if fa_idx is None else fa_idx.data_ptr()
+                dbg["loss_approx"] = la
+                keep += [fa_out, fa_idx]
             _ffi.check(self.lib.isdf_train_step_adamw(C.byref(self.cnet), C.byref(closs), C.byref(a), C.byref(o),
                                                       C.byref(q), _ffi.ptr(ws), ws.numel(), _stream()),
                        "isdf_train_step_adamw")

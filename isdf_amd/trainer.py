@@ -422,7 +422,7 @@ class HipTrainer:
         return out
 
     # ---- loss + backward (trainer.py:768-868, 981) -----------------------------------
-    def sdf_eval_and_loss(self, sample, do_avg_loss=True, fused_optim=False):
+    def sdf_eval_and_loss(self, sample, do_avg_loss=True, fused_optim=False, frame_avg_dst=None):
         """fused_optim: also apply the optimiser step inside the same native call (single-GPU fast path,
         isdf_train_step_adamw); the caller must then NOT call self.optimiser.step()."""
         s, sc = sample["_raw"], sample["_sc"]
@@ -442,16 +442,21 @@ class HipTrainer:
                 raise ValueError("fused_optim is the single-GPU path: the gradient all-reduce sits before the update")
             g = self.optimiser.param_groups[0]
             kw["optim"] = dict(lr=g["lr"], weight_decay=g["weight_decay"], betas=g["betas"], eps=g["eps"])
+            if do_avg_loss and frame_avg_dst is not None:   # frames.frame_avg_losses[idxs] = ... inside the launch
+                kw["optim"].update(frame_avg_out=frame_avg_dst[0], frame_avg_index=frame_avg_dst[1])
         if self.dist_group is not None and self.bounds_method == "pc":
             kw["surf_group"] = self.dist_group
-        self.engine.train_step(s, self._loss_cfg(), sc, noise=noise, **kw)
+        dbg = self.engine.train_step(s, self._loss_cfg(), sc, noise=noise, **kw)
         if self.dist_group is not None:   # sums over ranks; AdamW divides by the reduced count
             dp.allreduce_(self.engine.reduce_buf, self.dist_group)
         ls = self.engine.loss_sums()
         losses = LazyLosses(ls, self.grad_weight != 0, self.eik_weight != 0)
         total_loss = ls[_ffi.LS_TOTAL] / ls[_ffi.LS_COUNT]
         loss_approx = frame_avg_loss = None
-        if do_avg_loss:
+        if do_avg_loss and "loss_approx" in dbg:      # written by the fused tail, straight into frame_avg_dst
+            loss_approx = dbg["loss_approx"]
+            frame_avg_loss = frame_avg_dst[0][frame_avg_dst[1].long()] if frame_avg_dst[1] is not None else frame_avg_dst[0]
+        elif do_avg_loss:
             loss_approx, frame_avg_loss = self.engine.frame_avg(s["n_frames"])
         return total_loss, losses, loss_approx, frame_avg_loss
 
@@ -477,8 +482,10 @@ class HipTrainer:
         self.active_pixels = {k: sample_pts[k] for k in ("indices_b", "indices_h", "indices_w")}
 
         fused = self.dist_group is None and getattr(self, "fuse_optimiser", True)
-        total_loss, losses, active_loss_approx, frame_avg_loss = self.sdf_eval_and_loss(sample_pts, True, fused)
-        self.frames.frame_avg_losses[fidx.long()] = frame_avg_loss
+        dst = (self.frames.frame_avg_losses, fidx) if fused and self.frames.frame_avg_losses.is_contiguous() else None
+        total_loss, losses, active_loss_approx, frame_avg_loss = self.sdf_eval_and_loss(sample_pts, True, fused, dst)
+        if dst is None:
+            self.frames.frame_avg_losses[fidx.long()] = frame_avg_loss   # trainer.py:979
         if not fused:
             self.optimiser.step()                       # backward is fused into sdf_eval_and_loss
         self._step_count += 1

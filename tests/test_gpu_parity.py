@@ -272,14 +272,20 @@ def test_fused_adamw_step_is_bit_identical_to_two_call_path():
             s = eng.sample(_dev(g["depth_batch"]), _dev(g["T_WC_batch"]), _dev(g["normal_batch"]), idx, idx, sc,
                            seed=7, offset=it)
             kw = dict(noise_std=0.08, noise_seed=3, noise_offset=it)
-            if fused:
-                eng.train_step(s, lc, sc, optim=dict(lr=0.0013, weight_decay=0.012), **kw)
+            if fused:      # ... and loss.frame_avg scattered into a keyframe-store-like vector by the same launch
+                store = torch.full((F + 3,), -1.0, device="cuda")
+                slot = (torch.arange(F, dtype=torch.int32, device="cuda") * 1 + 2).flip(0).contiguous()
+                dbg = eng.train_step(s, lc, sc, optim=dict(lr=0.0013, weight_decay=0.012, frame_avg_out=store,
+                                                           frame_avg_index=slot), **kw)
+                la, fa = dbg["loss_approx"], store[slot.long()]
+                assert store[0] == -1 and store[1] == -1 and store[F + 2] == -1
             else:
                 eng.train_step(s, lc, sc, **kw)
+                la, fa = eng.frame_avg(F)
                 eng.adamw(lr=0.0013, weight_decay=0.012)
             torch.cuda.synchronize()
             states.append(dict(params=eng.params.clone(), m=eng.exp_avg.clone(), v=eng.exp_avg_sq.clone(),
-                               shadow=eng.shadow.clone(), red=eng.reduce_buf.clone()))
+                               shadow=eng.shadow.clone(), red=eng.reduce_buf.clone(), la=la.clone(), fa=fa.clone()))
         for k in states[0]:
             a, b = states[0][k], states[1][k]
             assert torch.equal(a.view(torch.uint8), b.view(torch.uint8)), (it, k, int((a != b).sum()))
