@@ -10,16 +10,15 @@ using namespace isdf;
 namespace isdf {
 int launch_chain(const ChainParams& p, int mode, int64_t nTiles, hipStream_t st);
 int launch_dw(const DwParams& p, hipStream_t st);
-int launch_dw_reduce(const ReduceParams& p, hipStream_t st);
 int launch_sample_pixels(const isdf_sample_args& a, const isdf_sample_out& o, hipStream_t st);
 int launch_sample_along_rays(const isdf_sample_args& a, const isdf_sample_out& o, hipStream_t st);
 int launch_adamw(float* p, float* m, float* v, const float* g, const float* cnt, float gs, float lr, float b1,
                  float b2, float eps, float wd, int step, int64_t n, hipStream_t st);
 int launch_pack(const NetLayout& L, const float* params, uint16_t* shadow, hipStream_t st);
-int launch_finalize(const float* wg_loss, int64_t maxTiles, const int32_t* n_valid, int S, const float* tot_ws,
-                    const int64_t* ib, const int64_t* ih, const int64_t* iw, int F, int H, int W, float* loss_sums,
-                    float* bl, float* bc, hipStream_t st);
-int launch_step_tail(const NetLayout& L, const float* dwPart, const float* vecPart, int vecStride, float* grad,
+int launch_adamw_pack(const NetLayout& L, float* params, float* m, float* v, uint16_t* shadow, const float* grad,
+                      const float* count_ptr, float grad_scale, float lr, float b1, float b2, float eps, float wd,
+                      int step, hipStream_t st);
+int launch_step_tail(int phase, const NetLayout& L, const float* dwPart, const float* vecPart, int vecStride, float* grad,
                      float* params, float* m, float* v, uint16_t* shadow, float grad_scale, float lr, float b1, float b2,
                      float eps, float wd, int step, const float* wg_loss, int64_t maxTiles, const int32_t* n_valid, int S,
                      const float* tot_ws, const int64_t* ib, const int64_t* ih, const int64_t* iw, int F, int H, int W,
@@ -172,7 +171,7 @@ static int train_step_impl(const isdf_net_cfg* net, const isdf_loss_cfg* loss, c
   float* blockLoss = lossSums + 8;
   float* blockCnt = blockLoss + (int64_t)a->n_frames * 64;
   if (opt) {   // single-GPU tail: slab reduction + AdamW + operand repack + loss/bin finalisation in one launch
-    rc = launch_step_tail(l, dwPart, vecPart, w.vecStride, o->reduce_buf, opt->params, opt->exp_avg, opt->exp_avg_sq,
+    rc = launch_step_tail(0, l, dwPart, vecPart, w.vecStride, o->reduce_buf, opt->params, opt->exp_avg, opt->exp_avg_sq,
                           (uint16_t*)opt->shadow, opt->grad_scale, opt->lr, opt->beta1, opt->beta2, opt->eps,
                           opt->weight_decay, opt->step, wgLoss, w.nTiles, a->n_valid, a->S, totLoss, a->indices_b,
                           a->indices_h, a->indices_w, a->n_frames, a->H, a->W, lossSums, blockLoss, blockCnt,
@@ -181,13 +180,12 @@ static int train_step_impl(const isdf_net_cfg* net, const isdf_loss_cfg* loss, c
     if (ev && hipEventRecord(ev[3], st) != hipSuccess) return ISDF_EHIP;
     return ISDF_OK;
   }
-  ReduceParams rp = {};
-  rp.lay = l; rp.dwPart = dwPart; rp.vecPart = vecPart; rp.vecStride = w.vecStride; rp.n_valid = a->n_valid;
-  rp.S = a->S; rp.grad = o->reduce_buf;
-  rc = launch_dw_reduce(rp, st);
-  if (rc) return rc;
-  rc = launch_finalize(wgLoss, w.nTiles, a->n_valid, a->S, totLoss, a->indices_b, a->indices_h, a->indices_w,
-                       a->n_frames, a->H, a->W, lossSums, blockLoss, blockCnt, st);
+  // two-call / data-parallel form: slab + partial reduction and loss/bin finalisation in ONE launch; the summed
+  // gradient then goes to the all-reduce and isdf_adamw
+  rc = launch_step_tail(1, l, dwPart, vecPart, w.vecStride, o->reduce_buf, nullptr, nullptr, nullptr, nullptr, 1.f, 0.f,
+                        0.f, 0.f, 0.f, 0.f, 1, wgLoss, w.nTiles, a->n_valid, a->S, totLoss, a->indices_b, a->indices_h,
+                        a->indices_w, a->n_frames, a->H, a->W, lossSums, blockLoss, blockCnt, nullptr, nullptr, nullptr,
+                        st);
   if (rc) return rc;
   if (ev && hipEventRecord(ev[3], st) != hipSuccess) return ISDF_EHIP;
   return ISDF_OK;
@@ -243,6 +241,9 @@ int isdf_adamw(const isdf_net_cfg* net, float* params, float* exp_avg, float* ex
   NetLayout l; int rc = make_layout(net, &l);
   if (rc) return rc;
   if (!params || !exp_avg || !exp_avg_sq || !grad_sum || step < 1) return ISDF_EINVAL;
+  if (shadow && layout_supported(l))   // update + the four packed operand copies in one launch
+    return launch_adamw_pack(l, params, exp_avg, exp_avg_sq, (uint16_t*)shadow, grad_sum, count_ptr, grad_scale, lr,
+                             beta1, beta2, eps, weight_decay, step, (hipStream_t)stream);
   rc = launch_adamw(params, exp_avg, exp_avg_sq, grad_sum, count_ptr, grad_scale, lr, beta1, beta2, eps, weight_decay,
                     step, l.n_params, (hipStream_t)stream);
   if (rc || !shadow) return rc;

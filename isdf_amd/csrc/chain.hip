@@ -25,6 +25,9 @@
 
 namespace isdf {
 
+#ifndef GEMM_HOOK_BEFORE_LAST_CHUNK
+#define GEMM_HOOK_BEFORE_LAST_CHUNK 0   // 1: request one spill tensor before the last chunk (measured +15 us, 16 spilled VGPRs)
+#endif
 #ifndef GEMM_ROLLING_REFILL
 #define GEMM_ROLLING_REFILL 0
 #endif
@@ -132,9 +135,9 @@ __device__ __forceinline__ void preload_w(WChunk<FBN>& wq, rsrc_t rw, WRef r, in
       wq.v[s][fb] = bload16<0>(rw, lane16 + (s & 3) * 1024, r.soff + fb * r.rb + (s >> 2) * 4096);
 }
 
-template <bool F16, int KSTEPS, int FBN, int PBN, int ROWB, typename Hook>
+template <bool F16, int KSTEPS, int FBN, int PBN, int ROWB, typename Hook, typename Hook2>
 __device__ __forceinline__ void gemm(f32x16 (&acc)[FBN][PBN], WChunk<FBN>& wq, rsrc_t rw, WRef wr, const char* xl,
-                                     int colByteBase, int lane, Hook&& lateHook) {
+                                     int colByteBase, int lane, Hook&& earlyHook, Hook2&& lateHook) {
   constexpr int CK = 8 / FBN;                  // k-steps per chunk: CK*FBN uint4 = 32 VGPRs
   static_assert(KSTEPS % CK == 0, "K must be a multiple of the chunk");
   static_assert((ROWB & 1023) == 0, "row base must leave the swizzle bits clear");
@@ -196,8 +199,19 @@ __device__ __forceinline__ void gemm(f32x16 (&acc)[FBN][PBN], WChunk<FBN>& wq, r
   };
 #pragma unroll 1
   for (int ch = 0; ch < NCH - 1; ++ch) chunk(ch, std::true_type{});
+  // The epilogue's spill-tile prefetch is split: ONE tensor (16 VGPRs) is requested before the last chunk --
+  // behind the last weight request, because vmcnt retires in order and a prefetch in front of a weight load
+  // would put its HBM round trip into the MFMA stream -- so the last chunk's MFMAs cover its latency; the
+  // rest goes out after the last MFMA, when the weight registers are dead (both early = 111 spilled VGPRs).
+#if GEMM_HOOK_BEFORE_LAST_CHUNK
+  earlyHook();
+  __builtin_amdgcn_sched_barrier(0);
   chunk(NCH - 1, std::false_type{});
-  lateHook();   // after the last MFMA: the weight registers are dead, so the prefetch adds no pressure
+#else
+  chunk(NCH - 1, std::false_type{});
+  earlyHook();
+#endif
+  lateHook();
 }
 
 template <int FBN, int PBN> __device__ __forceinline__ void zero_acc(f32x16 (&acc)[FBN][PBN]) {
@@ -455,11 +469,11 @@ __global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 ? 4 : 2)) void chain_kern
     zero_acc(acc);
     refresh();
     if (li == 0)
-      gemm<F16, EP / 16, FB, PB, ROWB>(acc, wq, rsW, fwdW(setFwdA, li), X, HD * 2, lane, [] {});
+      gemm<F16, EP / 16, FB, PB, ROWB>(acc, wq, rsW, fwdW(setFwdA, li), X, HD * 2, lane, [] {}, [] {});
     else if (li == L.cat)
-      gemm<F16, (HD + EP) / 16, FB, PB, ROWB>(acc, wq, rsW, fwdW(setFwdA, li), X, 0, lane, [] {});
+      gemm<F16, (HD + EP) / 16, FB, PB, ROWB>(acc, wq, rsW, fwdW(setFwdA, li), X, 0, lane, [] {}, [] {});
     else
-      gemm<F16, HD / 16, FB, PB, ROWB>(acc, wq, rsW, fwdW(setFwdA, li), X, 0, lane, [] {});
+      gemm<F16, HD / 16, FB, PB, ROWB>(acc, wq, rsW, fwdW(setFwdA, li), X, 0, lane, [] {}, [] {});
     TS();
     lds_barrier();  // all waves finished reading region 1
     TS();
@@ -533,7 +547,7 @@ __global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 ? 4 : 2)) void chain_kern
     zero_acc(acc);
     refresh();
     gemm<F16, HD / 16, FB, PB, ROWB>(acc, wq, rsW, wptr(setBwdA, L.bwdMat[li], HD), X, 0, lane,
-                                     [&] { prefetch(p.sp.A[li], preA); });
+                                     [&] { prefetch(p.sp.A[li], preA); }, [] {});
     TS();
     lds_barrier();
     TS();
@@ -573,7 +587,7 @@ __global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 ? 4 : 2)) void chain_kern
     if (p.normals) { li_n[0] = p.normals[ray * 3]; li_n[1] = p.normals[ray * 3 + 1]; li_n[2] = p.normals[ray * 3 + 2]; }
   };
   refresh();
-  gemm<F16, (2 * HD) / 16, FB, PB, ROWB>(acc, wq, rsW, wptr(setBwdA, L.bwdG, 2 * HD), X, 0, lane, loss_inputs);
+  gemm<F16, (2 * HD) / 16, FB, PB, ROWB>(acc, wq, rsW, wptr(setBwdA, L.bwdG, 2 * HD), X, 0, lane, [] {}, loss_inputs);
   // g_x' = J_pe^T Eg.  Eg goes through the (now idle) X tile as fp32 [BM][HD] so the contraction can run in
   // the PE stage's (point, direction-slice) mapping: 2*nf sin/cos per direction per thread and wave-uniform
   // direction constants, instead of one cos + index arithmetic per accumulator element (which took
@@ -761,19 +775,19 @@ __global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 ? 4 : 2)) void chain_kern
   // The top layer's epilogue also IS the top of the ordinary reverse sweep (zbar_L needs only a_L, the
   // injection just computed and sbar*w_out), so INJ[L-1] never leaves registers and the reverse sweep
   // starts at layer L-2 with its operand already in the X tile.
-  auto adj_gemm = [&](int li, auto&& pf) {
+  auto adj_gemm = [&](int li, auto&& pf0, auto&& pf) {
     zero_acc(acc);
     refresh();
     if (li == 0)
-      gemm<false, EP / 16, FB, PB, ROWB>(acc, wq, rsW, fwdW(setFwdB, li), X, HD * 2, lane, pf);
+      gemm<false, EP / 16, FB, PB, ROWB>(acc, wq, rsW, fwdW(setFwdB, li), X, HD * 2, lane, pf0, pf);
     else if (li == L.cat)
-      gemm<false, (HD + EP) / 16, FB, PB, ROWB>(acc, wq, rsW, fwdW(setFwdB, li), X, 0, lane, pf);
+      gemm<false, (HD + EP) / 16, FB, PB, ROWB>(acc, wq, rsW, fwdW(setFwdB, li), X, 0, lane, pf0, pf);
     else
-      gemm<false, HD / 16, FB, PB, ROWB>(acc, wq, rsW, fwdW(setFwdB, li), X, 0, lane, pf);
+      gemm<false, HD / 16, FB, PB, ROWB>(acc, wq, rsW, fwdW(setFwdB, li), X, 0, lane, pf0, pf);
   };
   for (int li = 0; li < L.L - 1; ++li) {
     Pre preA, preP;
-    adj_gemm(li, [&] { prefetch(p.sp.A[li + 1], preA); prefetch(p.sp.P[li], preP); });
+    adj_gemm(li, [&] { prefetch(p.sp.A[li + 1], preA); }, [&] { prefetch(p.sp.P[li], preP); });
     TS();
     lds_barrier();
     TS();
@@ -800,7 +814,7 @@ __global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 ? 4 : 2)) void chain_kern
   {   // top layer (peeled: its three partial-sum streams must not raise the register pressure of the loop above)
     const int li = L.L - 1;
     Pre preA, preP;
-    adj_gemm(li, [&] { prefetch(p.sp.A[li + 1], preA); prefetch(p.sp.P[li], preP); });
+    adj_gemm(li, [&] { prefetch(p.sp.A[li + 1], preA); }, [&] { prefetch(p.sp.P[li], preP); });
     TS();
     lds_barrier();
     TS();
@@ -847,10 +861,11 @@ __global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 ? 4 : 2)) void chain_kern
   // ------------------------------------------------------------------ ordinary reverse sweep with injection
   for (int li = L.L - 2; li >= 0; --li) {
     Pre preA, preI;
-    auto pf = [&] { prefetch(p.sp.A[li + 1], preA); prefetch(p.sp.INJ[li], preI); };
+    auto pf0 = [&] { prefetch(p.sp.A[li + 1], preA); };
+    auto pf = [&] { prefetch(p.sp.INJ[li], preI); };
     zero_acc(acc);
     refresh();
-    gemm<false, HD / 16, FB, PB, ROWB>(acc, wq, rsW, wptr(setBwdB, L.bwdMat[li + 1], HD), X, 0, lane, pf);
+    gemm<false, HD / 16, FB, PB, ROWB>(acc, wq, rsW, wptr(setBwdB, L.bwdMat[li + 1], HD), X, 0, lane, pf0, pf);
     TS();
     lds_barrier();
     TS();

@@ -38,12 +38,5 @@ struct DwParams {
   float* dwPart;   // [units][DW_SPLITK][HD*HD]
 };
 
-struct ReduceParams {
-  NetLayout lay;
-  const float* dwPart;
-  const float* vecPart; int32_t vecStride;
-  const int32_t* n_valid; int32_t S;
-  float* grad;
-};
 
 }  // namespace isdf

@@ -173,79 +173,7 @@ __global__ __launch_bounds__(512, 2) void dw_kernel(const DwParams p) {
       }
 }
 
-// Sum the K-split dW slabs and the per-workgroup bias / out-layer partials into
-// the flat gradient (every gradient element is written exactly once).
-__global__ void dw_reduce_kernel(const ReduceParams p) {
-  const NetLayout& L = p.lay;
-  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int HD = L.HD;
-  constexpr int64_t perUnit = (int64_t)DW_BLK * DW_BLK;
-  const int unit = (int)(idx / perUnit);
-  if (unit >= dw_units(L)) return;
-  const DwUnit du = dw_unit(L, unit);
-  const int rem = (int)(idx - unit * perUnit);
-  const int o = du.ob * DW_BLK + rem / DW_BLK;
-  const int ip = du.ib * DW_BLK + rem % DW_BLK;          // padded input column
-  const int li = du.li;
-  int col;                                               // column in the fp32 weight [HD x K_li]
-  if (li == 0) { if (ip >= L.E) return; col = ip; }
-  else if (li == L.cat) {
-    if (ip < HD) col = ip;
-    else { if (ip - HD >= L.E) return; col = ip; }       // [a | emb]: emb column e sits at HD + e
-  } else col = ip;
-  float s = 0.f;
-  const float* src = p.dwPart + (int64_t)unit * DW_SPLITK * perUnit + rem;
-#pragma unroll 4
-  for (int k = 0; k < DW_SPLITK; ++k) s += src[(int64_t)k * perUnit];
-  p.grad[L.offW[li] + (int64_t)o * L.K[li] + col] = s;
-}
-
-// biases (L*HD), w_out (HD), b_out (1): sum the per-workgroup partials.  256
-// threads = 64 parameters x 4 tile groups so the loads of a block are
-// independent (a single thread walking all tiles is latency-bound).
-__global__ __launch_bounds__(1024) void vec_reduce_kernel(const ReduceParams p) {
-  __shared__ float sh[16][64];
-  const NetLayout& L = p.lay;
-  const int HD = L.HD;
-  const int pi = threadIdx.x & 63, g = threadIdx.x >> 6;     // 16 tile groups
-  const int v = blockIdx.x * 64 + pi;
-  const int nVec = L.L * HD + HD + 1;
-  const int64_t P = (int64_t)(*p.n_valid) * p.S;
-  const int nTiles = (int)((P + TILE_PTS - 1) / TILE_PTS);
-  int slotA = 0, slotB = -1, dst = -1;
-  if (v < L.L * HD) { slotA = v; dst = L.offB[v / HD] + v % HD; }
-  else if (v < L.L * HD + HD) { slotA = v; slotB = v + HD; dst = L.offWout + (v - L.L * HD); }
-  else if (v < nVec) { slotA = L.L * HD + 2 * HD; dst = L.offBout; }
-  float s = 0.f, s2 = 0.f;
-  if (dst >= 0) {
-    int t = g;
-    for (; t + 48 < nTiles; t += 64) {      // 4 independent loads in flight per thread
-      const float* r0 = p.vecPart + (int64_t)t * p.vecStride;
-      const float a0 = r0[slotA], a1 = r0[(int64_t)16 * p.vecStride + slotA],
-                  a2 = r0[(int64_t)32 * p.vecStride + slotA], a3 = r0[(int64_t)48 * p.vecStride + slotA];
-      s += (a0 + a1) + (a2 + a3);
-      if (slotB >= 0) {
-        const float b0 = r0[slotB], b1 = r0[(int64_t)16 * p.vecStride + slotB],
-                    b2 = r0[(int64_t)32 * p.vecStride + slotB], b3 = r0[(int64_t)48 * p.vecStride + slotB];
-        s2 += (b0 + b1) + (b2 + b3);
-      }
-    }
-    for (; t < nTiles; t += 16) {
-      const float* row = p.vecPart + (int64_t)t * p.vecStride;
-      s += row[slotA];
-      if (slotB >= 0) s2 += row[slotB];
-    }
-    s += s2;
-  }
-  sh[g][pi] = s;
-  __syncthreads();
-  if (g == 0 && dst >= 0) {
-    float t = 0.f;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) t += sh[k][pi];
-    p.grad[dst] = t;
-  }
-}
+// The K-split slabs and the per-workgroup bias / out-layer partials are summed by the step-tail kernel (optim.hip).
 
 int launch_dw(const DwParams& p, hipStream_t st) {
   if (!layout_supported(p.lay)) return ISDF_EUNSUPPORTED;
@@ -260,15 +188,6 @@ int launch_dw(const DwParams& p, hipStream_t st) {
     if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES) != hipSuccess) return ISDF_EHIP;
     hipLaunchKernelGGL(k, grid, block, T::LDS_BYTES, st, p);
   }
-  return hipGetLastError() == hipSuccess ? ISDF_OK : ISDF_EHIP;
-}
-
-int launch_dw_reduce(const ReduceParams& p, hipStream_t st) {
-  const NetLayout& L = p.lay;
-  const int64_t total = (int64_t)dw_units(L) * DW_BLK * DW_BLK;
-  hipLaunchKernelGGL(dw_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, p);
-  const int nVec = L.L * L.HD + L.HD + 1;
-  hipLaunchKernelGGL(vec_reduce_kernel, dim3((unsigned)((nVec + 63) / 64)), dim3(1024), 0, st, p);
   return hipGetLastError() == hipSuccess ? ISDF_OK : ISDF_EHIP;
 }
 

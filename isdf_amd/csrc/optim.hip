@@ -187,10 +187,6 @@ __device__ __forceinline__ void finalize_block(int block, const FinalizeArgs& a,
     }
   }
 }
-__global__ __launch_bounds__(1024) void finalize_kernel(const FinalizeArgs a) {
-  __shared__ FinalizeLds lds;
-  finalize_block(blockIdx.x, a, lds);
-}
 
 // ---- fused step tail (single-GPU path) ------------------------------------------
 // One launch after the dW kernel: [weights: sum the K-split dW slabs -> gradient -> AdamW -> the four packed
@@ -204,7 +200,8 @@ struct TailParams {
   const float* dwPart; const float* vecPart; int32_t vecStride;
   float* grad;                       // [n_params] summed gradient (still written: reduce_buf contract)
   float *params, *m, *v; uint16_t* shadow;
-  AdamwCoef c; float grad_scale;     // gradient = sum * grad_scale / (n_valid * S)
+  AdamwCoef c; float grad_scale;     // gradient = sum * grad_scale / (n_valid * S)   [PHASE 0]
+  const float* count_ptr;            // PHASE 2: gradient = grad[] * grad_scale / *count_ptr (reduced count)
   FinalizeArgs fin;
   int nW, nV;                        // blocks of the weight and the vector sections
 };
@@ -219,14 +216,19 @@ __device__ __forceinline__ int64_t packed_elem(int row, int k, int Kp) {
   return ((((int64_t)(row >> 5) * (Kp >> 4) + (k >> 4)) * 64 + (row & 31) + 32 * ((k & 15) >> 3)) << 3) + (k & 7);
 }
 
+// PHASE 0: everything (single GPU).  PHASE 1: reduction + finalisation only (isdf_train_step: the gradient
+// sums go to the all-reduce).  PHASE 2: AdamW + operand repack from an already reduced gradient (isdf_adamw).
+template <int PHASE>
 __global__ __launch_bounds__(1024) void step_tail_kernel(const TailParams p) {
   __shared__ FinalizeLds lds;
   const NetLayout& L = p.lay;
   const int HD = L.HD;
   const int b = blockIdx.x;
-  if (b >= p.nW + p.nV) { finalize_block(b - p.nW - p.nV, p.fin, lds); return; }
-  const int64_t P = (int64_t)(*p.fin.n_valid) * p.fin.S;
-  const float gs = p.grad_scale / (float)P;
+  if (b >= p.nW + p.nV) { if (PHASE != 2) finalize_block(b - p.nW - p.nV, p.fin, lds); return; }
+  const int64_t P = PHASE == 2 ? 0 : (int64_t)(*p.fin.n_valid) * p.fin.S;
+  float gs = p.grad_scale;
+  if (PHASE == 0) gs /= (float)P;
+  if (PHASE == 2 && p.count_ptr) gs /= *p.count_ptr;
   if (b < p.nW) {
     // ---- weights (dw_reduce_kernel's mapping: one thread per element of a 256x256 dW unit)
     const int64_t idx = (int64_t)b * 1024 + threadIdx.x;
@@ -241,12 +243,16 @@ __global__ __launch_bounds__(1024) void step_tail_kernel(const TailParams p) {
     if (li == 0 && ip >= L.E) return;
     if (li == L.cat && ip >= HD && ip - HD >= L.E) return;
     const int col = ip;                                    // column in the fp32 weight [HD x K_li]
-    float s = 0.f;
-    const float* src = p.dwPart + (int64_t)unit * DW_SPLITK * perUnit + rem;
-#pragma unroll 4
-    for (int k = 0; k < DW_SPLITK; ++k) s += src[(int64_t)k * perUnit];
     const int64_t pi = L.offW[li] + (int64_t)o * L.K[li] + col;
-    p.grad[pi] = s;
+    float s = 0.f;
+    if (PHASE == 2) s = p.grad[pi];
+    else {
+      const float* src = p.dwPart + (int64_t)unit * DW_SPLITK * perUnit + rem;
+#pragma unroll 4
+      for (int k = 0; k < DW_SPLITK; ++k) s += src[(int64_t)k * perUnit];
+      p.grad[pi] = s;
+      if (PHASE == 1) return;
+    }
     const float w = adamw_update(p.params, p.m, p.v, pi, s, gs, p.c);
     // packed operand copies (pack_kernel's sources, inverted): forward orientation ...
     const int KpF = li == 0 ? L.EP : (li == L.cat ? HD + L.EP : HD);
@@ -268,6 +274,10 @@ __global__ __launch_bounds__(1024) void step_tail_kernel(const TailParams p) {
   if (v < L.L * HD) { slotA = v; dst = L.offB[v / HD] + v % HD; }
   else if (v < L.L * HD + HD) { slotA = v; slotB = v + HD; dst = L.offWout + (v - L.L * HD); }
   else if (v < nVec) { slotA = L.L * HD + 2 * HD; dst = L.offBout; }
+  if (PHASE == 2) {
+    if (g == 0 && dst >= 0) adamw_update(p.params, p.m, p.v, dst, p.grad[dst], gs, p.c);
+    return;
+  }
   float s = 0.f, s2 = 0.f;
   if (dst >= 0) {
     int t = g;
@@ -296,7 +306,7 @@ __global__ __launch_bounds__(1024) void step_tail_kernel(const TailParams p) {
 #pragma unroll
     for (int k = 0; k < 16; ++k) t += sh[k][pi];
     p.grad[dst] = t;
-    adamw_update(p.params, p.m, p.v, dst, t, gs, p.c);
+    if (PHASE == 0) adamw_update(p.params, p.m, p.v, dst, t, gs, p.c);
   }
 }
 
@@ -373,14 +383,9 @@ static FinalizeArgs finalize_args(const float* wg_loss, int64_t maxTiles, const 
   FinalizeArgs a = {wg_loss, maxTiles, n_valid, S, tot_ws, ib, ih, iw, F, H, W, loss_sums, bl, bc, nullptr, nullptr, nullptr};
   return a;
 }
-int launch_finalize(const float* wg_loss, int64_t maxTiles, const int32_t* n_valid, int S, const float* tot_ws,
-                    const int64_t* ib, const int64_t* ih, const int64_t* iw, int F, int H, int W, float* loss_sums,
-                    float* bl, float* bc, hipStream_t st) {
-  hipLaunchKernelGGL(finalize_kernel, dim3(1 + F), dim3(1024), 0, st,
-                     finalize_args(wg_loss, maxTiles, n_valid, S, tot_ws, ib, ih, iw, F, H, W, loss_sums, bl, bc));
-  return hipGetLastError() == hipSuccess ? ISDF_OK : ISDF_EHIP;
-}
-int launch_step_tail(const NetLayout& L, const float* dwPart, const float* vecPart, int vecStride, float* grad,
+// phase 0: params/m/v/shadow + optim scalars + finalize args; phase 1: grad + finalize args only;
+// phase 2 (launch_adamw_pack): params/m/v/shadow + optim scalars + count_ptr, grad = reduced gradient
+int launch_step_tail(int phase, const NetLayout& L, const float* dwPart, const float* vecPart, int vecStride, float* grad,
                      float* params, float* m, float* v, uint16_t* shadow, float grad_scale, float lr, float b1, float b2,
                      float eps, float wd, int step, const float* wg_loss, int64_t maxTiles, const int32_t* n_valid, int S,
                      const float* tot_ws, const int64_t* ib, const int64_t* ih, const int64_t* iw, int F, int H, int W,
@@ -389,13 +394,29 @@ int launch_step_tail(const NetLayout& L, const float* dwPart, const float* vecPa
   TailParams p = {};
   p.lay = L; p.dwPart = dwPart; p.vecPart = vecPart; p.vecStride = vecStride; p.grad = grad;
   p.params = params; p.m = m; p.v = v; p.shadow = shadow; p.grad_scale = grad_scale;
-  p.c = AdamwCoef{lr, b1, b2, eps, wd, 1.f - powf(b1, (float)step), sqrtf(1.f - powf(b2, (float)step))};
+  if (phase == 0)
+    p.c = AdamwCoef{lr, b1, b2, eps, wd, 1.f - powf(b1, (float)step), sqrtf(1.f - powf(b2, (float)step))};
   p.fin = finalize_args(wg_loss, maxTiles, n_valid, S, tot_ws, ib, ih, iw, F, H, W, loss_sums, bl, bc);
   if (la_out && fa_out) { p.fin.la_out = la_out; p.fin.fa_out = fa_out; p.fin.fa_index = fa_index; }
   const int64_t total = (int64_t)dw_units(L) * DW_BLK * DW_BLK;
   p.nW = (int)((total + 1023) / 1024);
   p.nV = (L.L * L.HD + L.HD + 1 + 63) / 64;
-  hipLaunchKernelGGL(step_tail_kernel, dim3((unsigned)(p.nW + p.nV + 1 + F)), dim3(1024), 0, st, p);
+  const dim3 grid((unsigned)(p.nW + p.nV + 1 + F));
+  if (phase == 0) hipLaunchKernelGGL(step_tail_kernel<0>, grid, dim3(1024), 0, st, p);
+  else hipLaunchKernelGGL(step_tail_kernel<1>, grid, dim3(1024), 0, st, p);
+  return hipGetLastError() == hipSuccess ? ISDF_OK : ISDF_EHIP;
+}
+int launch_adamw_pack(const NetLayout& L, float* params, float* m, float* v, uint16_t* shadow, const float* grad,
+                      const float* count_ptr, float grad_scale, float lr, float b1, float b2, float eps, float wd,
+                      int step, hipStream_t st) {
+  TailParams p = {};
+  p.lay = L; p.grad = const_cast<float*>(grad); p.params = params; p.m = m; p.v = v; p.shadow = shadow;
+  p.grad_scale = grad_scale; p.count_ptr = count_ptr;
+  p.c = AdamwCoef{lr, b1, b2, eps, wd, 1.f - powf(b1, (float)step), sqrtf(1.f - powf(b2, (float)step))};
+  const int64_t total = (int64_t)dw_units(L) * DW_BLK * DW_BLK;
+  p.nW = (int)((total + 1023) / 1024);
+  p.nV = (L.L * L.HD + L.HD + 1 + 63) / 64;
+  hipLaunchKernelGGL(step_tail_kernel<2>, dim3((unsigned)(p.nW + p.nV)), dim3(1024), 0, st, p);
   return hipGetLastError() == hipSuccess ? ISDF_OK : ISDF_EHIP;
 }
 int launch_frame_avg(const float* bl, const float* bc, int F, float* la, float* fa, hipStream_t st) {
