@@ -147,12 +147,17 @@ def main():
     local = local % max(torch.cuda.device_count(), 1) if backend != "nccl" else local
     torch.cuda.set_device(local)
     group = None
-    if world > 1:
+    # ISDF_BENCH_FORCE_DP=1: run the data-parallel step sequence (two-call form + all-reduce) with a one-rank
+    # process group, to exercise the N>1 code path end to end on a single-GPU box.  Not the N=1 bench line.
+    force_dp = world == 1 and os.environ.get("ISDF_BENCH_FORCE_DP") == "1"
+    if world > 1 or force_dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        kw = dict(rank=rank, world_size=world)
         if backend == "nccl":
-            torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local))
+            torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local), **kw)
         else:
-            torch.distributed.init_process_group(backend)
+            torch.distributed.init_process_group(backend, **kw)
         group = torch.distributed.group.WORLD
 
     import __graft_entry__
@@ -198,8 +203,7 @@ def main():
         if group is not None:   # data parallel: all-reduce the summed gradient, then AdamW + repack
             dp.allreduce_(eng.reduce_buf, group)
             tr.optimiser.step()
-            la, fa = eng.frame_avg(F)
-            tr.frames.frame_avg_losses[fidx.long()] = fa        # trainer.py:979
+            eng.frame_avg(F, out=tr.frames.frame_avg_losses, index=fidx)   # trainer.py:979, scattered in-kernel
         return s
 
     for i in range(W):

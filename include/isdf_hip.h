@@ -233,10 +233,13 @@ int isdf_bounds_pc(const int32_t* n_valid, int32_t max_rays, int32_t S, const fl
                    const float* z_vals, const float* depth_sample, const float* surf_pts,
                    int64_t n_surf, float* bounds, float* grad_vec, void* stream);
 
-/* per-frame 8x8 block-loss averages from the reduced bins (loss.py:208-240):
- * loss_approx [F,8,8], frame_avg_loss [F]                                      */
+/* per-frame 8x8 block-loss averages from the (all-reduced) bins (loss.py:208-240): loss_approx [F,8,8] and
+ * frame_avg_loss[frame_avg_index ? frame_avg_index[f] : f] -- pass the keyframe store's frame_avg_losses and
+ * the window's keyframe ids to get `self.frames.frame_avg_losses[idxs] = frame_avg_loss` (trainer.py:979)
+ * without the separate index_put; frame_avg_index NULL: dense [F] output.                                  */
 int isdf_frame_avg(const float* reduce_buf, int64_t n_params, int32_t n_frames,
-                   float* loss_approx, float* frame_avg_loss, void* stream);
+                   float* loss_approx, float* frame_avg_loss, const int32_t* frame_avg_index,
+                   void* stream);
 
 /* ---- per-frame ingest and keyframe test ("next" tier) ------------
  * isdf_estimate_normals: transform.pointcloud_from_depth_torch +

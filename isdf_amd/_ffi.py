@@ -113,7 +113,7 @@ def lib():
     L.isdf_train_step.argtypes = [P(NetCfg), P(LossCfg), vp, vp, P(StepArgs), P(StepOut), vp, i64, vp]
     L.isdf_train_step_adamw.argtypes = [P(NetCfg), P(LossCfg), P(StepArgs), P(StepOut), P(OptimArgs), vp, i64, vp]
     L.isdf_bounds_pc.argtypes = [vp, i32, i32, vp, vp, vp, vp, i64, vp, vp, vp]
-    L.isdf_frame_avg.argtypes = [vp, i64, i32, vp, vp, vp]
+    L.isdf_frame_avg.argtypes = [vp, i64, i32, vp, vp, vp, vp]
     L.isdf_adamw.argtypes = [P(NetCfg), vp, vp, vp, vp, vp, f32, f32, f32, f32, f32, f32, i32, vp, vp]
     L.isdf_estimate_normals.argtypes = [vp, i32, i32, f32, f32, f32, f32, vp, vp]
     L.isdf_render_depth.argtypes = [vp, i64, i64, i32, vp, vp, vp, f32, vp, vp, vp]

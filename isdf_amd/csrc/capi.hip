@@ -24,7 +24,8 @@ int launch_step_tail(int phase, const NetLayout& L, const float* dwPart, const f
                      const float* tot_ws, const int64_t* ib, const int64_t* ih, const int64_t* iw, int F, int H, int W,
                      float* loss_sums, float* bl, float* bc, float* la_out, float* fa_out, const int32_t* fa_index,
                      hipStream_t st);
-int launch_frame_avg(const float* bl, const float* bc, int F, float* la, float* fa, hipStream_t st);
+int launch_frame_avg(const float* bl, const float* bc, int F, float* la, float* fa, const int32_t* fa_index,
+                     hipStream_t st);
 int launch_bounds_pc(const int32_t* n_valid, int max_rays, int S, const float* pc, const float* z, const float* depth,
                      const float* surf, int64_t n_surf, float* bounds, float* gv, hipStream_t st);
 int launch_normals(const float* depth, int H, int W, float fx, float fy, float cx, float cy, float* normals,
@@ -214,10 +215,11 @@ int isdf_bounds_pc(const int32_t* n_valid, int32_t max_rays, int32_t S, const fl
 }
 
 int isdf_frame_avg(const float* reduce_buf, int64_t n_params, int32_t n_frames, float* loss_approx,
-                   float* frame_avg_loss, void* stream) {
+                   float* frame_avg_loss, const int32_t* frame_avg_index, void* stream) {
   if (!reduce_buf || !loss_approx || !frame_avg_loss || n_frames < 1 || n_params < 0) return ISDF_EINVAL;
   const float* bl = reduce_buf + n_params + 8;
-  return launch_frame_avg(bl, bl + (int64_t)n_frames * 64, n_frames, loss_approx, frame_avg_loss, (hipStream_t)stream);
+  return launch_frame_avg(bl, bl + (int64_t)n_frames * 64, n_frames, loss_approx, frame_avg_loss, frame_avg_index,
+                          (hipStream_t)stream);
 }
 
 int isdf_estimate_normals(const float* depth, int32_t H, int32_t W, float fx, float fy, float cx, float cy,

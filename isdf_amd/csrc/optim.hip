@@ -311,7 +311,8 @@ __global__ __launch_bounds__(1024) void step_tail_kernel(const TailParams p) {
 }
 
 __global__ void frame_avg_kernel(const float* __restrict__ block_loss, const float* __restrict__ block_cnt,
-                                 int n_frames, float* __restrict__ loss_approx, float* __restrict__ frame_avg) {
+                                 int n_frames, float* __restrict__ loss_approx, float* __restrict__ frame_avg,
+                                 const int32_t* __restrict__ fa_index) {
   const int f = blockIdx.x, t = threadIdx.x;  // 64 threads
   float c = block_cnt[f * 64 + t];
   c = c == 0.f ? 1.f : c;                      // loss.py:215
@@ -319,7 +320,7 @@ __global__ void frame_avg_kernel(const float* __restrict__ block_loss, const flo
   loss_approx[f * 64 + t] = v;
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-  if (t == 0) frame_avg[f] = v / 64.f;         // loss.py:236-238
+  if (t == 0) frame_avg[fa_index ? fa_index[f] : f] = v / 64.f;         // loss.py:236-238
 }
 
 // ---- bounds_pc: brute-force nearest surface point, LDS-tiled -------------------
@@ -419,8 +420,9 @@ int launch_adamw_pack(const NetLayout& L, float* params, float* m, float* v, uin
   hipLaunchKernelGGL(step_tail_kernel<2>, dim3((unsigned)(p.nW + p.nV)), dim3(1024), 0, st, p);
   return hipGetLastError() == hipSuccess ? ISDF_OK : ISDF_EHIP;
 }
-int launch_frame_avg(const float* bl, const float* bc, int F, float* la, float* fa, hipStream_t st) {
-  hipLaunchKernelGGL(frame_avg_kernel, dim3(F), dim3(64), 0, st, bl, bc, F, la, fa);
+int launch_frame_avg(const float* bl, const float* bc, int F, float* la, float* fa, const int32_t* fa_index,
+                     hipStream_t st) {
+  hipLaunchKernelGGL(frame_avg_kernel, dim3(F), dim3(64), 0, st, bl, bc, F, la, fa, fa_index);
   return hipGetLastError() == hipSuccess ? ISDF_OK : ISDF_EHIP;
 }
 int launch_bounds_pc(const int32_t* n_valid, int max_rays, int S, const float* pc, const float* z, const float* depth,

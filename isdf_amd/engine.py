@@ -339,11 +339,18 @@ class Engine:
     def loss_sums(self):
         return self.reduce_buf[self.n_params:self.n_params + 8]
 
-    def frame_avg(self, n_frames):
+    def frame_avg(self, n_frames, out=None, index=None):
+        """loss.frame_avg from the (reduced) bins.  out/index: write frame f's average to out[index[f]] (the
+        keyframe store's frame_avg_losses and the window's keyframe ids) instead of a fresh [F] tensor."""
         la = torch.empty(n_frames, 8, 8, dtype=torch.float32, device=self.device)
-        fa = torch.empty(n_frames, dtype=torch.float32, device=self.device)
+        if out is None:
+            fa = torch.empty(n_frames, dtype=torch.float32, device=self.device)
+        else:
+            assert out.dtype == torch.float32 and out.is_contiguous()
+            assert index is None or (index.dtype == torch.int32 and index.numel() == n_frames)
+            fa = out
         _ffi.check(self.lib.isdf_frame_avg(_ffi.ptr(self.reduce_buf), self.n_params, n_frames, _ffi.ptr(la),
-                                           _ffi.ptr(fa), _stream()), "isdf_frame_avg")
+                                           _ffi.ptr(fa), _ffi.ptr(index), _stream()), "isdf_frame_avg")
         return la, fa
 
     # ---- per-frame ingest / keyframe test (SURVEY 8f) -------------------------------

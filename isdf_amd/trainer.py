@@ -424,7 +424,9 @@ class HipTrainer:
     # ---- loss + backward (trainer.py:768-868, 981) -----------------------------------
     def sdf_eval_and_loss(self, sample, do_avg_loss=True, fused_optim=False, frame_avg_dst=None):
         """fused_optim: also apply the optimiser step inside the same native call (single-GPU fast path,
-        isdf_train_step_adamw); the caller must then NOT call self.optimiser.step()."""
+        isdf_train_step_adamw); the caller must then NOT call self.optimiser.step().
+        frame_avg_dst = (store, index): write frame f's average loss to store[index[f]] inside the native call
+        (what trainer.py:979 does with the returned vector); frame_avg_loss is then returned as None."""
         s, sc = sample["_raw"], sample["_sc"]
         noise = None
         if self.noise_std is not None:   # fc_map.py:106-108 (drawn even for 0, SURVEY q3)
@@ -455,7 +457,10 @@ class HipTrainer:
         loss_approx = frame_avg_loss = None
         if do_avg_loss and "loss_approx" in dbg:      # written by the fused tail, straight into frame_avg_dst
             loss_approx = dbg["loss_approx"]
-            frame_avg_loss = frame_avg_dst[0][frame_avg_dst[1].long()] if frame_avg_dst[1] is not None else frame_avg_dst[0]
+            frame_avg_loss = None                         # already in frame_avg_dst (no gather launch for nothing)
+        elif do_avg_loss and frame_avg_dst is not None:   # two-call / data-parallel path: scatter inside isdf_frame_avg
+            loss_approx, _ = self.engine.frame_avg(s["n_frames"], out=frame_avg_dst[0], index=frame_avg_dst[1])
+            frame_avg_loss = None
         elif do_avg_loss:
             loss_approx, frame_avg_loss = self.engine.frame_avg(s["n_frames"])
         return total_loss, losses, loss_approx, frame_avg_loss
@@ -482,7 +487,7 @@ class HipTrainer:
         self.active_pixels = {k: sample_pts[k] for k in ("indices_b", "indices_h", "indices_w")}
 
         fused = self.dist_group is None and getattr(self, "fuse_optimiser", True)
-        dst = (self.frames.frame_avg_losses, fidx) if fused and self.frames.frame_avg_losses.is_contiguous() else None
+        dst = (self.frames.frame_avg_losses, fidx) if self.frames.frame_avg_losses.is_contiguous() else None
         total_loss, losses, active_loss_approx, frame_avg_loss = self.sdf_eval_and_loss(sample_pts, True, fused, dst)
         if dst is None:
             self.frames.frame_avg_losses[fidx.long()] = frame_avg_loss   # trainer.py:979
