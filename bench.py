@@ -225,6 +225,18 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # ---- informational: the host mirror's own step(), device-synchronised per step exactly as the reference's
+    # metrics.start_timing/end_timing measure it (metrics.py:13-38): includes the host's
+    # time-to-first-launch that the pipelined figure above overlaps.  Not part of `value`.
+    tr.noise_std = tr.noise_kf
+    for _ in range(10):
+        tr.step()
+    n_sync = 100
+    ts = time.perf_counter()
+    for _ in range(n_sync):
+        tr.step()
+    sync_step_ms = (time.perf_counter() - ts) / n_sync * 1e3
+
     # ---- per-kernel timing from the HIP events recorded inside the timed region
     t_chain = np.mean([events.ms(4 * i, 4 * i + 1) for i in range(K)]) * 1e-3
     t_dw = np.mean([events.ms(4 * i + 1, 4 * i + 2) for i in range(K)]) * 1e-3
@@ -269,6 +281,7 @@ def main():
             "points_per_s": round(world * P * K / elapsed, 1),
             "valid_points_per_step": round(P, 1),
             "final_total_loss": round(final_loss, 5),
+            "trainer_step_sync_ms": round(sync_step_ms, 4),   # HipTrainer.step(), synchronised per step like the reference
             "kernel_ms": {"chain": round(t_chain * 1e3, 4), "dw": round(t_dw * 1e3, 4),
                           "tail(reduce,adamw,pack,finalize)" if group is None else "reduce+finalize": round(t_red * 1e3, 4)},
             "roofline": {"bound": "mfma", "kernel": "chain_kernel (fused PE+MLP fwd / input-grad / adjoint / reverse)",

@@ -200,7 +200,7 @@ class Engine:
             a.rng_mode = 1
             a.seed, a.offset = int(seed), int(offset)
         out = dict(
-            n_valid=torch.zeros(1, dtype=torch.int32, device=dev),
+            n_valid=torch.empty(1, dtype=torch.int32, device=dev),   # always written by sample_pixels (no fill launch)
             indices_b=torch.empty(R0, dtype=torch.int64, device=dev),
             indices_h=torch.empty(R0, dtype=torch.int64, device=dev),
             indices_w=torch.empty(R0, dtype=torch.int64, device=dev),

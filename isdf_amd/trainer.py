@@ -477,10 +477,18 @@ class HipTrainer:
         else:
             idxs = np.arange(K)
         self.active_idxs = idxs
-        fidx = torch.as_tensor(np.asarray(idxs), dtype=torch.int32, device=self.device)
-        # reference quirk q4: normals are read from the UN-windowed normal_batch with
-        # window-local indices (trainer.py:956,969); fix_normal_window=True uses idxs.
-        nidx = fidx if self.fix_normal_window else torch.arange(len(idxs), dtype=torch.int32, device=self.device)
+        # device copies of the window indices are cached while the window does not change (between keyframe
+        # selections the reference rebuilds them every step: one H2D copy + one arange launch in front of the
+        # first kernel of a device-synchronised step)
+        key = (tuple(int(i) for i in idxs), bool(self.fix_normal_window))
+        cache = getattr(self, "_idx_cache", None)
+        if cache is None or cache[0] != key:
+            fidx = torch.as_tensor(np.asarray(idxs), dtype=torch.int32, device=self.device)
+            # reference quirk q4: normals are read from the UN-windowed normal_batch with
+            # window-local indices (trainer.py:956,969); fix_normal_window=True uses idxs.
+            nidx = fidx if self.fix_normal_window else torch.arange(len(idxs), dtype=torch.int32, device=self.device)
+            self._idx_cache = cache = (key, fidx, nidx)
+        _, fidx, nidx = cache
         norm_batch = self.frames.normal_batch if self.do_normal else None
         sample_pts = self.sample_points(self.frames.depth_batch, self.frames.T_WC_batch, norm_batch=norm_batch,
                                         _idx=(fidx, nidx))
