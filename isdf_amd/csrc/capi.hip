@@ -1,6 +1,7 @@
 // extern "C" entry points declared in include/isdf_hip.h: argument validation,
 // layout computation and kernel launches.  No allocation, no synchronisation,
 // no global state.
+#include <cstdio>
 #include "isdf_common.h"
 #include "chain_params.h"
 #include <cstdlib>
@@ -35,6 +36,8 @@ int launch_render_depth(const int32_t* n_valid, int64_t n_host, int64_t max_rays
                         hipStream_t st);
 }  // namespace isdf
 
+namespace isdf { thread_local int g_isdf_last_hip_error = 0; }
+
 extern "C" {
 
 int isdf_abi_version(void) { return ISDF_ABI_VERSION; }
@@ -45,7 +48,11 @@ const char* isdf_error_string(int code) {
     case ISDF_EINVAL: return "invalid argument";
     case ISDF_EUNSUPPORTED: return "unsupported configuration (kernels are built for hidden 256 with n_freqs<=6 and hidden 512 with 7<=n_freqs<=12)";
     case ISDF_EWORKSPACE: return "workspace too small";
-    case ISDF_EHIP: return "HIP runtime error";
+    case ISDF_EHIP: {
+      static thread_local char buf[160];
+      snprintf(buf, sizeof(buf), "HIP runtime error: %s", g_isdf_last_hip_error ? hipGetErrorString((hipError_t)g_isdf_last_hip_error) : "(no launch status recorded)");
+      return buf;
+    }
   }
   return "unknown error";
 }
@@ -75,6 +82,7 @@ int64_t isdf_reduce_floats(const isdf_net_cfg* net, int32_t n_frames) {
 }
 
 int isdf_pack_weights(const isdf_net_cfg* net, const float* params, void* shadow, void* stream) {
+  isdf_clear_stale_hip_error();
   NetLayout l; int rc = make_layout(net, &l);
   if (rc) return rc;
   if (!params || !shadow) return ISDF_EINVAL;
@@ -82,6 +90,7 @@ int isdf_pack_weights(const isdf_net_cfg* net, const float* params, void* shadow
 }
 
 int isdf_sample_pixels(const isdf_sample_args* a, const isdf_sample_out* o, void* stream) {
+  isdf_clear_stale_hip_error();
   if (!a || !o || !a->depth_batch || !a->T_WC_batch || !a->frame_idx || !o->n_valid || !o->indices_b ||
       !o->indices_h || !o->indices_w || !o->depth_sample || !o->dirs_C_sample || !o->dirs_W_sample)
     return ISDF_EINVAL;
@@ -92,6 +101,7 @@ int isdf_sample_pixels(const isdf_sample_args* a, const isdf_sample_out* o, void
 }
 
 int isdf_sample_along_rays(const isdf_sample_args* a, const isdf_sample_out* o, void* stream) {
+  isdf_clear_stale_hip_error();
   if (!a || !o || !o->n_valid || !o->z_vals || !o->pc || !o->depth_sample || !o->dirs_W_sample || !o->indices_b)
     return ISDF_EINVAL;
   if (a->n_strat < 1 || a->n_surf < 0) return ISDF_EINVAL;
@@ -102,6 +112,7 @@ int isdf_sample_along_rays(const isdf_sample_args* a, const isdf_sample_out* o, 
 int isdf_sdf_eval(const isdf_net_cfg* net, const float* params, const void* shadow, const float* pts,
                   int64_t n_points, const float* noise, float* sdf, float* sdf_grad, void* workspace,
                   int64_t workspace_bytes, void* stream) {
+  isdf_clear_stale_hip_error();
   NetLayout l; int rc = make_layout(net, &l);
   if (rc) return rc;
   if (!layout_supported(l)) return ISDF_EUNSUPPORTED;
@@ -122,6 +133,7 @@ int isdf_sdf_eval(const isdf_net_cfg* net, const float* params, const void* shad
 static int train_step_impl(const isdf_net_cfg* net, const isdf_loss_cfg* loss, const float* params, const void* shadow,
                            const isdf_step_args* a, const isdf_step_out* o, void* workspace, int64_t workspace_bytes,
                            void* stream, const isdf_optim_args* opt) {
+  isdf_clear_stale_hip_error();
   NetLayout l; int rc = make_layout(net, &l);
   if (rc) return rc;
   if (!layout_supported(l)) return ISDF_EUNSUPPORTED;
@@ -208,6 +220,7 @@ int isdf_train_step_adamw(const isdf_net_cfg* net, const isdf_loss_cfg* loss, co
 int isdf_bounds_pc(const int32_t* n_valid, int32_t max_rays, int32_t S, const float* pc, const float* z_vals,
                    const float* depth_sample, const float* surf_pts, int64_t n_surf, float* bounds, float* grad_vec,
                    void* stream) {
+  isdf_clear_stale_hip_error();
   if (!n_valid || !pc || !z_vals || !depth_sample || !bounds || !grad_vec || max_rays < 1 || S < 1) return ISDF_EINVAL;
   if (surf_pts && n_surf < 1) return ISDF_EINVAL;
   return launch_bounds_pc(n_valid, max_rays, S, pc, z_vals, depth_sample, surf_pts, n_surf, bounds, grad_vec,
@@ -216,6 +229,7 @@ int isdf_bounds_pc(const int32_t* n_valid, int32_t max_rays, int32_t S, const fl
 
 int isdf_frame_avg(const float* reduce_buf, int64_t n_params, int32_t n_frames, float* loss_approx,
                    float* frame_avg_loss, const int32_t* frame_avg_index, void* stream) {
+  isdf_clear_stale_hip_error();
   if (!reduce_buf || !loss_approx || !frame_avg_loss || n_frames < 1 || n_params < 0) return ISDF_EINVAL;
   const float* bl = reduce_buf + n_params + 8;
   return launch_frame_avg(bl, bl + (int64_t)n_frames * 64, n_frames, loss_approx, frame_avg_loss, frame_avg_index,
@@ -224,6 +238,7 @@ int isdf_frame_avg(const float* reduce_buf, int64_t n_params, int32_t n_frames, 
 
 int isdf_estimate_normals(const float* depth, int32_t H, int32_t W, float fx, float fy, float cx, float cy,
                           float* normals, void* stream) {
+  isdf_clear_stale_hip_error();
   if (!depth || !normals || H < 1 || W < 1 || fx == 0.f || fy == 0.f) return ISDF_EINVAL;
   return launch_normals(depth, H, W, fx, fy, cx, cy, normals, (hipStream_t)stream);
 }
@@ -231,6 +246,7 @@ int isdf_estimate_normals(const float* depth, int32_t H, int32_t W, float fx, fl
 int isdf_render_depth(const int32_t* n_valid, int64_t n_rays_host, int64_t max_rays, int32_t S, const float* z_vals,
                       const float* sdf, const float* depth_sample, float kf_dist_th, float* view_depth,
                       int32_t* below_count, void* stream) {
+  isdf_clear_stale_hip_error();
   if (!z_vals || !sdf || !view_depth || S < 1 || max_rays < 1) return ISDF_EINVAL;
   if (!n_valid && (n_rays_host < 0 || n_rays_host > max_rays)) return ISDF_EINVAL;
   return launch_render_depth(n_valid, n_rays_host, max_rays, S, z_vals, sdf, depth_sample, kf_dist_th, view_depth,
@@ -240,6 +256,7 @@ int isdf_render_depth(const int32_t* n_valid, int64_t n_rays_host, int64_t max_r
 int isdf_adamw(const isdf_net_cfg* net, float* params, float* exp_avg, float* exp_avg_sq, const float* grad_sum,
                const float* count_ptr, float grad_scale, float lr, float beta1, float beta2, float eps,
                float weight_decay, int32_t step, void* shadow, void* stream) {
+  isdf_clear_stale_hip_error();
   NetLayout l; int rc = make_layout(net, &l);
   if (rc) return rc;
   if (!params || !exp_avg || !exp_avg_sq || !grad_sum || step < 1) return ISDF_EINVAL;

@@ -906,7 +906,7 @@ static int launch_one(const ChainParams& p, int64_t nTiles, hipStream_t st) {
   auto k = chain_kernel<HD, HD, F16, MODE>;
   if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES) != hipSuccess) return ISDF_EHIP;
   hipLaunchKernelGGL(k, dim3((unsigned)nTiles), dim3(CHAIN_NW * 64), T::LDS_BYTES, st, p);
-  return hipGetLastError() == hipSuccess ? ISDF_OK : ISDF_EHIP;
+  return isdf_launch_status();
 }
 
 template <int MODE>

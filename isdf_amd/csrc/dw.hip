@@ -188,7 +188,7 @@ int launch_dw(const DwParams& p, hipStream_t st) {
     if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES) != hipSuccess) return ISDF_EHIP;
     hipLaunchKernelGGL(k, grid, block, T::LDS_BYTES, st, p);
   }
-  return hipGetLastError() == hipSuccess ? ISDF_OK : ISDF_EHIP;
+  return isdf_launch_status();
 }
 
 }  // namespace isdf

@@ -96,7 +96,7 @@ int launch_normals(const float* depth, int H, int W, float fx, float fy, float c
                    hipStream_t st) {
   hipLaunchKernelGGL(normals_kernel, dim3((W + 31) / 32, (H + 7) / 8), dim3(256), 0, st, depth, H, W, fx, fy, cx, cy,
                      normals);
-  return hipGetLastError() == hipSuccess ? ISDF_OK : ISDF_EHIP;
+  return isdf_launch_status();
 }
 
 int launch_render_depth(const int32_t* n_valid, int64_t n_host, int64_t max_rays, int S, const float* z,
@@ -106,7 +106,7 @@ int launch_render_depth(const int32_t* n_valid, int64_t n_host, int64_t max_rays
   if (below && hipMemsetAsync(below, 0, 4, st) != hipSuccess) return ISDF_EHIP;
   hipLaunchKernelGGL(render_depth_kernel<64>, dim3((unsigned)((max_rays + 127) / 128)), dim3(128), 0, st, n_valid,
                      n_host, S, z, sdf, depth_sample, th, view, below);
-  return hipGetLastError() == hipSuccess ? ISDF_OK : ISDF_EHIP;
+  return isdf_launch_status();
 }
 
 }  // namespace isdf

@@ -69,6 +69,22 @@ struct WorkspaceLayout {
   int64_t totalBytes;
 };
 
+// ---- launch status ------------------------------------------------------------
+// hipGetLastError() is sticky per host thread: an error left behind by ANOTHER library's HIP call (torch probes
+// produce benign ones) would otherwise be reported by our next launcher.  Entry points clear it first
+// (isdf_clear_stale_hip_error), launchers report their own status (isdf_launch_status) and remember the HIP
+// code for isdf_error_string(ISDF_EHIP).
+#if defined(__HIPCC__)
+extern thread_local int g_isdf_last_hip_error;
+inline void isdf_clear_stale_hip_error() { (void)hipGetLastError(); }
+inline int isdf_launch_status() {
+  const hipError_t e = hipGetLastError();
+  if (e == hipSuccess) return ISDF_OK;
+  g_isdf_last_hip_error = (int)e;
+  return ISDF_EHIP;
+}
+#endif
+
 inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
 inline int make_layout(const isdf_net_cfg* c, NetLayout* l) {

@@ -371,12 +371,12 @@ int launch_adamw(float* p, float* m, float* v, const float* g, const float* cnt,
                  float b1, float b2, float eps, float wd, int step, int64_t n, hipStream_t st) {
   const AdamwCoef c = {lr, b1, b2, eps, wd, 1.f - powf(b1, (float)step), sqrtf(1.f - powf(b2, (float)step))};
   hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p, m, v, g, cnt, gs, c, n);
-  return hipGetLastError() == hipSuccess ? ISDF_OK : ISDF_EHIP;
+  return isdf_launch_status();
 }
 int launch_pack(const NetLayout& L, const float* params, uint16_t* shadow, hipStream_t st) {
   const int64_t groups = (L.fwdSetElems + L.bwdSetElems) / 8;
   hipLaunchKernelGGL(pack_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, st, L, params, shadow);
-  return hipGetLastError() == hipSuccess ? ISDF_OK : ISDF_EHIP;
+  return isdf_launch_status();
 }
 static FinalizeArgs finalize_args(const float* wg_loss, int64_t maxTiles, const int32_t* n_valid, int S, const float* tot_ws,
                                   const int64_t* ib, const int64_t* ih, const int64_t* iw, int F, int H, int W,
@@ -405,7 +405,7 @@ int launch_step_tail(int phase, const NetLayout& L, const float* dwPart, const f
   const dim3 grid((unsigned)(p.nW + p.nV + 1 + F));
   if (phase == 0) hipLaunchKernelGGL(step_tail_kernel<0>, grid, dim3(1024), 0, st, p);
   else hipLaunchKernelGGL(step_tail_kernel<1>, grid, dim3(1024), 0, st, p);
-  return hipGetLastError() == hipSuccess ? ISDF_OK : ISDF_EHIP;
+  return isdf_launch_status();
 }
 int launch_adamw_pack(const NetLayout& L, float* params, float* m, float* v, uint16_t* shadow, const float* grad,
                       const float* count_ptr, float grad_scale, float lr, float b1, float b2, float eps, float wd,
@@ -418,19 +418,19 @@ int launch_adamw_pack(const NetLayout& L, float* params, float* m, float* v, uin
   p.nW = (int)((total + 1023) / 1024);
   p.nV = (L.L * L.HD + L.HD + 1 + 63) / 64;
   hipLaunchKernelGGL(step_tail_kernel<2>, dim3((unsigned)(p.nW + p.nV)), dim3(1024), 0, st, p);
-  return hipGetLastError() == hipSuccess ? ISDF_OK : ISDF_EHIP;
+  return isdf_launch_status();
 }
 int launch_frame_avg(const float* bl, const float* bc, int F, float* la, float* fa, const int32_t* fa_index,
                      hipStream_t st) {
   hipLaunchKernelGGL(frame_avg_kernel, dim3(F), dim3(64), 0, st, bl, bc, F, la, fa, fa_index);
-  return hipGetLastError() == hipSuccess ? ISDF_OK : ISDF_EHIP;
+  return isdf_launch_status();
 }
 int launch_bounds_pc(const int32_t* n_valid, int max_rays, int S, const float* pc, const float* z, const float* depth,
                      const float* surf, int64_t n_surf, float* bounds, float* gv, hipStream_t st) {
   const int64_t maxPts = (int64_t)max_rays * S;
   hipLaunchKernelGGL(bounds_pc_kernel, dim3((unsigned)((maxPts + 255) / 256)), dim3(256), 0, st, n_valid, S, pc, z,
                      depth, surf, n_surf, bounds, gv);
-  return hipGetLastError() == hipSuccess ? ISDF_OK : ISDF_EHIP;
+  return isdf_launch_status();
 }
 
 }  // namespace isdf

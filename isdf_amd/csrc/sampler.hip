@@ -124,12 +124,12 @@ __global__ void sample_along_rays_kernel(const isdf_sample_args a, const isdf_sa
 
 int launch_sample_pixels(const isdf_sample_args& a, const isdf_sample_out& o, hipStream_t st) {
   hipLaunchKernelGGL(sample_pixels_kernel, dim3(1), dim3(1024), 0, st, a, o);
-  return hipGetLastError() == hipSuccess ? ISDF_OK : ISDF_EHIP;
+  return isdf_launch_status();
 }
 int launch_sample_along_rays(const isdf_sample_args& a, const isdf_sample_out& o, hipStream_t st) {
   const int64_t maxPts = (int64_t)a.n_frames * a.n_rays * (a.n_strat + a.n_surf);
   hipLaunchKernelGGL(sample_along_rays_kernel, dim3((unsigned)((maxPts + 255) / 256)), dim3(256), 0, st, a, o);
-  return hipGetLastError() == hipSuccess ? ISDF_OK : ISDF_EHIP;
+  return isdf_launch_status();
 }
 
 }  // namespace isdf
