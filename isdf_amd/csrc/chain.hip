@@ -40,7 +40,8 @@ constexpr float kBeta = 100.f;
 template <int HD, int EP>
 struct Tile {
   static constexpr int BM = TILE_PTS;
-  static constexpr int NW = CHAIN_NW;
+  static constexpr int NW = chain_nw(HD);
+  static constexpr int CKF = chain_chunk_frags(NW);   // weight fragments per chunk
   static constexpr int FB = HD / (NW * 32);   // 32-row feature blocks per wave
   static constexpr int PB = BM / 32;          // 32-point blocks
   static constexpr int R2 = (EP > HD ? EP : HD);
@@ -118,16 +119,16 @@ __device__ __forceinline__ int swz(int row, int colbytes) { return colbytes ^ ((
 // barrier keeps the load block ahead of the MFMAs, and the k-steps are fully unrolled.
 // `lateHook` (the epilogue's spill prefetch) is issued right after the last MFMA: issuing it
 // mid-GEMM overlapped more latency but pushed the train kernel 130 VGPRs over its budget.
-template <int FBN> struct WChunk { uint4 v[8 / FBN][FBN]; };   // one chunk of packed weight fragments (32 VGPRs)
+template <int FBN, int CKF> struct WChunk { uint4 v[CKF / FBN][FBN]; };   // one chunk of packed weight fragments (32 VGPRs)
 struct WRef { int soff; int rb; };   // byte offset of a wave's slice of a packed matrix in the shadow buffer + row-block stride (bytes)
 
 // request chunk 0 of a matrix (the whole 8-k-step slice up front: one L2 round trip per chunk).
 // Measured: issuing this at the END of the previous epilogue, ahead of the barrier, is 13 us SLOWER for the whole
 // kernel (and costs 32 spilled VGPRs); so is re-requesting each fragment register right after its MFMAs
 // (GEMM_ROLLING_REFILL, +4 us) and reading the activation operand two k-steps ahead (GEMM_LDS_DEPTH 2, +3 us).
-template <int FBN>
-__device__ __forceinline__ void preload_w(WChunk<FBN>& wq, rsrc_t rw, WRef r, int lane16) {
-  constexpr int CK = 8 / FBN;
+template <int FBN, int CKF>
+__device__ __forceinline__ void preload_w(WChunk<FBN, CKF>& wq, rsrc_t rw, WRef r, int lane16) {
+  constexpr int CK = CKF / FBN;
 #pragma unroll
   for (int s = 0; s < CK; ++s)
 #pragma unroll
@@ -135,10 +136,10 @@ __device__ __forceinline__ void preload_w(WChunk<FBN>& wq, rsrc_t rw, WRef r, in
       wq.v[s][fb] = bload16<0>(rw, lane16 + (s & 3) * 1024, r.soff + fb * r.rb + (s >> 2) * 4096);
 }
 
-template <bool F16, int KSTEPS, int FBN, int PBN, int ROWB, typename Hook, typename Hook2>
-__device__ __forceinline__ void gemm(f32x16 (&acc)[FBN][PBN], WChunk<FBN>& wq, rsrc_t rw, WRef wr, const char* xl,
+template <bool F16, int KSTEPS, int FBN, int PBN, int ROWB, int CKF, typename Hook, typename Hook2>
+__device__ __forceinline__ void gemm(f32x16 (&acc)[FBN][PBN], WChunk<FBN, CKF>& wq, rsrc_t rw, WRef wr, const char* xl,
                                      int colByteBase, int lane, Hook&& earlyHook, Hook2&& lateHook) {
-  constexpr int CK = 8 / FBN;                  // k-steps per chunk: CK*FBN uint4 = 32 VGPRs
+  constexpr int CK = CKF / FBN;                  // k-steps per chunk: CK*FBN uint4 = 32 VGPRs
   static_assert(KSTEPS % CK == 0, "K must be a multiple of the chunk");
   static_assert((ROWB & 1023) == 0, "row base must leave the swizzle bits clear");
   constexpr int NCH = KSTEPS / CK;
@@ -272,7 +273,7 @@ __device__ __forceinline__ float softplus_s1(float z, float& s1) {   // also sig
 __device__ __forceinline__ float s1_from_a(float a) { return 1.f - __builtin_amdgcn_exp2f(-kC1 * a); }
 
 template <int HD, int EP, bool F16, int MODE>
-__global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 ? 4 : 2)) void chain_kernel(const ChainParams p) {
+__global__ __launch_bounds__(chain_nw(HD) * 64, (HD <= 256 && chain_nw(HD) == 8 ? 4 : 2)) void chain_kernel(const ChainParams p) {
   typedef Tile<HD, EP> T;
   static_assert(HD == EP, "tile kernels assume padded embedding width == hidden width");
   constexpr int BM = T::BM, FB = T::FB, PB = T::PB, ROWB = T::ROWB;
@@ -414,7 +415,7 @@ __global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 ? 4 : 2)) void chain_kern
   auto fwdW = [&](int64_t set, int li) {   // forward-orientation matrix of layer li (K = EP | HD+EP | HD)
     return wptr(set, L.fwdMat[li], li == 0 ? EP : (li == L.cat ? HD + EP : HD));
   };
-  WChunk<FB> wq;   // the weight-fragment registers of the running gemm
+  WChunk<FB, T::CKF> wq;   // the weight-fragment registers of the running gemm
   // iterate the wave's accumulator as (fb, pb, qp) blocks of 8 values:
   // values v[0..3] -> features f0..f0+3, v[4..7] -> f0+8..f0+11, point row = pb*32+j
   auto for_blocks2 = [&](auto&& fn, auto&& tail) {
@@ -469,11 +470,11 @@ __global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 ? 4 : 2)) void chain_kern
     zero_acc(acc);
     refresh();
     if (li == 0)
-      gemm<F16, EP / 16, FB, PB, ROWB>(acc, wq, rsW, fwdW(setFwdA, li), X, HD * 2, lane, [] {}, [] {});
+      gemm<F16, EP / 16, FB, PB, ROWB, T::CKF>(acc, wq, rsW, fwdW(setFwdA, li), X, HD * 2, lane, [] {}, [] {});
     else if (li == L.cat)
-      gemm<F16, (HD + EP) / 16, FB, PB, ROWB>(acc, wq, rsW, fwdW(setFwdA, li), X, 0, lane, [] {}, [] {});
+      gemm<F16, (HD + EP) / 16, FB, PB, ROWB, T::CKF>(acc, wq, rsW, fwdW(setFwdA, li), X, 0, lane, [] {}, [] {});
     else
-      gemm<F16, HD / 16, FB, PB, ROWB>(acc, wq, rsW, fwdW(setFwdA, li), X, 0, lane, [] {}, [] {});
+      gemm<F16, HD / 16, FB, PB, ROWB, T::CKF>(acc, wq, rsW, fwdW(setFwdA, li), X, 0, lane, [] {}, [] {});
     TS();
     lds_barrier();  // all waves finished reading region 1
     TS();
@@ -546,7 +547,7 @@ __global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 ? 4 : 2)) void chain_kern
     Pre preA;
     zero_acc(acc);
     refresh();
-    gemm<F16, HD / 16, FB, PB, ROWB>(acc, wq, rsW, wptr(setBwdA, L.bwdMat[li], HD), X, 0, lane,
+    gemm<F16, HD / 16, FB, PB, ROWB, T::CKF>(acc, wq, rsW, wptr(setBwdA, L.bwdMat[li], HD), X, 0, lane,
                                      [&] { prefetch(p.sp.A[li], preA); }, [] {});
     TS();
     lds_barrier();
@@ -587,7 +588,7 @@ __global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 ? 4 : 2)) void chain_kern
     if (p.normals) { li_n[0] = p.normals[ray * 3]; li_n[1] = p.normals[ray * 3 + 1]; li_n[2] = p.normals[ray * 3 + 2]; }
   };
   refresh();
-  gemm<F16, (2 * HD) / 16, FB, PB, ROWB>(acc, wq, rsW, wptr(setBwdA, L.bwdG, 2 * HD), X, 0, lane, [] {}, loss_inputs);
+  gemm<F16, (2 * HD) / 16, FB, PB, ROWB, T::CKF>(acc, wq, rsW, wptr(setBwdA, L.bwdG, 2 * HD), X, 0, lane, [] {}, loss_inputs);
   // g_x' = J_pe^T Eg.  Eg goes through the (now idle) X tile as fp32 [BM][HD] so the contraction can run in
   // the PE stage's (point, direction-slice) mapping: 2*nf sin/cos per direction per thread and wave-uniform
   // direction constants, instead of one cos + index arithmetic per accumulator element (which took
@@ -779,11 +780,11 @@ __global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 ? 4 : 2)) void chain_kern
     zero_acc(acc);
     refresh();
     if (li == 0)
-      gemm<false, EP / 16, FB, PB, ROWB>(acc, wq, rsW, fwdW(setFwdB, li), X, HD * 2, lane, pf0, pf);
+      gemm<false, EP / 16, FB, PB, ROWB, T::CKF>(acc, wq, rsW, fwdW(setFwdB, li), X, HD * 2, lane, pf0, pf);
     else if (li == L.cat)
-      gemm<false, (HD + EP) / 16, FB, PB, ROWB>(acc, wq, rsW, fwdW(setFwdB, li), X, 0, lane, pf0, pf);
+      gemm<false, (HD + EP) / 16, FB, PB, ROWB, T::CKF>(acc, wq, rsW, fwdW(setFwdB, li), X, 0, lane, pf0, pf);
     else
-      gemm<false, HD / 16, FB, PB, ROWB>(acc, wq, rsW, fwdW(setFwdB, li), X, 0, lane, pf0, pf);
+      gemm<false, HD / 16, FB, PB, ROWB, T::CKF>(acc, wq, rsW, fwdW(setFwdB, li), X, 0, lane, pf0, pf);
   };
   for (int li = 0; li < L.L - 1; ++li) {
     Pre preA, preP;
@@ -865,7 +866,7 @@ __global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 ? 4 : 2)) void chain_kern
     auto pf = [&] { prefetch(p.sp.INJ[li], preI); };
     zero_acc(acc);
     refresh();
-    gemm<false, HD / 16, FB, PB, ROWB>(acc, wq, rsW, wptr(setBwdB, L.bwdMat[li + 1], HD), X, 0, lane, pf0, pf);
+    gemm<false, HD / 16, FB, PB, ROWB, T::CKF>(acc, wq, rsW, wptr(setBwdB, L.bwdMat[li + 1], HD), X, 0, lane, pf0, pf);
     TS();
     lds_barrier();
     TS();
@@ -905,7 +906,7 @@ static int launch_one(const ChainParams& p, int64_t nTiles, hipStream_t st) {
   typedef Tile<HD, HD> T;
   auto k = chain_kernel<HD, HD, F16, MODE>;
   if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES) != hipSuccess) return ISDF_EHIP;
-  hipLaunchKernelGGL(k, dim3((unsigned)nTiles), dim3(CHAIN_NW * 64), T::LDS_BYTES, st, p);
+  hipLaunchKernelGGL(k, dim3((unsigned)nTiles), dim3(T::NW * 64), T::LDS_BYTES, st, p);
   return isdf_launch_status();
 }
 

@@ -11,7 +11,14 @@ constexpr int MAXL = 16;       // max hidden layers (2B+2)
 constexpr int N_DIRS = 21;     // icosahedron directions, embedding.py:40-62
 constexpr int TILE_PTS = 64;   // points per chain-kernel workgroup (two workgroups per CU)
 constexpr int DW_PTS = 64;     // points per dW-kernel stage (half a chain tile)
-constexpr int CHAIN_NW = 8;    // waves per chain-kernel workgroup (each owns HD/CHAIN_NW features)
+#ifndef ISDF_CHAIN_NW
+#define ISDF_CHAIN_NW 8
+#endif
+constexpr int CHAIN_NW = ISDF_CHAIN_NW;    // waves per chain-kernel workgroup (each owns HD/CHAIN_NW features)
+// the 512-wide instantiation always runs 8 waves (one workgroup per CU)
+constexpr int chain_nw(int hd) { return hd == 256 ? CHAIN_NW : 8; }
+// weight fragments a wave requests at once: 8 (32 VGPRs) at the 128-VGPR budget of 8-wave workgroups, 16 at 4 waves
+constexpr int chain_chunk_frags(int nw) { return nw == 8 ? 8 : 16; }
 constexpr int DW_SPLITK = 36;  // K-splits per dW unit (7 units x 36 = 252 workgroups)
 
 // Vector types for the 16-bit MFMA operands.
