@@ -133,6 +133,9 @@ def main():
     ap.add_argument("--rays-per-frame", type=int, default=200)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fwd-operand", default="fp16", choices=["fp16", "bf16"])
+    ap.add_argument("--wide", action="store_true",
+                    help="BASELINE configs[4] instead of the metric's configuration: hidden 512, 3 blocks (8 hidden layers), "
+                         "n_freqs 10, 8000 rays = 216k points per GPU-step (not the reported bench line)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -167,6 +170,14 @@ def main():
 
     cfg = reference_config()
     cfg["sample"]["n_rays"] = args.rays_per_frame
+    m_mac = M_MAC
+    if args.wide:
+        cfg["model"].update(hidden_feature_size=512, hidden_layers_block=3)
+        cfg["model"]["embedding"]["n_embed_funcs"] = 9          # n_freqs 10 -> E = 423
+        if args.rays_per_frame == 200:
+            cfg["sample"]["n_rays"] = args.rays_per_frame = 1600
+        E, H = 423, 512
+        m_mac = E * H + 6 * H * H + (H + E) * H + H             # 2 268 672 MAC/point
     cam = dict(synthetic.REPLICA_CAM)
     F = cfg["model"]["window_size"]
     depth, normal, T = make_keyframes(cam, F)
@@ -258,7 +269,7 @@ def main():
             tj = json.load(f)                                     # command (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)
         traffic, traffic_src = tj["chain_kernel"]["hbm_bytes"], tj["source"]
     if rank == 0:
-        flops_chain = 8.0 * M_MAC * P      # fwd 2M + input-grad 2M + its adjoint 2M + reverse sweep 2M
+        flops_chain = 8.0 * m_mac * P      # fwd 2M + input-grad 2M + its adjoint 2M + reverse sweep 2M
         res = {
             "metric": "train-steps/sec (27k-point ray batches through Trainer.step's hot path; whole job)",
             "value": round(world * K / elapsed, 2),
@@ -270,9 +281,13 @@ def main():
             "vs_baseline": None,
             "dtype": "f16/bf16 MFMA operands, f32 accumulate" if args.fwd_operand == "fp16" else "bf16 MFMA operands, f32 accumulate",
             "data": "synthetic",
-            "config": {"workload": "replicaCAD.json defaults: 5 keyframes x %d rays x 27 samples = %d points per "
-                                   "rank-step, 680x1200 synthetic room depth, 6x256 Softplus MLP + 255-wide "
-                                   "icosahedron PE (460033 params), eik+normal loss, bounds=ray, AdamW"
+            "config": {"workload": ("replicaCAD.json defaults: 5 keyframes x %d rays x 27 samples = %d points per "
+                                    "rank-step, 680x1200 synthetic room depth, 6x256 Softplus MLP + 255-wide "
+                                    "icosahedron PE (460033 params), eik+normal loss, bounds=ray, AdamW"
+                                    if not args.wide else
+                                    "BASELINE configs[4] (wide): 5 keyframes x %d rays x 27 samples = %d points per "
+                                    "rank-step, 680x1200 synthetic room depth, 8x512 Softplus MLP + 423-wide "
+                                    "icosahedron PE (2272769 params), eik+normal loss, bounds=ray, AdamW")
                                    % (sc.n_rays, max_rays * S),
                        "global_points_per_step": int(world * max_rays * S),
                        "parallelism": "dp%d (rays sharded, one %s all-reduce of %d floats)"
@@ -290,7 +305,7 @@ def main():
                          "traffic_unit": "HBM bytes per launch (rocprofv3 --pmc, separate passes)", "traffic_source": traffic_src,
                          "hbm_GBps_at_that_traffic": None if traffic is None else round(traffic / t_chain / 1e9, 1),
                          "algorithmic_flop_per_launch": flops_chain,
-                         "whole_step_frac_of_mfma_peak": round(12.0 * M_MAC * P * K / elapsed / MFMA_PEAK, 5)},
+                         "whole_step_frac_of_mfma_peak": round(12.0 * m_mac * P * K / elapsed / MFMA_PEAK, 5)},
         }
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(depth, normal, T, cam, cfg)
