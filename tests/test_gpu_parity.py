@@ -290,6 +290,12 @@ def test_fused_adamw_step_is_bit_identical_to_two_call_path():
             a, b = states[0][k], states[1][k]
             assert torch.equal(a.view(torch.uint8), b.view(torch.uint8)), (it, k, int((a != b).sum()))
     assert engs[0].opt_step == engs[1].opt_step == 3
+    # the incrementally maintained operand copies equal a from-scratch repack of the final parameters
+    for eng in engs:
+        kept = eng.shadow.clone()
+        eng.pack()
+        torch.cuda.synchronize()
+        assert torch.equal(kept, eng.shadow)
 
 
 def test_three_full_steps_track_oracle():
