@@ -111,7 +111,9 @@ struct FinalizeArgs {
   // loss_approx [F,8,8] and frame_avg[fa_index ? fa_index[f] : f] (the keyframe store's frame_avg_losses)
   float *la_out, *fa_out; const int32_t* fa_index;
 };
-struct FinalizeLds { float sh[16][8]; float binS[64], binC[64]; int range[2]; uint32_t keys[FIN_CAP]; };
+// binS: 32.32 fixed point -- integer LDS atomics are order-independent, so the bins (hence frame_avg_losses and
+// the keyframe-selection probabilities built from them) are bit-reproducible; float atomics are not
+struct FinalizeLds { float sh[16][8]; unsigned long long binS[64]; float binC[64]; int range[2]; uint32_t keys[FIN_CAP]; };
 
 __device__ __forceinline__ void finalize_block(int block, const FinalizeArgs& a, FinalizeLds& lds) {
   const float* __restrict__ wg_loss = a.wg_loss; const int64_t maxTiles = a.maxTiles; const int S = a.S;
@@ -152,7 +154,7 @@ __device__ __forceinline__ void finalize_block(int block, const FinalizeArgs& a,
     while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (ib[mid] < key) lo = mid + 1; else hi = mid; }
     range[tid] = (int)lo;
   }
-  if (tid < 64) { binS[tid] = 0.f; binC[tid] = 0.f; }
+  if (tid < 64) { binS[tid] = 0ull; binC[tid] = 0.f; }
   __syncthreads();
   const int lo = range[0], n = range[1] - range[0];
   const bool staged = n <= FIN_CAP;
@@ -170,16 +172,17 @@ __device__ __forceinline__ void finalize_block(int block, const FinalizeArgs& a,
     const float* tp = tot_ws + (int64_t)(lo + r) * S;
     for (int k = 0; k < S; ++k) s += tp[k];               // total_loss_mat.sum(-1), loss.py:229
     const int bin = (int)((h / hb) * 8 + (w / wb));
-    atomicAdd(&binS[bin], s);
+    atomicAdd(&binS[bin], (unsigned long long)(long long)llrint((double)s * 4294967296.0));
     atomicAdd(&binC[bin], 1.f);
   }
   __syncthreads();
   if (tid < 64) {
-    block_loss[f * 64 + tid] = binS[tid]; block_cnt[f * 64 + tid] = binC[tid];
+    const float bs = (float)((double)(long long)binS[tid] * (1.0 / 4294967296.0));
+    block_loss[f * 64 + tid] = bs; block_cnt[f * 64 + tid] = binC[tid];
     if (a.la_out) {   // frame_avg_kernel's arithmetic, on the bins just built (loss.py:208-240)
       float c = binC[tid];
       c = c == 0.f ? 1.f : c;
-      float v = binS[tid] / c;
+      float v = bs / c;
       a.la_out[f * 64 + tid] = v;
 #pragma unroll
       for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
