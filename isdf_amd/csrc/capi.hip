@@ -214,6 +214,7 @@ int isdf_train_step_adamw(const isdf_net_cfg* net, const isdf_loss_cfg* loss, co
                           const isdf_step_out* o, const isdf_optim_args* opt, void* workspace,
                           int64_t workspace_bytes, void* stream) {
   if (!opt || !opt->params || !opt->exp_avg || !opt->exp_avg_sq || !opt->shadow || opt->step < 1) return ISDF_EINVAL;
+  if ((opt->loss_approx == nullptr) != (opt->frame_avg == nullptr)) return ISDF_EINVAL;   // both or neither
   return train_step_impl(net, loss, opt->params, opt->shadow, a, o, workspace, workspace_bytes, stream, opt);
 }
 

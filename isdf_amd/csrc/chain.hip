@@ -11,9 +11,9 @@
 // The weight-gradient contractions over points are done by dw.hip from the
 // bf16 operand tiles this kernel spills.
 //
-// Mapping to CDNA4: one workgroup = 4 waves = 64 points, two workgroups per CU
-// (64 KB LDS each) so one does MFMA while the other is in an elementwise
-// epilogue.  Every GEMM is C[feature][point] = W[feature][k] * X[k][point] on
+// Mapping to CDNA4: one workgroup = 8 waves = 64 points, two workgroups per CU
+// (74 KB LDS each; 128 VGPRs per wave) so one does MFMA while the other is in an
+// elementwise epilogue.  Every GEMM is C[feature][point] = W[feature][k] * X[k][point] on
 // v_mfma_f32_32x32x16_{f16,bf16}: A = packed weights streamed straight from L2
 // in fragment order (1 KB contiguous per wave-load, each weight is used by
 // exactly one wave of the workgroup so LDS staging would add nothing),
