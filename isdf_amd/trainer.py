@@ -404,9 +404,11 @@ class HipTrainer:
         if active_loss_approx is not None:
             raise Exception('Active sampling not currently supported.')
         sc = self._sample_cfg(n_rays, dist_behind_surf, n_strat_samples, n_surf_samples)
-        F = depth_batch.shape[0] if _idx is None else _idx[0].numel()
-        ar = torch.arange(F, dtype=torch.int32, device=self.device)
-        frame_idx, normal_idx = (ar, ar) if _idx is None else _idx
+        if _idx is None:
+            ar = torch.arange(depth_batch.shape[0], dtype=torch.int32, device=self.device)
+            frame_idx, normal_idx = ar, ar
+        else:
+            frame_idx, normal_idx = _idx
         s = self._sample(depth_batch.contiguous(), T_WC_batch.contiguous(),
                          None if norm_batch is None else norm_batch.contiguous(), frame_idx, normal_idx, sc)
         R = int(s["n_valid"].item()) if self.rng == "torch" else None
@@ -422,7 +424,7 @@ class HipTrainer:
         return out
 
     # ---- loss + backward (trainer.py:768-868, 981) -----------------------------------
-    def sdf_eval_and_loss(self, sample, do_avg_loss=True, fused_optim=False, frame_avg_dst=None):
+    def sdf_eval_and_loss(self, sample, do_avg_loss=True, fused_optim=False, frame_avg_dst=None, _want_total=True):
         """fused_optim: also apply the optimiser step inside the same native call (single-GPU fast path,
         isdf_train_step_adamw); the caller must then NOT call self.optimiser.step().
         frame_avg_dst = (store, index): write frame f's average loss to store[index[f]] inside the native call
@@ -453,7 +455,9 @@ class HipTrainer:
             dp.allreduce_(self.engine.reduce_buf, self.dist_group)
         ls = self.engine.loss_sums()
         losses = LazyLosses(ls, self.grad_weight != 0, self.eik_weight != 0)
-        total_loss = ls[_ffi.LS_TOTAL] / ls[_ffi.LS_COUNT]
+        # the reference returns the graph-attached mean loss; here backward is already done, so step() skips the
+        # (one tiny launch) division and callers get it through losses['total_loss'] on demand
+        total_loss = ls[_ffi.LS_TOTAL] / ls[_ffi.LS_COUNT] if _want_total else None
         loss_approx = frame_avg_loss = None
         if do_avg_loss and "loss_approx" in dbg:      # written by the fused tail, straight into frame_avg_dst
             loss_approx = dbg["loss_approx"]
@@ -496,7 +500,7 @@ class HipTrainer:
 
         fused = self.dist_group is None and getattr(self, "fuse_optimiser", True)
         dst = (self.frames.frame_avg_losses, fidx) if self.frames.frame_avg_losses.is_contiguous() else None
-        total_loss, losses, active_loss_approx, frame_avg_loss = self.sdf_eval_and_loss(sample_pts, True, fused, dst)
+        total_loss, losses, active_loss_approx, frame_avg_loss = self.sdf_eval_and_loss(sample_pts, True, fused, dst, _want_total=False)
         if dst is None:
             self.frames.frame_avg_losses[fidx.long()] = frame_avg_loss   # trainer.py:979
         if not fused:
