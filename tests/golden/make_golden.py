@@ -102,51 +102,17 @@ class DrawRecorder:
         return [g[1] for g in got]
 
 
-def synth_frames(rng, F, H, W, fx, fy, cx, cy):
-    """Small posed-depth keyframes: smooth depth 1-4 m, ~4% invalid (0), unit
-    normals with a NaN border + a few NaN pixels (as the reference's normal
-    estimator leaves them)."""
-    v, u = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
-    depth = np.empty((F, H, W), np.float32)
-    normal = np.empty((F, H, W, 3), np.float32)
-    T = np.empty((F, 4, 4), np.float32)
-    for f in range(F):
-        depth[f] = (2.5 + 1.2 * np.sin(0.11 * u + f) * np.cos(0.07 * v - 0.5 * f)
-                    + 0.3 * rng.standard_normal((H, W))).astype(np.float32)
-        depth[f][rng.uniform(size=(H, W)) < 0.04] = 0.0
-        n = rng.standard_normal((H, W, 3)).astype(np.float32)
-        n /= np.linalg.norm(n, axis=-1, keepdims=True)
-        n[:2] = np.nan; n[-2:] = np.nan; n[:, :2] = np.nan; n[:, -2:] = np.nan
-        n[rng.uniform(size=(H, W)) < 0.02] = np.nan
-        normal[f] = n
-        a = 0.3 * f
-        Rm = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]])
-        b = 0.1 * f
-        Rx = np.array([[1, 0, 0], [0, np.cos(b), -np.sin(b)], [0, np.sin(b), np.cos(b)]])
-        T[f] = np.eye(4)
-        T[f, :3, :3] = Rm @ Rx
-        T[f, :3, 3] = [0.5 * f - 1.0, 0.1 * f, 0.2 * f]
-    return depth, normal, T
-
-
-def bounds_transform(rng):
-    a, b = 0.4, -0.25
-    Rz = np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1]])
-    Ry = np.array([[np.cos(b), 0, np.sin(b)], [0, 1, 0], [-np.sin(b), 0, np.cos(b)]])
-    T = np.eye(4, dtype=np.float32)
-    T[:3, :3] = (Rz @ Ry).astype(np.float32)
-    T[:3, 3] = [0.3, -0.2, 0.1]
-    return T
+from tests.golden_util import synth_frames, synth_frames_exact, frames_checksum, bounds_transform  # noqa: E402
 
 
 def build_trainer(mods, cam, net, lossc, samplec, frames_np, params_np, transform_np,
-                  noise_std, window_size=5, incremental=True):
+                  noise_std, window_size=5, incremental=True, do_normal=True):
     trainer, sample, embedding, fc_map, loss, transform, FrameData = mods
     tr = object.__new__(trainer.Trainer)
     tr.device = "cpu"
     tr.incremental = incremental
     tr.window_size = window_size
-    tr.do_normal = True
+    tr.do_normal = do_normal
     tr.H, tr.W = cam["H"], cam["W"]
     tr.n_rays = samplec["n_rays"]
     tr.dist_behind_surf = samplec["dist_behind_surf"]
@@ -198,18 +164,26 @@ def t2n(x):
 
 
 def run_eval_case(mods, name, net, lossc, samplec, F, cam, seed, noise_std, full_grads,
-                  transform_on=True):
-    """sample_points + sdf_eval_and_loss + backward on the reference; store everything."""
+                  transform_on=True, exact_frames=False, with_normals=True, slim=False):
+    """sample_points + sdf_eval_and_loss + backward on the reference; store everything.
+    exact_frames: BASELINE-size keyframes from golden_util.synth_frames_exact -- NOT stored (65 MB at
+    680x1200x5), the tests regenerate them from the seed and verify the checksum.
+    with_normals=False: the reference's do_normal=False path (norm_batch None, needs grad_weight 0).
+    slim: store no per-point tensors (same draws as a sibling fixture; losses + gradient digests only)."""
     import oracle.isdf_oracle as orc
     rng = np.random.RandomState(seed)
-    frames_np = synth_frames(rng, F, cam["H"], cam["W"], cam["fx"], cam["fy"], cam["cx"], cam["cy"])
+    if exact_frames:
+        frames_np = synth_frames_exact(seed, F, cam["H"], cam["W"])
+    else:
+        frames_np = synth_frames(rng, F, cam["H"], cam["W"], cam["fx"], cam["fy"], cam["cx"], cam["cy"])
     params_np = orc.init_params(net["H"], net["B"], net["n_freqs"], np.random.RandomState(seed + 100))
     Tb = bounds_transform(rng) if transform_on else None
-    tr = build_trainer(mods, cam, net, lossc, samplec, frames_np, params_np, Tb, noise_std)
+    tr = build_trainer(mods, cam, net, lossc, samplec, frames_np, params_np, Tb, noise_std,
+                       do_normal=with_normals)
     torch.manual_seed(seed)
     with DrawRecorder() as rec:
         sp = tr.sample_points(tr.frames.depth_batch, tr.frames.T_WC_batch,
-                              norm_batch=tr.frames.normal_batch)
+                              norm_batch=tr.frames.normal_batch if with_normals else None)
         pc_in = sp["pc"].clone()
         total, losses, loss_approx, frame_avg_loss = tr.sdf_eval_and_loss(sp, do_avg_loss=True)
         ih, iw, U, N_off, noise = rec.pop_step(with_noise=True)
@@ -222,8 +196,13 @@ def run_eval_case(mods, name, net, lossc, samplec, F, cam, seed, noise_std, full
     sdf_grad = mods_fc.gradient(pc, raw_sdf).detach()
     total.backward()
     grads = {k: t2n(p.grad) for k, p in tr.sdf_map.named_parameters()}
+    if exact_frames:
+        frames_kw = dict(frames_gen=np.array([F, seed], np.int64),
+                         frames_sum=np.array(frames_checksum(*frames_np), np.int64))
+    else:
+        frames_kw = dict(depth_batch=frames_np[0], normal_batch=frames_np[1], T_WC_batch=frames_np[2])
     out = dict(
-        depth_batch=frames_np[0], normal_batch=frames_np[1], T_WC_batch=frames_np[2],
+        with_normals=np.array([int(with_normals)]),
         cam=np.array([cam["H"], cam["W"], cam["fx"], cam["fy"], cam["cx"], cam["cy"]], np.float64),
         net=np.array([net["H"], net["B"], net["n_freqs"], net["scale_input"], net["scale_output"]], np.float64),
         seed=np.array([seed]), noise_std=np.array([noise_std], np.float64),
@@ -242,6 +221,14 @@ def run_eval_case(mods, name, net, lossc, samplec, F, cam, seed, noise_std, full
         eikonal_loss=np.array([losses.get("eikonal_loss", np.nan)]),
         loss_approx=t2n(loss_approx), frame_avg_loss=t2n(frame_avg_loss),
     )
+    if not with_normals:
+        out.pop("norm_sample")
+    if slim:
+        for k in ("pc", "z_vals", "dirs_C_sample", "T_WC_sample", "norm_sample", "sdf_nonoise", "sdf_grad"):
+            out.pop(k, None)
+    elif exact_frames:
+        out.pop("T_WC_sample")          # = T_WC_batch[indices_b]; 64 B/ray of redundancy
+    out.update(frames_kw)
     for k, v in lossc.items():
         out["loss_" + k] = np.array([v]) if not isinstance(v, str) else np.array(v)
     for k, v in samplec.items():
@@ -264,8 +251,18 @@ def run_eval_case(mods, name, net, lossc, samplec, F, cam, seed, noise_std, full
           {k: round(float(v), 6) if not torch.is_tensor(v) else float(v) for k, v in losses.items()})
 
 
-def run_step_case(mods, name, net, lossc, samplec, K, cam, seed, noise_std, n_steps, window_size):
-    """Unmodified Trainer.step (incl. select_keyframes when K > window) for n_steps."""
+def _digest(out, prefix, k, v, prng):
+    v64 = v.astype(np.float64)
+    probe = prng.standard_normal(v.shape)
+    out[prefix + "dig/" + k] = np.array([np.linalg.norm(v64), float((v64 * probe).sum())])
+    out[prefix + "head/" + k] = v.reshape(-1)[:64].copy()
+
+
+def run_step_case(mods, name, net, lossc, samplec, K, cam, seed, noise_std, n_steps, window_size,
+                  digest=False):
+    """Unmodified Trainer.step (incl. select_keyframes when K > window) for n_steps.
+    digest: default-size net -- the initial weights regenerate from the seed and the final parameters /
+    AdamW moments are stored as (norm, probe dot, first 64 values) per tensor instead of in full."""
     import oracle.isdf_oracle as orc
     rng = np.random.RandomState(seed)
     frames_np = synth_frames(rng, K, cam["H"], cam["W"], cam["fx"], cam["fy"], cam["cx"], cam["cy"])
@@ -289,8 +286,9 @@ def run_step_case(mods, name, net, lossc, samplec, K, cam, seed, noise_std, n_st
         out["loss_" + k] = np.array([v]) if not isinstance(v, str) else np.array(v)
     for k, v in samplec.items():
         out["sample_" + k] = np.array([v], np.float64)
-    for k, v in params_np.items():
-        out["param/" + k] = v
+    if not digest:
+        for k, v in params_np.items():
+            out["param/" + k] = v
     with DrawRecorder() as rec:
         for s in range(n_steps):
             losses, _ = tr.step()
@@ -307,13 +305,20 @@ def run_step_case(mods, name, net, lossc, samplec, K, cam, seed, noise_std, n_st
             out["s%d/eikonal_loss" % s] = np.array([losses["eikonal_loss"]])
             out["s%d/frame_avg_losses" % s] = t2n(tr.frames.frame_avg_losses)
             print(name, "step", s, "idxs", list(tr.active_idxs), "total", float(losses["total_loss"]))
-    for k, p in tr.sdf_map.named_parameters():
-        out["param_after/" + k] = t2n(p)
     st = tr.optimiser.state_dict()["state"]
     names = [k for k, _ in tr.sdf_map.named_parameters()]
-    for i, k in enumerate(names):
-        out["exp_avg/" + k] = t2n(st[i]["exp_avg"])
-        out["exp_avg_sq/" + k] = t2n(st[i]["exp_avg_sq"])
+    if digest:
+        prng = np.random.RandomState(4321)
+        for i, (k, p) in enumerate(tr.sdf_map.named_parameters()):
+            _digest(out, "param_after_", k, t2n(p) - params_np[k], prng)     # the UPDATE, not the weights
+            _digest(out, "exp_avg_", k, t2n(st[i]["exp_avg"]), prng)
+            _digest(out, "exp_avg_sq_", k, t2n(st[i]["exp_avg_sq"]), prng)
+    else:
+        for k, p in tr.sdf_map.named_parameters():
+            out["param_after/" + k] = t2n(p)
+        for i, k in enumerate(names):
+            out["exp_avg/" + k] = t2n(st[i]["exp_avg"])
+            out["exp_avg_sq/" + k] = t2n(st[i]["exp_avg_sq"])
     path = os.path.join(HERE, name + ".npz")
     np.savez_compressed(path, **out)
     print("wrote", path)
@@ -352,6 +357,39 @@ def main():
     if only == "ingest":
         run_ingest_case(mods, "ingest_small", 31)
         return
+    full = dict(H=256, B=2, n_freqs=6, scale_input=0.05937489, scale_output=0.14)
+    cam_replica = dict(H=680, W=1200, fx=600.0, fy=600.0, cx=599.5, cy=339.5)      # replicaCAD.json:10-17
+    cam_scannet = dict(H=480, W=640, fx=577.87, fy=577.87, cx=319.5, cy=239.5)
+    base_sample = dict(SAMPLE_DEFAULT, n_rays=200)                                  # replicaCAD.json:41-44
+    cam_s = dict(H=48, W=64, fx=60.0, fy=60.0, cx=31.5, cy=23.5)
+    small = dict(H=64, B=1, n_freqs=6, scale_input=0.05937489, scale_output=0.14)
+    round2 = {
+        # BASELINE.json configs[1]: 5 keyframes x 200 rays x 27 samples, 680x1200, default net, bounds "ray" ...
+        "eval_base_680x1200_ray": lambda: run_eval_case(mods, "eval_base_680x1200_ray", full, LOSS_DEFAULT, base_sample,
+                                                        5, cam_replica, 41, 0.25, False, exact_frames=True),
+        # ... and "pc" (the supervision of the shipped results), same seed => same draws: losses + digests only
+        "eval_base_680x1200_pc": lambda: run_eval_case(mods, "eval_base_680x1200_pc", full,
+                                                       dict(LOSS_DEFAULT, bounds_method="pc"), base_sample, 5,
+                                                       cam_replica, 41, 0.25, False, exact_frames=True, slim=True),
+        # BASELINE.json configs[2] geometry: 480x640 (ScanNet-like intrinsics), same net
+        "eval_base_480x640_ray": lambda: run_eval_case(mods, "eval_base_480x640_ray", full, LOSS_DEFAULT, base_sample,
+                                                       5, cam_scannet, 42, 0.08, False, exact_frames=True),
+        # default-size net through the unmodified Trainer.step x3, K=7 > window (select_keyframes, quirk q4)
+        "step_full_k7": lambda: run_step_case(mods, "step_full_k7", full, LOSS_DEFAULT, dict(SAMPLE_DEFAULT, n_rays=30),
+                                              7, cam_s, 23, 0.08, 3, 5, digest=True),
+        # oracle pins for configurations the GPU tests exercise: orien_loss, eikonal-only without normals
+        "eval_small_orien": lambda: run_eval_case(mods, "eval_small_orien", small, dict(LOSS_DEFAULT, orien_loss=True),
+                                                  SAMPLE_DEFAULT, 3, cam_s, 15, 0.08, True),
+        "eval_small_eikonly": lambda: run_eval_case(mods, "eval_small_eikonly", small, dict(LOSS_DEFAULT, grad_weight=0.0),
+                                                    SAMPLE_DEFAULT, 3, cam_s, 16, 0.08, True, with_normals=False),
+    }
+    if only == "round2":
+        for fn in round2.values():
+            fn()
+        return
+    if only in round2:
+        round2[only]()
+        return
     cam_s = dict(H=48, W=64, fx=60.0, fy=60.0, cx=31.5, cy=23.5)
     small = dict(H=64, B=1, n_freqs=6, scale_input=0.05937489, scale_output=0.14)
     full = dict(H=256, B=2, n_freqs=6, scale_input=0.05937489, scale_output=0.14)
@@ -375,6 +413,9 @@ def main():
                   cam_s, 22, 0.04, 2, 5)
     # 7. next tier: per-frame normal estimation, keyframe depth render
     run_ingest_case(mods, "ingest_small", 31)
+    # 8. round 2: BASELINE-size fixtures, default-net Trainer.step, extra oracle pins
+    for fn in round2.values():
+        fn()
 
 
 if __name__ == "__main__":

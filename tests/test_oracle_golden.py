@@ -8,7 +8,10 @@ import pytest
 import oracle.isdf_oracle as orc
 from tests import golden_util as gu
 
-EVAL_CASES = ["eval_small_ray", "eval_small_pc_l2", "eval_small_nograd", "eval_full_ray"]
+EVAL_CASES = ["eval_small_ray", "eval_small_pc_l2", "eval_small_nograd", "eval_full_ray",
+              # round 2: orien_loss, eikonal-only without normals (do_normal False), and BASELINE.json's own
+              # configurations: 5 x 200 rays x 27 samples, default net, 680x1200 and 480x640
+              "eval_small_orien", "eval_small_eikonly", "eval_base_680x1200_ray", "eval_base_480x640_ray"]
 
 
 def _sample(g):
@@ -17,7 +20,8 @@ def _sample(g):
     dirs_C = orc.ray_dirs_C(cam["H"], cam["W"], cam["fx"], cam["fy"], cam["cx"], cam["cy"])
     ib = orc.sample_pixels_indices_b(sc["n_rays"], F)
     bd = orc.get_batch_data(g["depth_batch"], g["T_WC_batch"], dirs_C, ib,
-                            g["draw_indices_h"], g["draw_indices_w"], g["normal_batch"])
+                            g["draw_indices_h"], g["draw_indices_w"],
+                            g["normal_batch"] if gu.with_normals(g) else None)
     max_depth = bd["depth_sample"] + np.float32(sc["dist_behind_surf"])
     pc, z = orc.sample_along_rays(bd["T_WC_sample"], sc["min_depth"], max_depth, sc["n_strat"],
                                   sc["n_surf"], bd["dirs_C_sample"], bd["depth_sample"],
@@ -33,7 +37,10 @@ def test_sampler_matches_reference(case):
     for k in ["indices_b", "indices_h", "indices_w"]:
         assert np.array_equal(bd[k], g[k]), k
     assert np.array_equal(bd["depth_sample"], g["depth_sample"])
-    assert np.array_equal(bd["norm_sample"], g["norm_sample"])
+    if gu.with_normals(g):
+        assert np.array_equal(bd["norm_sample"], g["norm_sample"])
+    else:
+        assert bd["norm_sample"] is None
     assert np.array_equal(bd["T_WC_sample"], g["T_WC_sample"])
     np.testing.assert_allclose(bd["dirs_C_sample"], g["dirs_C_sample"], rtol=0, atol=1e-7)
     np.testing.assert_allclose(z, g["z_vals"], rtol=0, atol=2e-6)
@@ -61,7 +68,7 @@ def test_losses_and_param_grads(case):
     cfg, lc, params = gu.net_of(g), gu.loss_of(g), gu.params_of(g)
     noise = g["draw_noise"].reshape(g["z_vals"].shape) * np.float32(g["noise_std"][0])
     terms, grads = orc.loss_and_grads(params, cfg, lc, g["pc"], g["z_vals"], g["depth_sample"],
-                                      g["dirs_C_sample"], g["T_WC_sample"], g["norm_sample"],
+                                      g["dirs_C_sample"], g["T_WC_sample"], g.get("norm_sample"),
                                       noise=noise)
     assert abs(terms["total_loss"] - g["total_loss"][0]) < 2e-5 * abs(g["total_loss"][0])
     assert abs(terms["sdf_loss"] - g["sdf_loss"][0]) < 2e-5 * abs(g["sdf_loss"][0])
@@ -131,6 +138,78 @@ def test_full_steps_match_reference_trainer_step(case):
     for k in params:
         assert gu.rel_err(params[k], g["param_after/" + k]) < 2e-4, k
         assert gu.rel_err(state["exp_avg"][k], g["exp_avg/" + k]) < 2e-3, k
+
+
+def test_full_size_pc_variant_matches_reference():
+    """BASELINE-size batch with bounds_method "pc" (the supervision of the shipped results, loss.py:56-89):
+    the slim fixture shares seed and draws with eval_base_680x1200_ray; losses and gradient digests."""
+    g, gp = gu.load("eval_base_680x1200_ray"), gu.load("eval_base_680x1200_pc")
+    for k in ("draw_indices_h", "draw_indices_w", "draw_U", "draw_N_off", "draw_noise", "indices_h", "depth_sample"):
+        assert np.array_equal(g[k], gp[k]), k
+    cfg, lc, params = gu.net_of(gp), gu.loss_of(gp), gu.params_of(gp)
+    assert lc.bounds_method == "pc"
+    noise = g["draw_noise"].reshape(g["z_vals"].shape) * np.float32(gp["noise_std"][0])
+    terms, grads = orc.loss_and_grads(params, cfg, lc, g["pc"], g["z_vals"], g["depth_sample"],
+                                      g["dirs_C_sample"], g["T_WC_sample"], g["norm_sample"], noise=noise)
+    for k in ("total_loss", "sdf_loss", "grad_loss", "eikonal_loss"):
+        assert abs(terms[k] - gp[k][0]) < 5e-5 * abs(gp[k][0]), (k, terms[k], gp[k][0])
+    cam = gu.cam_of(gp)
+    la, fa = orc.frame_avg(terms["tot_loss_mat"], g["indices_b"], g["indices_h"], g["indices_w"], 5, cam["H"], cam["W"])
+    np.testing.assert_allclose(fa, gp["frame_avg_loss"], rtol=2e-4, atol=1e-6)
+    prng = np.random.RandomState(1234)
+    for k in params:
+        probe = prng.standard_normal(grads[k].shape)
+        nrm, dot = gp["gdig/" + k]
+        v = grads[k].astype(np.float64)
+        assert abs(np.linalg.norm(v) - nrm) < 3e-4 * nrm, k
+        assert abs((v * probe).sum() - dot) < 3e-4 * nrm * np.sqrt(v.size), k
+
+
+def replay_step_fixture(g, step_fn):
+    """Feed the recorded windows / draws of a `step_*` fixture to step_fn(s, idxs, frames, draws) -> dict with the
+    loss terms and frame_avg_loss; checks losses and frame_avg_losses against the reference after every step."""
+    fal = g["frame_avg_losses0"].copy()
+    for s in range(int(g["n_steps"][0])):
+        idxs = g["s%d/idxs" % s]
+        frames = dict(depth_batch=g["depth_batch"][idxs], T_WC_batch=g["T_WC_batch"][idxs],
+                      normal_batch=g["normal_batch"])  # quirk q4: normals NOT windowed
+        noise = g["s%d/draw_noise" % s] * np.float32(g["noise_std"][0])
+        draws = dict(indices_h=g["s%d/draw_indices_h" % s], indices_w=g["s%d/draw_indices_w" % s],
+                     U=g["s%d/draw_U" % s], N_off=g["s%d/draw_N_off" % s], noise=noise)
+        out = step_fn(s, idxs, frames, draws)
+        fal[idxs] = out["frame_avg_loss"]
+        for k in ["total_loss", "sdf_loss", "grad_loss", "eikonal_loss"]:
+            ref = g["s%d/%s" % (s, k)][0]
+            assert abs(out[k] - ref) < out.get("tol", 1e-4) * abs(ref), (s, k, out[k], ref)
+        np.testing.assert_allclose(fal, g["s%d/frame_avg_losses" % s], rtol=out.get("fa_rtol", 5e-4), atol=1e-6)
+
+
+def check_step_digests(g, params, init, exp_avg, exp_avg_sq, tol_p, tol_m, tol_v):
+    """final parameter UPDATE and AdamW moments vs the (norm, probe dot, first 64 values) digests of the reference"""
+    prng = np.random.RandomState(4321)
+    for k in params:
+        for prefix, v, tol in (("param_after_", np.asarray(params[k], np.float64) - init[k], tol_p),
+                               ("exp_avg_", exp_avg[k], tol_m), ("exp_avg_sq_", exp_avg_sq[k], tol_v)):
+            v = np.asarray(v, np.float64)
+            probe = prng.standard_normal(v.shape)
+            nrm, dot = g[prefix + "dig/" + k]
+            assert abs(np.linalg.norm(v) - nrm) < tol * nrm, (prefix, k, np.linalg.norm(v), nrm)
+            assert abs((v * probe).sum() - dot) < tol * nrm * np.sqrt(v.size), (prefix, k)
+            head = g[prefix + "head/" + k]
+            assert np.abs(v.reshape(-1)[:64] - head).max() < 4 * tol * max(np.abs(head).max(), nrm / np.sqrt(v.size)), (prefix, k)
+
+
+def test_default_net_trainer_step_x3_matches_reference():
+    """`step_full_k7`: the unmodified reference Trainer.step x3 with the DEFAULT 6x256 net, K=7 > window 5
+    (select_keyframes, quirk q4): losses, frame averages, and digests of the parameter update and both AdamW
+    moments.  This is the fixture the GPU test `test_hip_step_x3_default_net_vs_reference_fixture` runs on."""
+    g = gu.load("step_full_k7")
+    cfg, lc, params = gu.net_of(g), gu.loss_of(g), gu.params_of(g)
+    init = {k: v.astype(np.float64) for k, v in params.items()}
+    cam, sc = gu.cam_of(g), gu.sample_of(g)
+    state = orc.new_adam_state()
+    replay_step_fixture(g, lambda s, idxs, frames, draws: orc.train_step(params, state, cfg, lc, frames, cam, sc, draws))
+    check_step_digests(g, params, init, state["exp_avg"], state["exp_avg_sq"], 5e-4, 2e-3, 4e-3)
 
 
 def test_select_keyframes_numpy_rng():
