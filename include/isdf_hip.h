@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define ISDF_ABI_VERSION 2
+#define ISDF_ABI_VERSION 3
 
 enum {
   ISDF_OK = 0,
@@ -60,6 +60,10 @@ typedef struct isdf_net_cfg {
 
 int isdf_abi_version(void);
 const char* isdf_error_string(int code);
+
+/* ISDF_OK if the tile kernels are instantiated for this network shape, ISDF_EUNSUPPORTED otherwise (call it when
+ * the network is built -- trainer.py:419-439 -- rather than at the first step) */
+int isdf_check_net(const isdf_net_cfg* net);
 
 /* number of fp32 parameters (460033 for the default net) */
 int64_t isdf_param_count(const isdf_net_cfg* net);
@@ -154,7 +158,9 @@ typedef struct isdf_step_args {
   const int32_t* n_valid;     /* [1] device: R (from the sampler)              */
   int32_t max_rays;           /* capacity of the per-ray arrays (F*n_rays)     */
   int32_t S;                  /* samples per ray                               */
-  int32_t n_frames, H, W;     /* for the 8x8 block-loss bins (loss.py:208-240) */
+  int32_t n_frames, H, W;     /* for the 8x8 block-loss bins (loss.py:208-240);
+                                 H and W must be multiples of 8 (ISDF_EINVAL otherwise, as
+                                 the reference's .view raises)                    */
   const float* pc;            /* [max_rays,S,3]                                */
   const float* z_vals;        /* [max_rays,S]                                  */
   const float* depth_sample;  /* [max_rays]                                    */

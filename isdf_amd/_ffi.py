@@ -10,11 +10,11 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libisdf_hip.so")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 # every symbol include/isdf_hip.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
-    "isdf_abi_version", "isdf_error_string", "isdf_param_count", "isdf_shadow_bytes",
+    "isdf_abi_version", "isdf_error_string", "isdf_check_net", "isdf_param_count", "isdf_shadow_bytes",
     "isdf_workspace_bytes", "isdf_reduce_floats", "isdf_pack_weights", "isdf_sample_pixels",
     "isdf_sample_along_rays", "isdf_sdf_eval", "isdf_train_step", "isdf_train_step_adamw", "isdf_bounds_pc",
     "isdf_frame_avg", "isdf_adamw", "isdf_estimate_normals", "isdf_render_depth",
@@ -99,6 +99,8 @@ def lib():
     L.isdf_abi_version.restype = C.c_int
     L.isdf_error_string.restype = C.c_char_p
     L.isdf_error_string.argtypes = [C.c_int]
+    L.isdf_check_net.restype = C.c_int
+    L.isdf_check_net.argtypes = [P(NetCfg)]
     for n in ("isdf_param_count", "isdf_shadow_bytes"):
         getattr(L, n).restype = i64
         getattr(L, n).argtypes = [P(NetCfg)]
@@ -117,7 +119,7 @@ def lib():
     L.isdf_adamw.argtypes = [P(NetCfg), vp, vp, vp, vp, vp, f32, f32, f32, f32, f32, f32, i32, vp, vp]
     L.isdf_estimate_normals.argtypes = [vp, i32, i32, f32, f32, f32, f32, vp, vp]
     L.isdf_render_depth.argtypes = [vp, i64, i64, i32, vp, vp, vp, f32, vp, vp, vp]
-    for n in SYMBOLS[6:]:
+    for n in SYMBOLS[7:]:
         getattr(L, n).restype = C.c_int
     if L.isdf_abi_version() != ABI_VERSION:
         raise IsdfError("libisdf_hip.so ABI %d != binding ABI %d" % (L.isdf_abi_version(), ABI_VERSION))

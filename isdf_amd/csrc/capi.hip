@@ -46,7 +46,7 @@ const char* isdf_error_string(int code) {
   switch (code) {
     case ISDF_OK: return "ok";
     case ISDF_EINVAL: return "invalid argument";
-    case ISDF_EUNSUPPORTED: return "unsupported configuration (kernels are built for hidden 256 with n_freqs<=6 and hidden 512 with 7<=n_freqs<=12)";
+    case ISDF_EUNSUPPORTED: return "unsupported configuration (the tile kernels are built for hidden_feature_size 256 or 512, n_freqs = n_embed_funcs+1 in 1..12, any hidden_layers_block up to 7; bounds_method ray|pc)";
     case ISDF_EWORKSPACE: return "workspace too small";
     case ISDF_EHIP: {
       static thread_local char buf[160];
@@ -55,6 +55,12 @@ const char* isdf_error_string(int code) {
     }
   }
   return "unknown error";
+}
+
+int isdf_check_net(const isdf_net_cfg* net) {
+  NetLayout l; int rc = make_layout(net, &l);
+  if (rc) return rc;
+  return layout_supported(l) ? ISDF_OK : ISDF_EUNSUPPORTED;
 }
 
 int64_t isdf_param_count(const isdf_net_cfg* net) {
@@ -142,6 +148,8 @@ static int train_step_impl(const isdf_net_cfg* net, const isdf_loss_cfg* loss, c
       !a->indices_h || !a->indices_w || !a->n_valid)
     return ISDF_EINVAL;
   if (a->max_rays < 1 || a->S < 1 || a->n_frames < 1 || a->H < 8 || a->W < 8) return ISDF_EINVAL;
+  // the 8x8 block bins tile the image exactly (the reference's .view(-1, 8, H/8, 8, W/8) raises otherwise, loss.py:208-219)
+  if (a->H % 8 != 0 || a->W % 8 != 0 || a->H >= 65536 || a->W >= 65536) return ISDF_EINVAL;
   if (loss->bounds_method != 0 && loss->bounds_method != 1) return ISDF_EUNSUPPORTED;  // "normal" is broken upstream (loss.py:29)
   if (loss->bounds_method == 1 && (!a->pc_bounds || !a->pc_grad_vec)) return ISDF_EINVAL;
   if (loss->loss_type != 0 && loss->loss_type != 1) return ISDF_EINVAL;

@@ -73,3 +73,30 @@ def gather_surface_points(pc, n_valid, group=None):
     out = torch.empty(world * R0, 3, dtype=surf.dtype, device=surf.device)
     torch.distributed.all_gather_into_tensor(out, surf, group=group)
     return out
+
+
+def src_rank(group=None):
+    """global rank of the group's rank 0 (the broadcast source)"""
+    if group is None or group is torch.distributed.group.WORLD:
+        return 0
+    return torch.distributed.get_global_rank(group, 0)
+
+
+def broadcast_ints(values, group, device):
+    """rank 0's integer list on every rank (window indices of `select_keyframes`, trainer.py:652-674)"""
+    t = torch.as_tensor([int(v) for v in values], dtype=torch.int64, device=device)
+    torch.distributed.broadcast(t, src_rank(group), group=group)
+    return [int(v) for v in t.cpu()]
+
+
+def broadcast_floats(values, group, device):
+    t = torch.as_tensor([float(v) for v in values], dtype=torch.float64, device=device)
+    torch.distributed.broadcast(t, src_rank(group), group=group)
+    return [float(v) for v in t.cpu()]
+
+
+def max_over_ranks(value, group, device):
+    """the step time every rank adds to its virtual clock (trainer.py:1011-1013): the slowest rank's"""
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX, group=group)
+    return float(t.item())

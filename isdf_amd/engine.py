@@ -122,6 +122,9 @@ class Engine:
         if self.device.type != "cuda":
             raise _ffi.IsdfError("isdf_amd kernels need a HIP device (got %s); there is no CPU path" % device)
         self.cnet = net.to_c()
+        # fail where the network is built (trainer.py:419-439), not at the first step
+        _ffi.check(self.lib.isdf_check_net(C.byref(self.cnet)),
+                   "isdf_check_net(hidden=%d, blocks=%d, n_freqs=%d)" % (net.hidden, net.blocks, net.n_freqs))
         n = self.lib.isdf_param_count(C.byref(self.cnet))
         _ffi.check(min(n, 0), "isdf_param_count")
         self.n_params = int(n)

@@ -1,0 +1,534 @@
+"""The drop-in boundary on the Python side: `graft(trainer)` re-binds the three hot-path methods of a
+reference `isdf.modules.trainer.Trainer` INSTANCE to the HIP kernels behind the C ABI
+(include/isdf_hip.h), in place:
+
+    Trainer.step                trainer.py:951-1016
+    Trainer.sample_points       trainer.py:683-766
+    Trainer.sdf_eval_and_loss   trainer.py:768-868   (+ total_loss.backward(), trainer.py:981)
+    Trainer.is_keyframe         trainer.py:586-620   (fused sampler -> frozen net -> depth render)
+
+ONE object owns the state: every attribute the reference's drivers and its own remaining methods read or
+write -- `tot_step_time`, `steps_since_frame`, `optim_frames`, `last_is_keyframe`, `noise_std`, `frames`,
+`active_idxs`, `active_pixels`, `frozen_sdf_map`, `sdf_map`, `optimiser` (train.py:102-136,
+trainer.py:574-650,1011-1014) -- stays on the `Trainer` instance; the methods here only use `self.<name>`
+with the reference's names.  `trainer.sdf_map` becomes an `SDFMapHIP` (a real nn.Module with the
+reference's state_dict keys whose parameters are views of one flat buffer), `trainer.optimiser` a facade
+with the `torch.optim.AdamW` surface.  Everything else (`get_data`, `add_frame`,
+`check_keyframe_latest`, `select_keyframes`, evaluation, visualisation) keeps running as the
+reference's own code on the same object.
+
+Where the reference is not importable (the GPU box, bench.py), `isdf_amd.standin.StandinTrainer` provides
+the driver-side methods and `isdf_amd.trainer.HipTrainer` is `graft()` applied to it -- the same code path.
+
+There is no CPU fallback: without the HIP library or a HIP device `graft` raises.
+"""
+import copy
+import types
+
+import numpy as np
+import torch
+
+from . import _ffi, dp
+from .engine import LossConfig, SampleConfig
+from .modules import PositionalEncodingHIP, SDFMapHIP
+
+
+class FlatAdamW:
+    """Facade with the `torch.optim.AdamW` surface the drivers touch
+    (`state_dict()`, `param_groups`, `step()`; trainer.py:435-439, train.py:213);
+    the update itself is the fused flat HIP kernel."""
+
+    def __init__(self, sdf_map, lr, weight_decay, betas=(0.9, 0.999), eps=1e-8):
+        self.sdf_map = sdf_map
+        self.param_groups = [dict(params=list(sdf_map.parameters()), lr=lr, betas=betas, eps=eps,
+                                  weight_decay=weight_decay, amsgrad=False)]
+
+    def step(self):
+        g = self.param_groups[0]
+        self.sdf_map.engine.adamw(lr=g["lr"], weight_decay=g["weight_decay"], betas=g["betas"], eps=g["eps"])
+
+    def zero_grad(self, set_to_none=True):
+        pass   # gradients never live on the parameters (they are sums in the engine's reduce buffer)
+
+    def state_dict(self):
+        eng = self.sdf_map.engine
+        state = {}
+        if eng.opt_step > 0:
+            for i, (k, (off, shp)) in enumerate(eng.slices.items()):
+                n = int(np.prod(shp))
+                state[i] = dict(step=torch.tensor(float(eng.opt_step)),
+                                exp_avg=eng.exp_avg[off:off + n].view(*shp).clone(),
+                                exp_avg_sq=eng.exp_avg_sq[off:off + n].view(*shp).clone())
+        g = dict(self.param_groups[0])
+        g["params"] = list(range(len(eng.slices)))
+        return dict(state=state, param_groups=[g])
+
+    def load_state_dict(self, sd):
+        eng = self.sdf_map.engine
+        if not sd["state"]:          # a checkpoint taken before the first step: fresh moments
+            eng.exp_avg.zero_(); eng.exp_avg_sq.zero_(); eng.opt_step = 0
+        for i, (k, (off, shp)) in enumerate(eng.slices.items()):
+            if i in sd["state"]:
+                n = int(np.prod(shp))
+                eng.exp_avg[off:off + n].copy_(sd["state"][i]["exp_avg"].reshape(-1))
+                eng.exp_avg_sq[off:off + n].copy_(sd["state"][i]["exp_avg_sq"].reshape(-1))
+                eng.opt_step = int(float(sd["state"][i]["step"]))
+        for k in ("lr", "weight_decay", "betas", "eps"):
+            if sd.get("param_groups") and k in sd["param_groups"][0]:
+                self.param_groups[0][k] = sd["param_groups"][0][k]
+
+
+class StepLosses(dict):
+    """`losses` of `Trainer.step`: keys sdf_loss / grad_loss / eikonal_loss (floats) and total_loss (0-d tensor;
+    callers use '{:.6f}'.format and .item(), train.py:138,215).  Built from ONE 8-float device->host copy that
+    rides on the step's closing synchronisation instead of the reference's three `.item()` syncs
+    (loss.py:187-200); the values are snapshotted at construction, so a later step cannot change them."""
+
+    def __init__(self, loss_sums_host, has_grad, has_eik):
+        ls = [float(v) for v in loss_sums_host]
+        n = max(ls[_ffi.LS_COUNT], 1.0)
+        super().__init__()
+        self["sdf_loss"] = ls[_ffi.LS_SDF] / n
+        if has_grad:
+            self["grad_loss"] = ls[_ffi.LS_GRAD] / n
+        if has_eik:
+            self["eikonal_loss"] = ls[_ffi.LS_EIK] / n
+        self["total_loss"] = torch.tensor(ls[_ffi.LS_TOTAL] / n)
+
+
+class _LazyCut(dict):
+    """`self.active_pixels` (trainer.py:970-974, read by keyframe_vis :1162-1175): the sampler's index tensors
+    cut to the valid-ray count on first access, so `step()` itself never waits for the count."""
+
+    def __init__(self, raw):
+        super().__init__()
+        self._raw = raw
+
+    def _fill(self):
+        if self._raw is not None:
+            R = int(self._raw["n_valid"].item())
+            for k in ("indices_b", "indices_h", "indices_w"):
+                dict.__setitem__(self, k, self._raw[k][:R])
+            self._raw = None
+
+    def __getitem__(self, k):
+        self._fill(); return dict.__getitem__(self, k)
+
+    def keys(self):
+        self._fill(); return dict.keys(self)
+
+    def items(self):
+        self._fill(); return dict.items(self)
+
+    def values(self):
+        self._fill(); return dict.values(self)
+
+    def __iter__(self):
+        self._fill(); return dict.__iter__(self)
+
+    def __len__(self):
+        return 3
+
+    def __contains__(self, k):
+        return k in ("indices_b", "indices_h", "indices_w")
+
+
+class _BackwardDone(torch.autograd.Function):
+    """`total_loss` of `sdf_eval_and_loss`: the reference returns a graph-attached scalar and the caller runs
+    `total_loss.backward(); self.optimiser.step()` (trainer.py:981-982).  Here the backward pass has already
+    run inside the native call (gradient sums sit in the engine's reduce buffer), so `.backward()` is a no-op
+    and the same two caller lines keep working."""
+
+    @staticmethod
+    def forward(ctx, value, anchor):
+        return value.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        return None, None
+
+
+class HotPath:
+    """Mix-in holding the replaced methods.  `self` is the Trainer (reference or stand-in)."""
+
+    # ------------------------------------------------------------------ helpers
+    def _loss_cfg(self):
+        return LossConfig(self.bounds_method, self.loss_type, self.trunc_weight, self.trunc_distance,
+                          self.eik_weight, self.eik_apply_dist, self.grad_weight, bool(self.orien_loss))
+
+    def _sample_cfg(self, n_rays=None, dist_behind_surf=None, n_strat=None, n_surf=None):
+        return SampleConfig(n_rays=self.n_rays if n_rays is None else n_rays,
+                            n_strat=self.n_strat_samples if n_strat is None else n_strat,
+                            n_surf=self.n_surf_samples if n_surf is None else n_surf,
+                            min_depth=self.min_depth,
+                            dist_behind_surf=self.dist_behind_surf if dist_behind_surf is None else dist_behind_surf,
+                            H=self.H, W=self.W, fx=self.fx, fy=self.fy, cx=self.cx, cy=self.cy)
+
+    @property
+    def engine(self):
+        return self.sdf_map.engine
+
+    def _rank(self):
+        g = self._hip.dist_group
+        return 0 if g is None else torch.distributed.get_rank(g)
+
+    # ------------------------------------------------------------------ sampling (trainer.py:683-766)
+    def _draws_torch(self, F, sc, n_valid_fn):
+        """Reference draw order / shapes / devices: randint(h), randint(w) on the training device,
+        rand(R, n_strat) on the device, normal(0, 0.1, (R, n_surf-1)) on the CPU generator
+        (sample.py:15-16,123,160-162)."""
+        dev = self._hip.device
+        total = sc.n_rays * F
+        ih = torch.randint(0, sc.H, (total,), device=dev)
+        iw = torch.randint(0, sc.W, (total,), device=dev)
+        R = n_valid_fn(ih, iw)
+        U = torch.rand(R, sc.n_strat, device=dev)
+        N_off = torch.normal(torch.zeros(R, max(sc.n_surf - 1, 0)), 0.1).to(dev)
+        return dict(indices_h=ih, indices_w=iw, U=U, N_off=N_off)
+
+    def _sample_raw(self, depth_batch, T_WC_batch, norm_batch, frame_idx, normal_idx, sc, want_T, shared_key=False):
+        """sampler launch; returns the engine's capacity-sized output dict (rows >= n_valid are undefined).
+        shared_key: use the rank-INDEPENDENT Philox key (keyframe test under data parallelism: every rank
+        must reach the same decision)."""
+        eng, hip = self.engine, self._hip
+        if hip.rng == "torch":
+            def n_valid(ih, iw):   # the reference learns R from its boolean-mask compaction (a sync)
+                ib = torch.arange(frame_idx.numel(), device=ih.device).repeat_interleave(sc.n_rays)
+                d = depth_batch[frame_idx.long()[ib], ih, iw]
+                ok = d != 0
+                if norm_batch is not None:
+                    ok &= ~torch.isnan(norm_batch[normal_idx.long()[ib], ih, iw, 0])
+                return int(ok.sum().item())
+            draws = self._draws_torch(frame_idx.numel(), sc, n_valid)
+            return eng.sample(depth_batch, T_WC_batch, norm_batch, frame_idx, normal_idx, sc, draws=draws,
+                              want_T=want_T)
+        hip.draw_count += 1
+        seed = hip.seed if shared_key else dp.rank_seed(hip.seed, self._rank())
+        return eng.sample(depth_batch, T_WC_batch, norm_batch, frame_idx, normal_idx, sc,
+                          seed=seed, offset=hip.draw_count, want_T=want_T)
+
+    def sample_points(self, depth_batch, T_WC_batch, norm_batch=None, active_loss_approx=None, n_rays=None,
+                      dist_behind_surf=None, n_strat_samples=None, n_surf_samples=None, _shared_key=False):
+        """Same 11 named tensors as the reference (trainer.py:753-766), cut to the R valid rays (one host
+        sync for R, exactly where the reference's boolean-mask compaction has one, sample.py:39-55).
+        `binary_masks` is None: the dense [F,H,W] mask image is never materialised (sample.py:58-61)."""
+        if active_loss_approx is not None:
+            raise Exception('Active sampling not currently supported.')
+        sc = self._sample_cfg(n_rays, dist_behind_surf, n_strat_samples, n_surf_samples)
+        dev = self._hip.device
+        ar = torch.arange(depth_batch.shape[0], dtype=torch.int32, device=dev)
+        s = self._sample_raw(depth_batch.contiguous(), T_WC_batch.contiguous(),
+                             None if norm_batch is None else norm_batch.contiguous(), ar,
+                             None if norm_batch is None else ar, sc, want_T=True, shared_key=_shared_key)
+        R = int(s["n_valid"].item())
+
+        def cut(t):
+            return None if t is None else t[:R]
+        return {
+            "depth_batch": depth_batch, "pc": cut(s["pc"]), "z_vals": cut(s["z_vals"]),
+            "indices_b": cut(s["indices_b"]), "indices_h": cut(s["indices_h"]), "indices_w": cut(s["indices_w"]),
+            "dirs_C_sample": cut(s["dirs_C_sample"]), "depth_sample": cut(s["depth_sample"]),
+            "T_WC_sample": cut(s["T_WC_sample"]), "norm_sample": cut(s["norm_sample"]),
+            "binary_masks": None,
+            "_raw": s, "_sc": sc,
+        }
+
+    # ------------------------------------------------------------------ loss + backward (trainer.py:768-868, 981)
+    def _raw_from_public(self, sample):
+        """A `sample` dict that did not come from our sample_points (a caller assembled the reference's 11
+        tensors itself): rebuild what the step kernel needs."""
+        dev = self._hip.device
+        pc = sample["pc"].detach().to(dev, torch.float32).contiguous()
+        R, S = pc.shape[0], pc.shape[1]
+        T = sample["T_WC_sample"].to(dev, torch.float32)
+        dC = sample["dirs_C_sample"].to(dev, torch.float32).contiguous()
+        dW = (T[:, :3, :3] * dC[:, None, :]).sum(-1).contiguous()          # transform.py:36-41
+        i64 = lambda t: t.to(dev, torch.int64).contiguous()
+        F = int(sample["depth_batch"].shape[0])
+        s = dict(n_valid=torch.tensor([R], dtype=torch.int32, device=dev), pc=pc,
+                 z_vals=sample["z_vals"].to(dev, torch.float32).contiguous(),
+                 depth_sample=sample["depth_sample"].to(dev, torch.float32).contiguous(),
+                 dirs_C_sample=dC, dirs_W_sample=dW,
+                 norm_sample=None if sample.get("norm_sample") is None else sample["norm_sample"].to(dev, torch.float32).contiguous(),
+                 indices_b=i64(sample["indices_b"]), indices_h=i64(sample["indices_h"]), indices_w=i64(sample["indices_w"]),
+                 max_rays=R, S=S, n_frames=F)
+        sc = self._sample_cfg(n_strat=S - self.n_surf_samples)
+        return s, sc
+
+    def _step_kernels(self, s, sc, fused_optim, frame_avg_dst):
+        """sampler outputs -> reduce buffer (+ optimiser when fused).  Returns (loss_approx, frame_avg_loss)."""
+        hip, eng = self._hip, self.engine
+        noise, kw = None, {}
+        if self.noise_std is not None:   # fc_map.py:106-108 (drawn even for 0)
+            if hip.rng == "torch":
+                R = int(s["n_valid"].item())
+                noise = torch.randn(R, s["S"], device=hip.device) * self.noise_std
+            else:                        # philox mode: drawn inside the kernel
+                hip.noise_count += 1
+                kw = dict(noise_std=self.noise_std, noise_seed=dp.rank_seed(hip.seed, self._rank()),
+                          noise_offset=hip.noise_count)
+        if fused_optim:
+            g = self.optimiser.param_groups[0]
+            kw["optim"] = dict(lr=g["lr"], weight_decay=g["weight_decay"], betas=g["betas"], eps=g["eps"])
+            if frame_avg_dst is not None:   # frames.frame_avg_losses[idxs] = ... inside the launch
+                kw["optim"].update(frame_avg_out=frame_avg_dst[0], frame_avg_index=frame_avg_dst[1])
+        if hip.dist_group is not None and self.bounds_method == "pc":
+            kw["surf_group"] = hip.dist_group
+        dbg = eng.train_step(s, self._loss_cfg(), sc, noise=noise, **kw)
+        if hip.dist_group is not None:   # sums over ranks; AdamW divides by the reduced count
+            dp.allreduce_(eng.reduce_buf, hip.dist_group)
+        return dbg
+
+    def sdf_eval_and_loss(self, sample, do_avg_loss=True):
+        """(total_loss, losses, loss_approx, frame_avg_loss) as the reference.  The backward pass has already
+        run when this returns (gradient sums are in the engine's reduce buffer): the caller's
+        `total_loss.backward()` is a no-op and `self.optimiser.step()` applies the update."""
+        if "_raw" in sample:
+            s, sc = sample["_raw"], sample["_sc"]
+        else:
+            s, sc = self._raw_from_public(sample)
+        self._step_kernels(s, sc, fused_optim=False, frame_avg_dst=None)
+        eng = self.engine
+        ls = eng.loss_sums().detach().cpu()
+        losses = StepLosses(ls, self.grad_weight != 0, self.eik_weight != 0)
+        anchor = next(iter(self.sdf_map.parameters()))
+        total_loss = _BackwardDone.apply((eng.loss_sums()[_ffi.LS_TOTAL] / eng.loss_sums()[_ffi.LS_COUNT]).detach(), anchor)
+        loss_approx = frame_avg_loss = None
+        if do_avg_loss:
+            loss_approx, frame_avg_loss = eng.frame_avg(s["n_frames"])
+        return total_loss, losses, loss_approx, frame_avg_loss
+
+    # ------------------------------------------------------------------ step (trainer.py:951-1016)
+    def _timing_start(self):
+        """metrics.start_timing (metrics.py:13-22): device-synchronised, CUDA(HIP) events"""
+        if self._hip.device.type == "cuda":
+            torch.cuda.synchronize()
+            start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            start.record()
+            return start, end
+        import time
+        return time.perf_counter(), None
+
+    def _timing_end(self, start, end):
+        """metrics.end_timing (metrics.py:25-38), milliseconds"""
+        if self._hip.device.type == "cuda":
+            torch.cuda.synchronize()
+            end.record()
+            torch.cuda.synchronize()
+            return start.elapsed_time(end)
+        import time
+        return (time.perf_counter() - start) * 1000.0
+
+    def step(self):
+        hip = self._hip
+        start, end = self._timing_start()
+
+        K = self.frames.T_WC_batch.shape[0]
+        if len(self.frames) > self.window_size and self.incremental:
+            idxs = self.select_keyframes()
+            if hip.dist_group is not None:             # replicated window: rank 0's draw
+                idxs = dp.broadcast_ints(idxs, hip.dist_group, hip.device)
+        else:
+            idxs = np.arange(K)
+        self.active_idxs = idxs
+        # device copies of the window indices are cached while the window does not change
+        key = (tuple(int(i) for i in idxs), bool(hip.fix_normal_window))
+        if hip.idx_cache is None or hip.idx_cache[0] != key:
+            fidx = torch.as_tensor(np.asarray(idxs), dtype=torch.int32, device=hip.device)
+            # reference quirk q4: normals are read from the UN-windowed normal_batch with
+            # window-local indices (trainer.py:956,969); fix_normal_window=True uses idxs.
+            nidx = fidx if hip.fix_normal_window else torch.arange(len(idxs), dtype=torch.int32, device=hip.device)
+            hip.idx_cache = (key, fidx, nidx)
+        _, fidx, nidx = hip.idx_cache
+        norm_batch = self.frames.normal_batch if self.do_normal else None
+        sc = self._sample_cfg()
+        # no depth_batch[idxs] copy (trainer.py:965: 16 MB at 680x1200x5): the sampler takes the window indices
+        s = self._sample_raw(self.frames.depth_batch, self.frames.T_WC_batch, norm_batch, fidx,
+                             nidx if norm_batch is not None else None, sc, want_T=False)
+        self.active_pixels = _LazyCut(s)
+
+        fal = self.frames.frame_avg_losses
+        fused = hip.dist_group is None and hip.fuse_optimiser
+        direct = fal.is_contiguous() and fal.dtype == torch.float32 and fal.device == hip.device
+        dbg = self._step_kernels(s, sc, fused, (fal, fidx) if direct else None)
+        eng = self.engine
+        if not fused or not direct:                    # two-call / data-parallel path: bins -> frame averages
+            if direct:
+                eng.frame_avg(len(idxs), out=fal, index=fidx)
+            else:
+                _, fa = eng.frame_avg(len(idxs))
+                self.frames.frame_avg_losses[fidx.long()] = fa      # trainer.py:979
+        if not fused:
+            self.optimiser.step()                      # AdamW on the (all-reduced) gradient sums
+        hip.loss_host.copy_(eng.loss_sums(), non_blocking=True)   # rides on the closing synchronisation
+
+        step_time = self._timing_end(start, end)
+        if hip.virtual_step_ms is not None:            # pinned schedule (parity / accuracy runs)
+            step_time = float(hip.virtual_step_ms)
+        if hip.dist_group is not None:                 # ONE virtual clock for all ranks (frame schedule)
+            step_time = dp.max_over_ranks(step_time, hip.dist_group, hip.device)
+        losses = StepLosses(hip.loss_host, self.grad_weight != 0, self.eik_weight != 0)
+        hip.step_count += 1
+        self.tot_step_time += (1 / self.frac_time_perception) * (step_time / 1000.0)
+        self.steps_since_frame += 1
+        return losses, step_time
+
+    # ------------------------------------------------------------------ keyframe test (trainer.py:586-620)
+    def is_keyframe(self, T_WC, depth_gt):
+        """sampler (n_rays_is_kf rays, 0.8 m behind the surface) -> frozen net forward -> per-ray z sort +
+        first-zero-crossing depth render + below-threshold count, all in HIP kernels; the decision and the
+        printed line are the reference's.  Rank-independent draws under data parallelism."""
+        hip = self._hip
+        sample_pts = self.sample_points(depth_gt, T_WC, n_rays=self.n_rays_is_kf, dist_behind_surf=0.8,
+                                        _shared_key=hip.dist_group is not None)
+        s = sample_pts["_raw"]
+        pc = s["pc"]
+        noise = None
+        if self.noise_std is not None:
+            noise = torch.randn(pc.shape[:-1], device=hip.device) * self.noise_std
+        sdf = self.frozen_sdf_map.engine.sdf_eval(pc, noise=noise)           # frozen net, no grad (trainer.py:594-595)
+        view, below = self.engine.render_depth(s["z_vals"], sdf, s["depth_sample"], self.kf_dist_th,
+                                               n_valid=s["n_valid"])
+        n = int(s["n_valid"].item())
+        below_th_prop = float(below.item()) / max(n, 1)
+        is_keyframe = below_th_prop < self.kf_pixel_ratio
+        print("Proportion of loss below threshold", below_th_prop, "for KF should be less than",
+              self.kf_pixel_ratio, " ---> is keyframe:", is_keyframe)
+        return is_keyframe
+
+    # ------------------------------------------------------------------ data parallel
+    def check_keyframe_latest(self):
+        """The reference's decision logic (trainer.py:622-650) runs unchanged; under data parallelism rank 0's
+        outcome is broadcast so the keyframe sets (and with them the all-reduce message size) cannot diverge."""
+        add_new_frame = super().check_keyframe_latest()
+        hip = self._hip
+        if hip.dist_group is not None:
+            v = dp.broadcast_floats([float(add_new_frame), float(self.last_is_keyframe), float(self.optim_frames),
+                                     -1.0 if self.noise_std is None else float(self.noise_std)], hip.dist_group, hip.device)
+            add_new_frame, self.last_is_keyframe, self.optim_frames = bool(v[0]), bool(v[1]), int(v[2])
+            self.noise_std = None if v[3] < 0 else v[3]
+        return add_new_frame
+
+    def add_frame(self, frame_data):
+        """New frame: under data parallelism rank 0's depth / pose / normals are broadcast once per FRAME
+        (1.2-3.3 MB depth + 3.7-9.8 MB normals), then the reference's add_frame runs."""
+        hip = self._hip
+        if hip.dist_group is not None:
+            for k in ("depth_batch", "T_WC_batch", "normal_batch"):
+                t = getattr(frame_data, k, None)
+                if torch.is_tensor(t):
+                    torch.distributed.broadcast(t, dp.src_rank(hip.dist_group), group=hip.dist_group)
+        return super().add_frame(frame_data)
+
+    # ------------------------------------------------------------------ checkpoint / resume
+    def hip_state_dict(self):
+        """Everything needed for a true resume.  The reference saves only model + optimiser
+        (train.py:207-219) and restores only the model (trainer.py:441-444); keyframes, RNG
+        position, the frozen keyframe-test network and the virtual clock are lost there."""
+        fr, hip = self.frames, self._hip
+        frozen = getattr(self, "frozen_sdf_map", None)
+        return {
+            "model_state_dict": {k: v.detach().clone() for k, v in self.sdf_map.state_dict().items()},
+            "optimizer_state_dict": self.optimiser.state_dict(),
+            "frozen_state_dict": None if frozen is None else {k: v.detach().clone() for k, v in frozen.state_dict().items()},
+            "frames": {k: (None if getattr(fr, k, None) is None else
+                           (getattr(fr, k).copy() if isinstance(getattr(fr, k), np.ndarray) else getattr(fr, k).clone()))
+                       for k in ("frame_id", "im_batch", "depth_batch", "T_WC_batch", "normal_batch", "frame_avg_losses")},
+            "clock": dict(tot_step_time=self.tot_step_time, steps_since_frame=self.steps_since_frame,
+                          last_is_keyframe=self.last_is_keyframe, optim_frames=self.optim_frames,
+                          noise_std=self.noise_std, step_count=hip.step_count),
+            "rng": dict(draw_count=hip.draw_count, noise_count=hip.noise_count, seed=hip.seed,
+                        numpy=np.random.get_state(), torch=torch.get_rng_state(),
+                        torch_cuda=torch.cuda.get_rng_state(hip.device) if hip.device.type == "cuda" else None),
+        }
+
+    def load_hip_state_dict(self, sd):
+        hip = self._hip
+        self.sdf_map.load_state_dict(sd["model_state_dict"])
+        self.optimiser.load_state_dict(sd["optimizer_state_dict"])
+        if sd.get("frozen_state_dict") is not None:
+            self.frozen_sdf_map = copy.deepcopy(self.sdf_map)
+            self.frozen_sdf_map.load_state_dict(sd["frozen_state_dict"])
+        f = sd["frames"]
+        fr = type(self.frames)()
+        for k, v in f.items():
+            setattr(fr, k, v)
+        self.frames = fr
+        c = sd["clock"]
+        self.tot_step_time, self.steps_since_frame = c["tot_step_time"], c["steps_since_frame"]
+        self.last_is_keyframe, self.optim_frames = c["last_is_keyframe"], c["optim_frames"]
+        self.noise_std, hip.step_count = c["noise_std"], c["step_count"]
+        r = sd["rng"]
+        hip.draw_count, hip.noise_count, hip.seed = r["draw_count"], r["noise_count"], r["seed"]
+        hip.idx_cache = None
+        np.random.set_state(r["numpy"]); torch.set_rng_state(r["torch"])
+        if r.get("torch_cuda") is not None:
+            torch.cuda.set_rng_state(r["torch_cuda"], hip.device)
+
+
+UNSUPPORTED_HINT = ("isdf_amd hot path: %s (the reference's own Python path is the CPU / fallback path; "
+                    "this build ships no second implementation)")
+
+
+def graft(trainer, rng="philox", seed=1, dist_group=None, fix_normal_window=False, fwd_operand="fp16",
+          fuse_optimiser=True, virtual_step_ms=None, engine_factory=None):
+    """Re-bind the hot path of `trainer` (an `isdf.modules.trainer.Trainer` or a `StandinTrainer`) to the HIP
+    kernels, IN PLACE, and return it.
+
+    rng: "philox" (in-kernel draws, no host sync inside step) or "torch" (draw with torch in the reference's
+         order, shapes and devices: parity mode, one host sync per step like the reference).
+    dist_group: torch.distributed process group for ray-sharded data parallelism (one all-reduce per step);
+         weights are broadcast from rank 0 here so every rank starts from the same network.
+    virtual_step_ms: if set, the virtual clock advances by this much per step instead of the measured step time
+         (the frame schedule is a function of measured time, trainer.py:100-101,1011-1013; pin it to compare runs).
+    engine_factory: tests only (a stand-in engine for hosts without a GPU)."""
+    if isinstance(trainer, HotPath) and getattr(trainer, "_hip", None) is not None:
+        return trainer
+    dev = torch.device(trainer.device)
+    if engine_factory is None and dev.type != "cuda":
+        raise _ffi.IsdfError(UNSUPPORTED_HINT % ("device %r is not a HIP device" % (trainer.device,)))
+    if trainer.bounds_method not in ("ray", "pc"):
+        raise _ffi.IsdfError(UNSUPPORTED_HINT % "bounds_method 'normal' cannot run upstream either (loss.py:29)")
+    if getattr(trainer, "do_active", False):
+        raise _ffi.IsdfError(UNSUPPORTED_HINT % "active sampling is rejected by the reference itself (trainer.py:718)")
+    if rng not in ("philox", "torch"):
+        raise ValueError("rng must be 'philox' or 'torch'")
+
+    old = getattr(trainer, "sdf_map", None)
+    if old is not None and not isinstance(old, SDFMapHIP):
+        pe_old = old.positional_encoding
+        pe = PositionalEncodingHIP(min_deg=pe_old.min_deg, max_deg=pe_old.max_deg, scale=pe_old.scale,
+                                   transform=pe_old.transform)
+        n_block = len(old.mid1)
+        hidden = old.out_alpha.in_features
+        new = SDFMapHIP(pe, hidden_size=hidden, hidden_layers_block=n_block, scale_output=old.scale_output,
+                        device=dev, fwd_operand=fwd_operand, engine_factory=engine_factory)
+        new.load_state_dict({k: v.detach() for k, v in old.state_dict().items()})
+        new.train(old.training)
+        trainer.sdf_map = new
+        og = trainer.optimiser.param_groups[0]
+        trainer.optimiser = FlatAdamW(new, lr=og["lr"], weight_decay=og["weight_decay"], betas=tuple(og["betas"]),
+                                      eps=og["eps"])
+        if getattr(trainer, "frozen_sdf_map", None) is not None:
+            fz = copy.deepcopy(new)
+            fz.load_state_dict({k: v.detach() for k, v in trainer.frozen_sdf_map.state_dict().items()})
+            trainer.frozen_sdf_map = fz
+    elif old is None:
+        raise ValueError("graft() needs a trainer whose load_networks() has run")
+
+    hip = types.SimpleNamespace(rng=rng, seed=int(seed), dist_group=dist_group, fix_normal_window=bool(fix_normal_window),
+                                fuse_optimiser=bool(fuse_optimiser), device=dev, draw_count=0, noise_count=0,
+                                step_count=0, idx_cache=None,
+                                virtual_step_ms=None if virtual_step_ms is None else float(virtual_step_ms),
+                                loss_host=torch.zeros(8, dtype=torch.float32,
+                                                      pin_memory=(dev.type == "cuda")))
+    trainer._hip = hip
+    base = trainer.__class__
+    if not issubclass(base, HotPath):
+        trainer.__class__ = type("Hip" + base.__name__, (HotPath, base), {"__module__": HotPath.__module__})
+    if dist_group is not None:                           # replicated weights / moments
+        eng = trainer.sdf_map.engine
+        for t in (eng.params, eng.exp_avg, eng.exp_avg_sq):
+            torch.distributed.broadcast(t, dp.src_rank(dist_group), group=dist_group)
+        eng.pack()
+    return trainer

@@ -35,8 +35,9 @@ def _fc_block(in_f, out_f):
 
 class SDFMapHIP(nn.Module):
     def __init__(self, positional_encoding, hidden_size=256, hidden_layers_block=1, scale_output=1.0,
-                 device="cuda", fwd_operand="fp16"):
+                 device="cuda", fwd_operand="fp16", engine_factory=None):
         super().__init__()
+        object.__setattr__(self, "_engine_factory", engine_factory)
         self.scale_output = scale_output
         self.positional_encoding = positional_encoding
         E = positional_encoding.embedding_size
@@ -60,7 +61,8 @@ class SDFMapHIP(nn.Module):
         net = NetConfig(hidden=hidden_size, blocks=hidden_layers_block, n_freqs=positional_encoding.n_freqs,
                         scale_input=positional_encoding.scale, scale_output=scale_output,
                         transform=None if T is None else np.asarray(T, np.float32), fwd_operand=fwd_operand)
-        object.__setattr__(self, "engine", Engine(net, device))   # not a submodule / not in state_dict
+        make = Engine if engine_factory is None else engine_factory          # engine_factory: host-logic tests only
+        object.__setattr__(self, "engine", make(net, device))   # not a submodule / not in state_dict
         self._bind()
 
     def _bind(self):
@@ -93,22 +95,27 @@ class SDFMapHIP(nn.Module):
         """`copy.deepcopy(self.sdf_map)` (trainer.py:576): a frozen snapshot with its own buffers."""
         pe = copy.copy(self.positional_encoding)
         new = SDFMapHIP(pe, self.engine.net.hidden, self.engine.net.blocks, self.scale_output,
-                        device=self.engine.device, fwd_operand=self.engine.net.fwd_operand)
+                        device=self.engine.device, fwd_operand=self.engine.net.fwd_operand,
+                        engine_factory=self._engine_factory)
         new.engine.params.copy_(self.engine.params)
         new.engine.pack()
         new.train(self.training)
         return new
 
-    @torch.no_grad()
     def forward(self, x, noise_std=None, pe_mask=None, sdf1=None):
-        """`SDFMap.forward` (fc_map.py:94-111).  Inference only: autograd does not
-        flow through the HIP kernel (training uses Engine.train_step)."""
+        """`SDFMap.forward` (fc_map.py:94-111) on the fused HIP inference kernel.  Weight gradients never flow
+        through this call (training is Engine.train_step); the INPUT gradient does: when `x.requires_grad`
+        the kernel also returns d sdf / d x and `fc_map.gradient(x, sdf)` / `autograd.grad` (fc_map.py:12-22;
+        render.render_normals, render.py:39-47, and the slice/vis call sites use it) get it back first-order."""
         if pe_mask is not None:
             raise NotImplementedError("pe_mask is unused by the reference's training/eval paths")
         noise = None
         if noise_std is not None:     # drawn whenever noise_std is not None, even 0 (SURVEY q3)
             noise = torch.randn(x.shape[:-1], device=x.device) * noise_std
-        return self.engine.sdf_eval(x, noise=noise)
+        if torch.is_grad_enabled() and x.requires_grad:
+            return _SdfWithInputGrad.apply(x, self, noise)
+        with torch.no_grad():
+            return self.engine.sdf_eval(x, noise=noise)
 
     @torch.no_grad()
     def forward_with_grad(self, x, noise_std=None):
@@ -117,6 +124,19 @@ class SDFMapHIP(nn.Module):
         if noise_std is not None:
             noise = torch.randn(x.shape[:-1], device=x.device) * noise_std
         return self.engine.sdf_eval(x, noise=noise, want_grad=True)
+
+
+class _SdfWithInputGrad(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, module, noise):
+        sdf, grad = module.engine.sdf_eval(x.detach(), noise=noise, want_grad=True)
+        ctx.save_for_backward(grad)
+        return sdf
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return g.unsqueeze(-1) * grad, None, None
 
 
 def chunks(pc, chunk_size, fc_sdf_map, to_cpu=False):

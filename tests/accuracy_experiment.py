@@ -40,6 +40,7 @@ def config(cam):
         "model": {"do_active": 0, "frac_time_perception": 1.0, "scale_output": 0.14, "noise_std": 0.25,
                   "noise_kf": 0.08, "noise_frame": 0.04, "window_size": 5, "hidden_layers_block": 2,
                   "hidden_feature_size": 256, "iters_per_kf": 60, "iters_per_frame": 10,
+                  "kf_dist_th": 0.1, "kf_pixel_ratio": 0.65,
                   "embedding": {"scale_input": 0.05937489, "n_embed_funcs": 5}},
         "loss": {"bounds_method": "ray", "loss_type": "L1", "trunc_weight": 5.38344020,
                  "trunc_distance": 0.29365022, "eik_weight": 0.268, "eik_apply_dist": 0.1,
@@ -83,15 +84,17 @@ def run_hip(seed, depth, normal, T, cam, steps_per_kf):
 
 
 def run_hip_reference_schedule(seed, cam, n_steps=1200, virtual_step_ms=20.0, n_frames=600, quiet=True):
-    """The reference driver's frame scheduling (train.py:86-136) on the synthetic 30 fps stream:
-    after `optim_frames` steps on the latest frame, `check_keyframe_latest` (keyframe test on the
-    frozen net, trainer.py:586-650) decides whether it becomes a keyframe; the next frame id is
-    int(tot_step_time * fps) (trainer.py:100).  The virtual clock advances by `virtual_step_ms` per
-    step (pinned) instead of the measured step time so the schedule is reproducible."""
+    """The reference driver's frame scheduling (train.py:86-136, restated in tests/driver_loop.py) on the
+    synthetic 30 fps stream: after `optim_frames` steps on the latest frame, `check_keyframe_latest` (keyframe
+    test on the frozen net, trainer.py:586-650) decides whether it becomes a keyframe; the next frame id is
+    int(tot_step_time * fps) (trainer.py:100).  The virtual clock advances by `virtual_step_ms` per step
+    (pinned) instead of the measured step time so the schedule is reproducible."""
     import contextlib, io
     from isdf_amd.trainer import HipTrainer
+    from tests.driver_loop import run_train_loop
     np.random.seed(seed); torch.manual_seed(seed)
-    tr = HipTrainer("cuda", config(cam), inv_bounds_transform=synthetic.bounds_transform(), rng="philox", seed=seed)
+    tr = HipTrainer("cuda", config(cam), inv_bounds_transform=synthetic.bounds_transform(), rng="philox", seed=seed,
+                    virtual_step_ms=virtual_step_ms)
     traj = synthetic.trajectory(n_frames)
     rng = np.random.RandomState(seed)
     seen = {}
@@ -100,27 +103,13 @@ def run_hip_reference_schedule(seed, cam, n_steps=1200, virtual_step_ms=20.0, n_
         if i not in seen:
             seen[i] = synthetic.render_depth(traj[i], cam, rng, noise_std=0.01)
         return tr.make_frame(i, seen[i], traj[i])
-    fps, t, kf_ids = 30, 0, []
     sink = io.StringIO()
     with (contextlib.redirect_stdout(sink) if quiet else contextlib.nullcontext()):
-        for t in range(n_steps):
-            finish_optim = tr.steps_since_frame == tr.optim_frames
-            if finish_optim or t == 0:
-                add_new_frame = True if t == 0 else tr.check_keyframe_latest()
-                if add_new_frame:
-                    new_id = int(tr.tot_step_time * fps)
-                    if new_id >= n_frames:
-                        break
-                    tr.add_frame(frame(new_id))
-                    if t == 0:
-                        tr.last_is_keyframe = True
-                        tr.optim_frames = 200
-            losses, ms = tr.step()
-            tr.tot_step_time += (virtual_step_ms - ms) / 1000.0 / tr.frac_time_perception   # pin the clock
+        n, ingests, losses = run_train_loop(tr, frame, n_frames, n_steps)
     ids = [int(i) for i in tr.frames.frame_id]
     depth = np.stack([seen[i] for i in ids]); T = np.stack([traj[i] for i in ids])
     fn = lambda p: tr.sdf_map(torch.from_numpy(p.astype(np.float32)).to(tr.device)).cpu().numpy()
-    return fn, float(losses["total_loss"]), depth, T, ids, t + 1
+    return fn, float(losses["total_loss"]), depth, T, ids, n
 
 
 def run_port(seed, depth, normal, T, cam, steps_per_kf):
