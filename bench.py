@@ -63,6 +63,7 @@ def reference_config():
         "model": {"do_active": 0, "frac_time_perception": 1.0, "scale_output": 0.14, "noise_std": 0.25,
                   "noise_kf": 0.08, "noise_frame": 0.04, "window_size": 5, "hidden_layers_block": 2,
                   "hidden_feature_size": 256, "iters_per_kf": 60, "iters_per_frame": 10,
+                  "kf_dist_th": 0.1, "kf_pixel_ratio": 0.65,
                   "embedding": {"scale_input": 0.05937489, "n_embed_funcs": 5}},
         "loss": {"bounds_method": "ray", "loss_type": "L1", "trunc_weight": 5.38344020,
                  "trunc_distance": 0.29365022, "eik_weight": 0.268, "eik_apply_dist": 0.1,

@@ -130,10 +130,14 @@ typedef struct isdf_sample_out {
   float* pc;             /* [F*n_rays,S,3]                                     */
 } isdf_sample_out;
 
-/* pass 1: pixel draw (or injected), gather, validity, ORDER-PRESERVING compaction */
-int isdf_sample_pixels(const isdf_sample_args* a, const isdf_sample_out* o, void* stream);
-/* pass 2: per compacted ray: stratified + surface z values, world points       */
-int isdf_sample_along_rays(const isdf_sample_args* a, const isdf_sample_out* o, void* stream);
+/* ONE launch: pixel draw (or injected draws), gather of depth + normal, validity, ORDER-PRESERVING
+ * compaction across workgroups (decoupled look-back), then per compacted ray the stratified + surface z
+ * values and world points.  scan_ws: device scratch of isdf_sample_scan_bytes(F*n_rays) bytes that must be
+ * ZERO when first used and is otherwise private to this entry point (it re-arms itself at the end of every
+ * launch; launches sharing one scan_ws must be stream-ordered).                                            */
+int64_t isdf_sample_scan_bytes(int64_t max_rays);
+int isdf_sample_rays(const isdf_sample_args* a, const isdf_sample_out* o, void* scan_ws,
+                     int64_t scan_ws_bytes, void* stream);
 
 /* ---- fused PE + MLP (+ input gradient) inference --------------------------
  * Replaces SDFMap.forward and fc_map.gradient (fc_map.py:94-111,12-22) for

@@ -15,8 +15,8 @@ ABI_VERSION = 3
 # every symbol include/isdf_hip.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
     "isdf_abi_version", "isdf_error_string", "isdf_check_net", "isdf_param_count", "isdf_shadow_bytes",
-    "isdf_workspace_bytes", "isdf_reduce_floats", "isdf_pack_weights", "isdf_sample_pixels",
-    "isdf_sample_along_rays", "isdf_sdf_eval", "isdf_train_step", "isdf_train_step_adamw", "isdf_bounds_pc",
+    "isdf_workspace_bytes", "isdf_reduce_floats", "isdf_sample_scan_bytes", "isdf_pack_weights", "isdf_sample_rays",
+    "isdf_sdf_eval", "isdf_train_step", "isdf_train_step_adamw", "isdf_bounds_pc",
     "isdf_frame_avg", "isdf_adamw", "isdf_estimate_normals", "isdf_render_depth",
 ]
 
@@ -109,8 +109,9 @@ def lib():
     L.isdf_reduce_floats.restype = i64
     L.isdf_reduce_floats.argtypes = [P(NetCfg), i32]
     L.isdf_pack_weights.argtypes = [P(NetCfg), vp, vp, vp]
-    L.isdf_sample_pixels.argtypes = [P(SampleArgs), P(SampleOut), vp]
-    L.isdf_sample_along_rays.argtypes = [P(SampleArgs), P(SampleOut), vp]
+    L.isdf_sample_scan_bytes.restype = i64
+    L.isdf_sample_scan_bytes.argtypes = [i64]
+    L.isdf_sample_rays.argtypes = [P(SampleArgs), P(SampleOut), vp, i64, vp]
     L.isdf_sdf_eval.argtypes = [P(NetCfg), vp, vp, vp, i64, vp, vp, vp, vp, i64, vp]
     L.isdf_train_step.argtypes = [P(NetCfg), P(LossCfg), vp, vp, P(StepArgs), P(StepOut), vp, i64, vp]
     L.isdf_train_step_adamw.argtypes = [P(NetCfg), P(LossCfg), P(StepArgs), P(StepOut), P(OptimArgs), vp, i64, vp]
@@ -119,7 +120,7 @@ def lib():
     L.isdf_adamw.argtypes = [P(NetCfg), vp, vp, vp, vp, vp, f32, f32, f32, f32, f32, f32, i32, vp, vp]
     L.isdf_estimate_normals.argtypes = [vp, i32, i32, f32, f32, f32, f32, vp, vp]
     L.isdf_render_depth.argtypes = [vp, i64, i64, i32, vp, vp, vp, f32, vp, vp, vp]
-    for n in SYMBOLS[7:]:
+    for n in SYMBOLS[8:]:
         getattr(L, n).restype = C.c_int
     if L.isdf_abi_version() != ABI_VERSION:
         raise IsdfError("libisdf_hip.so ABI %d != binding ABI %d" % (L.isdf_abi_version(), ABI_VERSION))

@@ -11,8 +11,8 @@ using namespace isdf;
 namespace isdf {
 int launch_chain(const ChainParams& p, int mode, int64_t nTiles, hipStream_t st);
 int launch_dw(const DwParams& p, hipStream_t st);
-int launch_sample_pixels(const isdf_sample_args& a, const isdf_sample_out& o, hipStream_t st);
-int launch_sample_along_rays(const isdf_sample_args& a, const isdf_sample_out& o, hipStream_t st);
+int launch_sample_rays(const isdf_sample_args& a, const isdf_sample_out& o, void* scan_ws, hipStream_t st);
+int64_t sample_scan_bytes(int64_t max_rays);
 int launch_adamw(float* p, float* m, float* v, const float* g, const float* cnt, float gs, float lr, float b1,
                  float b2, float eps, float wd, int step, int64_t n, hipStream_t st);
 int launch_pack(const NetLayout& L, const float* params, uint16_t* shadow, hipStream_t st);
@@ -95,24 +95,21 @@ int isdf_pack_weights(const isdf_net_cfg* net, const float* params, void* shadow
   return launch_pack(l, params, (uint16_t*)shadow, (hipStream_t)stream);
 }
 
-int isdf_sample_pixels(const isdf_sample_args* a, const isdf_sample_out* o, void* stream) {
+int64_t isdf_sample_scan_bytes(int64_t max_rays) { return max_rays < 1 ? ISDF_EINVAL : sample_scan_bytes(max_rays); }
+
+int isdf_sample_rays(const isdf_sample_args* a, const isdf_sample_out* o, void* scan_ws, int64_t scan_ws_bytes,
+                     void* stream) {
   isdf_clear_stale_hip_error();
   if (!a || !o || !a->depth_batch || !a->T_WC_batch || !a->frame_idx || !o->n_valid || !o->indices_b ||
-      !o->indices_h || !o->indices_w || !o->depth_sample || !o->dirs_C_sample || !o->dirs_W_sample)
+      !o->indices_h || !o->indices_w || !o->depth_sample || !o->dirs_C_sample || !o->dirs_W_sample || !o->z_vals ||
+      !o->pc)
     return ISDF_EINVAL;
   if (a->normal_batch && !a->normal_idx) return ISDF_EINVAL;
-  if (a->n_frames < 1 || a->n_rays < 1 || a->H < 8 || a->W < 8) return ISDF_EINVAL;
-  if (a->rng_mode == 0 && (!a->draw_h || !a->draw_w)) return ISDF_EINVAL;
-  return launch_sample_pixels(*a, *o, (hipStream_t)stream);
-}
-
-int isdf_sample_along_rays(const isdf_sample_args* a, const isdf_sample_out* o, void* stream) {
-  isdf_clear_stale_hip_error();
-  if (!a || !o || !o->n_valid || !o->z_vals || !o->pc || !o->depth_sample || !o->dirs_W_sample || !o->indices_b)
-    return ISDF_EINVAL;
-  if (a->n_strat < 1 || a->n_surf < 0) return ISDF_EINVAL;
-  if (a->rng_mode == 0 && (!a->draw_u || (a->n_surf > 1 && !a->draw_n))) return ISDF_EINVAL;
-  return launch_sample_along_rays(*a, *o, (hipStream_t)stream);
+  if (a->n_frames < 1 || a->n_rays < 1 || a->H < 1 || a->W < 1 || a->n_strat < 1 || a->n_surf < 0) return ISDF_EINVAL;
+  if ((int64_t)a->n_frames * a->n_rays > 0x7fffffff / 64) return ISDF_EINVAL;
+  if (a->rng_mode == 0 && (!a->draw_h || !a->draw_w || !a->draw_u || (a->n_surf > 1 && !a->draw_n))) return ISDF_EINVAL;
+  if (!scan_ws || scan_ws_bytes < sample_scan_bytes((int64_t)a->n_frames * a->n_rays)) return ISDF_EWORKSPACE;
+  return launch_sample_rays(*a, *o, scan_ws, (hipStream_t)stream);
 }
 
 int isdf_sdf_eval(const isdf_net_cfg* net, const float* params, const void* shadow, const float* pts,

@@ -50,10 +50,15 @@ struct Tile {
   static constexpr int XBYTES = BM * ROWB;
   // small fp32 arrays after the X tile
   static constexpr int OFF_XS = XBYTES;                   // [BM][4] x' (scaled/transformed point)
-  static constexpr int OFF_PART = OFF_XS + BM * 16;       // [NW][BM][4] partial sums (raw / g)
-  static constexpr int OFF_GB = OFF_PART + NW * BM * 16;   // [BM][4] gbar in x' space, [3] = sbar*so
+  // EP > HD (realsense*.json nets): the embedding gradient goes through a separate fp32 [32 points][HD] buffer in
+  // (row half, point block) sub-passes, contracted by 32 points x NPART direction slices
+  static constexpr bool WIDE_E = EP > HD;
+  static constexpr int NPART = WIDE_E ? (NW * 64) / 32 : (NW * 64) / BM;
+  static constexpr int OFF_PART = OFF_XS + BM * 16;       // [NPART][BM][4] partial sums (raw / g)
+  static constexpr int OFF_GB = OFF_PART + NPART * BM * 16;   // [BM][4] gbar in x' space, [3] = sbar*so
   static constexpr int OFF_RED = OFF_GB + BM * 16;        // [BM/64][8] per-wave loss sums
-  static constexpr int LDS_BYTES = OFF_RED + (BM / 64) * 32 + 32;
+  static constexpr int OFF_EG = (OFF_RED + (BM / 64) * 32 + 32 + 1023) / 1024 * 1024;   // fp32 [32][HD], 1 KB-aligned rows
+  static constexpr int LDS_BYTES = WIDE_E ? OFF_EG + 32 * HD * 4 : OFF_RED + (BM / 64) * 32 + 32;
 };
 
 // Workgroup barrier that only waits for this wave's LDS traffic.  The global
@@ -141,7 +146,7 @@ __device__ __forceinline__ void gemm(f32x16 (&acc)[FBN][PBN], WChunk<FBN, CKF>& 
                                      int colByteBase, int lane, Hook&& earlyHook, Hook2&& lateHook) {
   constexpr int CK = CKF / FBN;                  // k-steps per chunk: CK*FBN uint4 = 32 VGPRs
   static_assert(KSTEPS % CK == 0, "K must be a multiple of the chunk");
-  static_assert((ROWB & 1023) == 0, "row base must leave the swizzle bits clear");
+  static_assert((ROWB & 255) == 0, "row base must leave the swizzle bits (4-7) clear");
   constexpr int NCH = KSTEPS / CK;
   typedef typename Op<F16>::v8 v8;
   const int j = lane & 31, hi = lane >> 5;
@@ -273,9 +278,10 @@ __device__ __forceinline__ float softplus_s1(float z, float& s1) {   // also sig
 __device__ __forceinline__ float s1_from_a(float a) { return 1.f - __builtin_amdgcn_exp2f(-kC1 * a); }
 
 template <int HD, int EP, bool F16, int MODE>
-__global__ __launch_bounds__(chain_nw(HD) * 64, (HD <= 256 && chain_nw(HD) == 8 ? 4 : 2)) void chain_kernel(const ChainParams p) {
+__global__ __launch_bounds__(chain_nw(HD) * 64, (HD <= 256 && EP == HD && chain_nw(HD) == 8 ? 4 : 2)) void chain_kernel(const ChainParams p) {
   typedef Tile<HD, EP> T;
-  static_assert(HD == EP, "tile kernels assume padded embedding width == hidden width");
+  static_assert(EP == HD || EP == 2 * HD, "padded embedding width is one or two hidden widths");
+  constexpr bool WIDE_E = T::WIDE_E;
   constexpr int BM = T::BM, FB = T::FB, PB = T::PB, ROWB = T::ROWB;
   extern __shared__ __attribute__((aligned(1024))) char smem[];   // gemm() needs bits 4-9 of row bases clear
   char* X = smem;
@@ -367,7 +373,7 @@ __global__ __launch_bounds__(chain_nw(HD) * 64, (HD <= 256 && chain_nw(HD) == 8 
     char* row = X + pt * ROWB;
     auto put = [&](int feat, float v) {
       *(opT*)(row + swz(pt, (HD + feat) * 2)) = (opT)v;
-      if (MODE == 2) *(__bf16*)(row + swz(pt, feat * 2)) = (__bf16)v;
+      if (MODE == 2 && !WIDE_E) *(__bf16*)(row + swz(pt, feat * 2)) = (__bf16)v;   // bf16 copy staged for the spill
     };
     if (prt == 0) {
       xs[pt * 4] = y0; xs[pt * 4 + 1] = y1; xs[pt * 4 + 2] = y2;
@@ -386,8 +392,9 @@ __global__ __launch_bounds__(chain_nw(HD) * 64, (HD <= 256 && chain_nw(HD) == 8 
     }
   }
   lds_barrier();
-  auto spill_region = [&](int colElemBase, int64_t tensorOff) {
-    // copy a bf16 [BM][HD] region of X to global in frag16 order (16 B per lane)
+  auto spill_region = [&](int colElemBase, int64_t tensorOff, auto cvt) {
+    // copy a [BM][HD] 16-bit region of X to global in frag16 order (16 B per lane); cvt: the region holds fp16
+    // operands and the spill tensors are bf16 (dW operand type)
 #pragma unroll
     for (int fb = 0; fb < FB; ++fb)
 #pragma unroll
@@ -397,13 +404,23 @@ __global__ __launch_bounds__(chain_nw(HD) * 64, (HD <= 256 && chain_nw(HD) == 8 
           const int lb = (xw ^ (64 * fb + 32 * qp)) + colElemBase * 2 + pb * 32 * ROWB;
           uint2 lo = *(const uint2*)(X + lb);
           uint2 hi2 = *(const uint2*)(X + (lb ^ 16));
+          if (decltype(cvt)::value) {
+            const f16x4 a = __builtin_bit_cast(f16x4, lo), b = __builtin_bit_cast(f16x4, hi2);
+            lo = pack4<false>((float)a[0], (float)a[1], (float)a[2], (float)a[3]);
+            hi2 = pack4<false>((float)b[0], (float)b[1], (float)b[2], (float)b[3]);
+          }
           bstore16_nt(make_uint4(lo.x, lo.y, hi2.x, hi2.y), srdS, lane16, sbase(tensorOff), cidx(fb, pb, qp));
         }
   };
   refresh();
   if (MODE == 2) {
-    spill_region(0, p.sp.A[0]);
-    lds_barrier();
+    if (!WIDE_E) {
+      spill_region(0, p.sp.A[0], std::false_type{});
+      lds_barrier();
+    } else {   // no room for a staged copy: spill the embedding halves straight from region 2
+      spill_region(HD, p.sp.A[0], std::integral_constant<bool, F16>{});
+      spill_region(2 * HD, p.sp.A[0] + p.sp.tensorElems, std::integral_constant<bool, F16>{});
+    }
   }
 
   // ------------------------------------------------------------------ forward
@@ -588,6 +605,7 @@ __global__ __launch_bounds__(chain_nw(HD) * 64, (HD <= 256 && chain_nw(HD) == 8 
     if (p.normals) { li_n[0] = p.normals[ray * 3]; li_n[1] = p.normals[ray * 3 + 1]; li_n[2] = p.normals[ray * 3 + 2]; }
   };
   refresh();
+  if constexpr (!WIDE_E) {
   gemm<F16, (2 * HD) / 16, FB, PB, ROWB, T::CKF>(acc, wq, rsW, wptr(setBwdA, L.bwdG, 2 * HD), X, 0, lane, [] {}, loss_inputs);
   // g_x' = J_pe^T Eg.  Eg goes through the (now idle) X tile as fp32 [BM][HD] so the contraction can run in
   // the PE stage's (point, direction-slice) mapping: 2*nf sin/cos per direction per thread and wave-uniform
@@ -610,7 +628,7 @@ __global__ __launch_bounds__(chain_nw(HD) * 64, (HD <= 256 && chain_nw(HD) == 8 
   lds_barrier();
   {
     const int pt = tid & (BM - 1), prt = tid / BM;
-    constexpr int NPART = (T::NW * 64) / BM;
+    constexpr int NPART = T::NPART;
     const float y0 = xs[pt * 4], y1 = xs[pt * 4 + 1], y2 = xs[pt * 4 + 2];
     const char* row = X + pt * ROWB;
     auto eg = [&](int feat) { return *(const float*)(row + swz(pt, feat * 4)); };
@@ -633,6 +651,60 @@ __global__ __launch_bounds__(chain_nw(HD) * 64, (HD <= 256 && chain_nw(HD) == 8 
     dst[0] = g0; dst[1] = g1; dst[2] = g2;
   }
   lds_barrier();
+  } else {
+    // EP = 2 HD: the X tile cannot hold fp32 [BM][EP] next to nothing, and the G operands (p_0 | p_cat in the
+    // first 2 HD columns) must survive the first row half.  So: one GEMM per row half of G (HD embedding
+    // features each), and per 32-point block the accumulator goes through a separate fp32 [32][HD] LDS buffer
+    // and is contracted by 32 points x NPART direction slices; partial g sums accumulate in part[].
+    char* EG = smem + T::OFF_EG;
+    constexpr int NPART = T::NPART;
+    for (int q = tid; q < NPART * BM; q += T::NW * 64) ((float4*)part)[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int half = N_DIRS * nf;
+#pragma unroll
+    for (int rh = 0; rh < EP / HD; ++rh) {
+      if (rh > 0) { zero_acc(acc); refresh(); }
+      WRef wg = wptr(setBwdA, L.bwdG, 2 * HD);
+      wg.soff += rh * (HD / 32) * ((2 * HD) / 16) * 1024;
+      if (rh == 0) gemm<F16, (2 * HD) / 16, FB, PB, ROWB, T::CKF>(acc, wq, rsW, wg, X, 0, lane, [] {}, loss_inputs);
+      else gemm<F16, (2 * HD) / 16, FB, PB, ROWB, T::CKF>(acc, wq, rsW, wg, X, 0, lane, [] {}, [] {});
+      refresh();
+#pragma unroll
+      for (int pb = 0; pb < PB; ++pb) {
+        lds_barrier();   // previous contraction finished reading EG
+#pragma unroll
+        for (int fb = 0; fb < FB; ++fb)
+#pragma unroll
+          for (int rq = 0; rq < 4; ++rq) {
+            const int f0 = w * (FB * 32) + fb * 32 + 8 * rq + 4 * hi;
+            *(float4*)(EG + j * (HD * 4) + swz(j, f0 * 4)) =
+                make_float4(acc[fb][pb][4 * rq], acc[fb][pb][4 * rq + 1], acc[fb][pb][4 * rq + 2], acc[fb][pb][4 * rq + 3]);
+          }
+        lds_barrier();
+        const int pl = tid & 31, prt = tid >> 5, pt = pb * 32 + pl;
+        const float y0 = xs[pt * 4], y1 = xs[pt * 4 + 1], y2 = xs[pt * 4 + 2];
+        const char* row = EG + pl * (HD * 4);
+        const int lo = rh * HD;
+        // feature `feat` of this row half (0 outside it)
+        auto eg = [&](int feat) { return (unsigned)(feat - lo) < (unsigned)HD ? *(const float*)(row + swz(pl, (feat - lo) * 4)) : 0.f; };
+        float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+        if (prt == 0 && rh == 0) { g0 = eg(0); g1 = eg(1); g2 = eg(2); }
+        for (int d = prt; d < N_DIRS; d += NPART) {
+          const float dx = kDirs[0][d], dy = kDirs[1][d], dz = kDirs[2][d];
+          const float proj = y0 * dx + y1 * dy + y2 * dz;
+          float fr = 1.f, c = 0.f;
+          for (int f = 0; f < nf; ++f) {
+            const float xb = proj * fr;
+            c += (__cosf(xb) * eg(3 + d * nf + f) + __cosf(xb + kHalfPi) * eg(3 + half + d * nf + f)) * fr;
+            fr *= 2.f;
+          }
+          g0 += c * dx; g1 += c * dy; g2 += c * dz;
+        }
+        float* dst = part + (prt * BM + pt) * 4;   // (prt, pt) is owned by this thread in every sub-pass
+        dst[0] += g0; dst[1] += g1; dst[2] += g2;
+      }
+    }
+    lds_barrier();
+  }
 
   // ------------------------------------------------------------------ loss + adjoints (one thread per point)
   float lsum[4] = {0.f, 0.f, 0.f, 0.f};
@@ -640,7 +712,7 @@ __global__ __launch_bounds__(chain_nw(HD) * 64, (HD <= 256 && chain_nw(HD) == 8 
     const int64_t n = n0 + tid;
     float e0 = 0.f, e1 = 0.f, e2 = 0.f;
 #pragma unroll
-    for (int k = 0; k < T::NW; ++k) {
+    for (int k = 0; k < T::NPART; ++k) {
       const float* s = part + (k * BM + tid) * 4;
       e0 += s[0]; e1 += s[1]; e2 += s[2];
     }
@@ -770,7 +842,8 @@ __global__ __launch_bounds__(chain_nw(HD) * 64, (HD <= 256 && chain_nw(HD) == 8 
     }
   }
   lds_barrier();
-  spill_region(HD, p.sp.GB[0]);
+  spill_region(HD, p.sp.GB[0], std::false_type{});
+  if (WIDE_E) spill_region(2 * HD, p.sp.GB[0] + p.sp.tensorElems, std::false_type{});
 
   // ------------------------------------------------------------------ adjoint of the first reverse sweep (upward)
   // The top layer's epilogue also IS the top of the ordinary reverse sweep (zbar_L needs only a_L, the
@@ -901,10 +974,10 @@ __global__ __launch_bounds__(chain_nw(HD) * 64, (HD <= 256 && chain_nw(HD) == 8 
 }
 
 // ---------------------------------------------------------------------------
-template <int HD, bool F16, int MODE>
+template <int HD, int EP, bool F16, int MODE>
 static int launch_one(const ChainParams& p, int64_t nTiles, hipStream_t st) {
-  typedef Tile<HD, HD> T;
-  auto k = chain_kernel<HD, HD, F16, MODE>;
+  typedef Tile<HD, EP> T;
+  auto k = chain_kernel<HD, EP, F16, MODE>;
   if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES) != hipSuccess) return ISDF_EHIP;
   hipLaunchKernelGGL(k, dim3((unsigned)nTiles), dim3(T::NW * 64), T::LDS_BYTES, st, p);
   return isdf_launch_status();
@@ -912,8 +985,11 @@ static int launch_one(const ChainParams& p, int64_t nTiles, hipStream_t st) {
 
 template <int MODE>
 static int launch_mode(const ChainParams& p, int64_t nTiles, hipStream_t st) {
-  if (p.lay.HD == 256) return p.lay.fwd_f16 ? launch_one<256, true, MODE>(p, nTiles, st) : launch_one<256, false, MODE>(p, nTiles, st);
-  return p.lay.fwd_f16 ? launch_one<512, true, MODE>(p, nTiles, st) : launch_one<512, false, MODE>(p, nTiles, st);
+  if (p.lay.HD == 256 && p.lay.EP == 256)
+    return p.lay.fwd_f16 ? launch_one<256, 256, true, MODE>(p, nTiles, st) : launch_one<256, 256, false, MODE>(p, nTiles, st);
+  if (p.lay.HD == 256)   // realsense*.json: hidden 256, E = 381 / 465
+    return p.lay.fwd_f16 ? launch_one<256, 512, true, MODE>(p, nTiles, st) : launch_one<256, 512, false, MODE>(p, nTiles, st);
+  return p.lay.fwd_f16 ? launch_one<512, 512, true, MODE>(p, nTiles, st) : launch_one<512, 512, false, MODE>(p, nTiles, st);
 }
 
 int launch_chain(const ChainParams& p, int mode, int64_t nTiles, hipStream_t st) {

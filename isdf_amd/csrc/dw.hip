@@ -55,7 +55,9 @@ __global__ __launch_bounds__(512, 2) void dw_kernel(const DwParams p) {
   // input-side operand: columns [256*ib, +256) of the padded layer input.  Layer 0 reads the
   // embedding; the cat layer reads [a | emb]; the rest read the previous activation.
   const bool fromEmb = li == 0 || (li == L.cat && du.ib * DW_BLK >= HD);
-  const int slB = (li == L.cat && fromEmb) ? du.ib - HD / DW_BLK : du.ib;
+  const int slBfull = (li == L.cat && fromEmb) ? du.ib - HD / DW_BLK : du.ib;   // 256-column slice of the operand
+  // an embedding-shaped operand is stored as EP/HD consecutive HD-wide tensors of HD/256 slices each
+  const int slT = slBfull / (HD / DW_BLK), slB = slBfull % (HD / DW_BLK);
   const int slA = du.ob;
 
   const int64_t P = p.n_valid ? (int64_t)(*p.n_valid) * p.S : p.n_points_host;
@@ -64,8 +66,8 @@ __global__ __launch_bounds__(512, 2) void dw_kernel(const DwParams p) {
 
   // stage q of tile t: q=0 -> (ZB[li], I), q=1 -> (P[li], GB)
   const int64_t offZ = p.sp.ZB[li], offP = p.sp.P[li];
-  const int64_t offI = fromEmb ? p.sp.A[0] : p.sp.A[li];
-  const int64_t offG = fromEmb ? p.sp.GB[0] : p.sp.GB[li];
+  const int64_t offI = fromEmb ? p.sp.A[0] + slT * p.sp.tensorElems : p.sp.A[li];
+  const int64_t offG = fromEmb ? p.sp.GB[0] + slT * p.sp.tensorElems : p.sp.GB[li];
 
   f32x16 acc[2][4];
 #pragma unroll

@@ -56,9 +56,9 @@ struct NetLayout {
 struct SpillLayout {
   int64_t tensorElems;   // per tensor per tile (TILE_PTS * HD); the buffer is [tile][tensor][tensorElems]
   int64_t tileStride;    // elements between consecutive tiles (= tensor count * tensorElems)
-  int64_t A[MAXL + 1];   // A[0] = embedding, A[li+1] = activation after layer li
+  int64_t A[MAXL + 1];   // A[0] = embedding (EP/HD consecutive HD-wide tensors), A[li+1] = activation after layer li
   int64_t P[MAXL];       // d sdf / d z_li
-  int64_t GB[MAXL];      // GB[0] = Ebar, GB[li] = adjoint entering layer li (li >= 1)
+  int64_t GB[MAXL];      // GB[0] = Ebar (EP/HD tensors), GB[li] = adjoint entering layer li (li >= 1)
   int64_t INJ[MAXL];     // injected second-order term of layer li
   int64_t ZB[MAXL];      // d loss / d z_li
   int64_t totalElems;
@@ -99,7 +99,9 @@ inline int make_layout(const isdf_net_cfg* c, NetLayout* l) {
   if (c->blocks < 1 || 2 * c->blocks + 2 > MAXL || c->n_freqs < 1 || c->hidden < 1) return ISDF_EINVAL;
   l->HD = c->hidden; l->B = c->blocks; l->n_freqs = c->n_freqs;
   l->E = 2 * N_DIRS * c->n_freqs + 3;
-  l->EP = round_up(l->E, 128);
+  // padded embedding width: a multiple of the 256-wide dW unit and at least the hidden width (the embedding
+  // shares region 2 of the activation tile with hidden-width operands)
+  l->EP = round_up(l->E, 256) > l->HD ? round_up(l->E, 256) : l->HD;
   l->L = 2 * c->blocks + 2; l->cat = c->blocks + 1;
   l->fwd_f16 = c->fwd_operand ? 1 : 0;
   l->has_transform = c->has_transform;
@@ -128,9 +130,12 @@ inline int make_layout(const isdf_net_cfg* c, NetLayout* l) {
   return ISDF_OK;
 }
 
-// The tile kernels are built for these shapes (the reference default net:
-// replicaCAD.json:57-58,65 -> Hd 256, E 255).  Other shapes: ISDF_EUNSUPPORTED.
-inline bool layout_supported(const NetLayout& l) { return (l.HD == 256 || l.HD == 512) && l.EP == l.HD; }
+// The tile kernels are instantiated for <HD, EP> = <256, 256> (replicaCAD.json / scanNet.json: hidden 256,
+// n_freqs 6 -> E 255), <256, 512> (realsense*.json: hidden 256, n_freqs 9 / 11 -> E 381 / 465) and <512, 512>
+// (BASELINE configs[4]).  Other shapes: ISDF_EUNSUPPORTED.
+inline bool layout_supported(const NetLayout& l) {
+  return (l.HD == 256 && (l.EP == 256 || l.EP == 512)) || (l.HD == 512 && l.EP == 512);
+}
 
 // dW is computed in 256x256 "units": (layer li, output block ob, padded-input block ib).
 constexpr int DW_BLK = 256;
@@ -158,10 +163,11 @@ inline void make_workspace(const NetLayout& l, int64_t maxPts, int64_t maxRays, 
   SpillLayout& s = w->sp;
   s.tensorElems = TILE_PTS * (int64_t)l.HD;   // offsets below are WITHIN a tile's block
   int64_t o = 0;
-  for (int i = 0; i <= l.L; ++i) { s.A[i] = o; o += s.tensorElems; }
+  const int embT = l.EP / l.HD;               // HD-wide tensors per embedding-shaped operand
+  for (int i = 0; i <= l.L; ++i) { s.A[i] = o; o += s.tensorElems * (i == 0 ? embT : 1); }
   if (train) {
     for (int i = 0; i < l.L; ++i) { s.P[i] = o; o += s.tensorElems; }
-    for (int i = 0; i < l.L; ++i) { s.GB[i] = o; o += s.tensorElems; }
+    for (int i = 0; i < l.L; ++i) { s.GB[i] = o; o += s.tensorElems * (i == 0 ? embT : 1); }
     for (int i = 0; i < l.L; ++i) { s.INJ[i] = o; o += s.tensorElems; }
     for (int i = 0; i < l.L; ++i) { s.ZB[i] = o; o += s.tensorElems; }
   }

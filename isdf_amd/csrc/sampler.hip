@@ -9,126 +9,198 @@
 // (sample.py:58-61): the block-loss bins are built from the ray list instead
 // (optim.hip).
 //
-// The work per step is tiny (F*n_rays rays), i.e. latency- not bandwidth-bound:
-// pass 1 is ONE persistent workgroup that walks the drawn rays in order, so the
-// compaction is order-preserving by construction and needs no inter-workgroup
-// protocol; pass 2 is one thread per (ray, sample).
+// ONE launch.  A workgroup (256 threads) takes a chunk of 64 drawn rays: wave 0
+// draws / reads the pixel, gathers depth + normal (one 4-B and one 12-B random
+// read per ray -- the only reads of the keyframe buffers), decides validity and
+// compacts with a ballot; the chunk's offset in the ORDERED output comes from a
+// decoupled look-back over the chunks before it (8-byte {epoch, flag, count}
+// granules, agent-scope stores / polls; chunk ids are handed out by an atomic
+// ticket so a chunk never waits for one that has not started).  All four waves
+// then expand the chunk's valid rays into their S samples (z values + world
+// points) with consecutive lanes on consecutive points, i.e. fully coalesced
+// 4-B / 12-B stores: that is where 86 % of the bytes go (432 of 500 B per ray).
+// At the reference batch (1000 rays) this is 16 workgroups and latency-bound;
+// at >= 1e6 rays it is a streaming kernel (bench.py --sampler-scale).
 #include "isdf_common.h"
 
 namespace isdf {
+
+constexpr int SMP_CHUNK = 64;      // rays per workgroup (one wave gathers and compacts them)
+constexpr int SMP_THREADS = 256;   // all four waves expand the samples
 
 __device__ __forceinline__ uint4 ray_random(const isdf_sample_args& a, uint32_t ray, uint32_t slot) {
   return philox4x32_10(make_uint4(ray, slot, (uint32_t)a.offset, (uint32_t)(a.offset >> 32)),
                        make_uint2((uint32_t)a.seed, (uint32_t)(a.seed >> 32)));
 }
 
-__global__ __launch_bounds__(1024) void sample_pixels_kernel(const isdf_sample_args a, const isdf_sample_out o) {
-  __shared__ int waveCnt[16];
-  __shared__ int baseSh;
+// scan workspace: [0] ticket, [1] finished chunks, [2] launch epoch, [3] pad (uint32), then one 64-bit state
+// word per chunk.  The last chunk to finish resets ticket/finished and bumps the epoch, so the buffer only
+// has to be zero when it is allocated.
+constexpr unsigned long long ST_AGG = 1ull, ST_INC = 2ull;
+__device__ __forceinline__ unsigned long long st_pack(uint32_t epoch, unsigned long long flag, uint32_t v) {
+  return ((unsigned long long)(epoch & 0x3fffffffu) << 34) | (flag << 32) | v;
+}
+
+__global__ __launch_bounds__(SMP_THREADS) void sample_rays_kernel(const isdf_sample_args a, const isdf_sample_out o,
+                                                                  uint32_t* __restrict__ ws, int nChunks) {
+  __shared__ int sChunk, sBase, sCnt;
+  __shared__ uint32_t sEpoch;
+  __shared__ float sRay[SMP_CHUNK][8];   // depth, origin xyz, dirs_W xyz, pad  (compacted order within the chunk)
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int total = a.n_frames * a.n_rays;
-  if (tid == 0) baseSh = 0;
+  unsigned long long* state = (unsigned long long*)(ws + 4);
+  if (tid == 0) {
+    sEpoch = __hip_atomic_load(ws + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+    sChunk = (int)atomicAdd(ws, 1u);      // dynamic chunk id: logical order == start order
+  }
   __syncthreads();
-  for (int r0 = 0; r0 < total; r0 += 1024) {
-    const int r = r0 + tid;
+  const int c = sChunk;
+  const uint32_t epoch = sEpoch;
+  const int total = a.n_frames * a.n_rays;
+  const int S = a.n_strat + a.n_surf;
+
+  if (wv == 0) {
+    const int r = c * SMP_CHUNK + lane;
     bool valid = false;
     int b = 0, h = 0, wq = 0; float d = 0.f, n0 = 0.f, n1 = 0.f, n2 = 0.f;
+    const float* T = a.T_WC_batch;
     if (r < total) {
       b = r / a.n_rays;  // indices_b = arange(F).repeat_interleave(n_rays), sample.py:18-19
       if (a.rng_mode == 0) { h = (int)a.draw_h[r]; wq = (int)a.draw_w[r]; }
       else { const uint4 u = ray_random(a, (uint32_t)r, 0u); h = (int)(u.x % (uint32_t)a.H); wq = (int)(u.y % (uint32_t)a.W); }
       const int64_t pix = (int64_t)h * a.W + wq;
-      d = a.depth_batch[(int64_t)a.frame_idx[b] * a.H * a.W + pix];
+      const int fi = a.frame_idx[b];
+      const float* np = a.normal_batch ? a.normal_batch + ((int64_t)a.normal_idx[b] * a.H * a.W + pix) * 3 : nullptr;
+      d = a.depth_batch[(int64_t)fi * a.H * a.W + pix];       // both gathers in flight together
+      if (np) { n0 = np[0]; n1 = np[1]; n2 = np[2]; }
+      T += (int64_t)fi * 16;
       valid = d != 0.f;                                       // sample.py:39-40
-      if (a.normal_batch) {
-        const float* np = a.normal_batch + ((int64_t)a.normal_idx[b] * a.H * a.W + pix) * 3;
-        n0 = np[0]; n1 = np[1]; n2 = np[2];
-        valid = valid && !(n0 != n0);                         // sample.py:47-49
-      }
+      if (np) valid = valid && !(n0 != n0);                   // sample.py:47-49
     }
-    // ordered compaction: wave ballot + prefix over the 16 waves
+    // ordered compaction inside the chunk ...
     const unsigned long long m = __ballot(valid);
     const int before = __popcll(m & ((1ull << lane) - 1ull));
-    if (lane == 0) waveCnt[wv] = __popcll(m);
-    __syncthreads();
-    int wbase = baseSh;
-    for (int k = 0; k < wv; ++k) wbase += waveCnt[k];
+    const int cnt = __popcll(m);
+    // ... and across chunks: decoupled look-back
+    int base = 0;
+    if (c == 0) {
+      if (lane == 0) __hip_atomic_store(state, st_pack(epoch, ST_INC, (uint32_t)cnt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      if (lane == 0) __hip_atomic_store(state + c, st_pack(epoch, ST_AGG, (uint32_t)cnt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      int pos = c - 1;
+      while (true) {
+        const int idx = pos - lane;
+        unsigned long long w = 0ull;
+        if (idx >= 0) w = __hip_atomic_load(state + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool ready = idx >= 0 && (uint32_t)(w >> 34) == (epoch & 0x3fffffffu) && ((w >> 32) & 3ull) != 0ull;
+        const bool inc = ready && ((w >> 32) & 3ull) == ST_INC;
+        const unsigned long long rm = __ballot(ready), im = __ballot(inc), vm = __ballot(idx >= 0);
+        const int firstInc = im ? __ffsll((long long)im) - 1 : 63;
+        const unsigned long long need = (firstInc == 63 ? ~0ull : ((2ull << firstInc) - 1ull)) & vm;
+        if ((rm & need) == need) {
+          int v = (need >> lane) & 1ull ? (int)(uint32_t)w : 0;
+#pragma unroll
+          for (int k = 32; k >= 1; k >>= 1) v += __shfl_xor(v, k, 64);
+          base += v;
+          if (im) break;
+          pos -= 64;          // 64 aggregates, no inclusive prefix among them: keep looking back
+        } else {
+          __builtin_amdgcn_s_sleep(2);
+        }
+      }
+      if (lane == 0) __hip_atomic_store(state + c, st_pack(epoch, ST_INC, (uint32_t)(base + cnt)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (lane == 0) { sBase = base; sCnt = cnt; }
+    if (c == nChunks - 1 && lane == 0) *o.n_valid = base + cnt;
     if (valid) {
-      const int q = wbase + before;
+      const int64_t q = base + before;
       o.indices_b[q] = b; o.indices_h[q] = h; o.indices_w[q] = wq;
       o.depth_sample[q] = d;
       if (o.norm_sample) { o.norm_sample[q * 3] = n0; o.norm_sample[q * 3 + 1] = n1; o.norm_sample[q * 3 + 2] = n2; }
       // ray_dirs_C, transform.py:13-33 ('z' depth)
       const float dx = ((float)wq - a.cx) / a.fx, dy = ((float)h - a.cy) / a.fy, dz = 1.f;
       o.dirs_C_sample[q * 3] = dx; o.dirs_C_sample[q * 3 + 1] = dy; o.dirs_C_sample[q * 3 + 2] = dz;
-      const float* T = a.T_WC_batch + (int64_t)a.frame_idx[b] * 16;
-      if (o.T_WC_sample) {
+      float Tm[12];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) o.T_WC_sample[(int64_t)q * 16 + k] = T[k];
+      for (int k = 0; k < 12; ++k) Tm[k] = T[k];
+      if (o.T_WC_sample) {
+        float4* dst = (float4*)(o.T_WC_sample + q * 16);
+        dst[0] = make_float4(Tm[0], Tm[1], Tm[2], Tm[3]); dst[1] = make_float4(Tm[4], Tm[5], Tm[6], Tm[7]);
+        dst[2] = make_float4(Tm[8], Tm[9], Tm[10], Tm[11]); dst[3] = make_float4(T[12], T[13], T[14], T[15]);
       }
       // origin_dirs_W, transform.py:36-41: (R * d).sum(-1), no fused multiply-add
+      float* sr = sRay[before];
+      sr[0] = d;
 #pragma unroll
       for (int i = 0; i < 3; ++i) {
-        const float s = __fadd_rn(__fadd_rn(__fmul_rn(T[i * 4], dx), __fmul_rn(T[i * 4 + 1], dy)), __fmul_rn(T[i * 4 + 2], dz));
+        const float s = __fadd_rn(__fadd_rn(__fmul_rn(Tm[i * 4], dx), __fmul_rn(Tm[i * 4 + 1], dy)), __fmul_rn(Tm[i * 4 + 2], dz));
         o.dirs_W_sample[q * 3 + i] = s;
+        sr[1 + i] = Tm[i * 4 + 3];
+        sr[4 + i] = s;
       }
     }
-    __syncthreads();
-    if (tid == 0) { int s = baseSh; for (int k = 0; k < 16; ++k) s += waveCnt[k]; baseSh = s; }
-    __syncthreads();
   }
-  if (tid == 0) *o.n_valid = baseSh;
-}
+  __syncthreads();
 
-__global__ void sample_along_rays_kernel(const isdf_sample_args a, const isdf_sample_out o) {
-  const int S = a.n_strat + a.n_surf;
-  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t R = *o.n_valid;
-  if (idx >= R * S) return;
-  const int r = (int)(idx / S), s = (int)(idx - (int64_t)r * S);
-  const float depth = o.depth_sample[r];
-  const float maxd = __fadd_rn(depth, a.dist_behind_surf);   // trainer.py:741
-  float z;
-  if (s < a.n_surf) {
-    if (s == 0) z = depth;                                     // sample.py:158
-    else {
-      float off;
-      if (a.rng_mode == 0) off = a.draw_n[(int64_t)r * (a.n_surf - 1) + (s - 1)];
-      else {  // Box-Muller, sigma 0.1 (sample.py:160-162)
-        const uint4 u = ray_random(a, (uint32_t)r, 1u + (uint32_t)s);
-        const float u1 = fmaxf(u01(u.x), 1e-7f), u2 = u01(u.y);
-        off = 0.1f * sqrtf(-2.f * __logf(u1)) * __cosf(6.2831853f * u2);
+  // ---- along-ray samples of the chunk's valid rays: point p of the chunk -> (ray j, sample s); consecutive
+  // threads write consecutive points (sample.py:131-178)
+  const int base = sBase, cnt = sCnt;
+  for (int p = tid; p < cnt * S; p += SMP_THREADS) {
+    const int j = p / S, s = p - j * S;
+    const int64_t r = (int64_t)base + j;             // compacted ray index: the draws are indexed by it
+    const float* sr = sRay[j];
+    const float depth = sr[0];
+    const float maxd = __fadd_rn(depth, a.dist_behind_surf);   // trainer.py:741
+    float z;
+    if (s < a.n_surf) {
+      if (s == 0) z = depth;                                     // sample.py:158
+      else {
+        float off;
+        if (a.rng_mode == 0) off = a.draw_n[r * (a.n_surf - 1) + (s - 1)];
+        else {  // Box-Muller, sigma 0.1 (sample.py:160-162)
+          const uint4 u = ray_random(a, (uint32_t)r, 1u + (uint32_t)s);
+          const float u1 = fmaxf(u01(u.x), 1e-7f), u2 = u01(u.y);
+          off = 0.1f * sqrtf(-2.f * __logf(u1)) * __cosf(6.2831853f * u2);
+        }
+        z = fminf(fmaxf(__fadd_rn(depth, off), a.min_depth), maxd);  // clamp, sample.py:167-171
       }
-      z = fminf(fmaxf(__fadd_rn(depth, off), a.min_depth), maxd);  // clamp, sample.py:167-171
+    } else {
+      const int k = s - a.n_surf, nb = a.n_strat;
+      float U;
+      if (a.rng_mode == 0) U = a.draw_u[r * nb + k];
+      else U = u01(ray_random(a, (uint32_t)r, 64u + (uint32_t)k).x);
+      // torch.linspace(0, 1, nb+1)[k] in fp32 (symmetric evaluation), sample.py:96-98
+      const float step = 1.f / (float)nb;
+      const float lin = k < (nb + 1) / 2 ? __fmul_rn(step, (float)k) : __fadd_rn(1.f, -__fmul_rn(step, (float)(nb - k)));
+      const float range = __fadd_rn(maxd, -a.min_depth);
+      const float lim = __fadd_rn(__fmul_rn(lin, range), a.min_depth);
+      const float blen = range / (float)nb;
+      z = __fadd_rn(lim, __fmul_rn(U, blen));                       // sample.py:123-126
     }
-  } else {
-    const int k = s - a.n_surf, nb = a.n_strat;
-    float U;
-    if (a.rng_mode == 0) U = a.draw_u[(int64_t)r * nb + k];
-    else U = u01(ray_random(a, (uint32_t)r, 64u + (uint32_t)k).x);
-    // torch.linspace(0, 1, nb+1)[k] in fp32 (symmetric evaluation), sample.py:96-98
-    const float step = 1.f / (float)nb;
-    const float lin = k < (nb + 1) / 2 ? __fmul_rn(step, (float)k) : __fadd_rn(1.f, -__fmul_rn(step, (float)(nb - k)));
-    const float range = __fadd_rn(maxd, -a.min_depth);
-    const float lim = __fadd_rn(__fmul_rn(lin, range), a.min_depth);
-    const float blen = range / (float)nb;
-    z = __fadd_rn(lim, __fmul_rn(U, blen));                       // sample.py:123-126
-  }
-  o.z_vals[idx] = z;
-  const int b = (int)o.indices_b[r];
-  const float* T = a.T_WC_batch + (int64_t)a.frame_idx[b] * 16;
+    const int64_t n = r * S + s;
+    o.z_vals[n] = z;
 #pragma unroll
-  for (int i = 0; i < 3; ++i)  // pc = origins + dirs_W * z, sample.py:176
-    o.pc[idx * 3 + i] = __fadd_rn(T[i * 4 + 3], __fmul_rn(o.dirs_W_sample[r * 3 + i], z));
+    for (int i = 0; i < 3; ++i)  // pc = origins + dirs_W * z, sample.py:176
+      o.pc[n * 3 + i] = __fadd_rn(sr[1 + i], __fmul_rn(sr[4 + i], z));
+  }
+
+  // ---- the last chunk to finish re-arms the workspace for the next launch
+  __syncthreads();
+  if (tid == 0) {
+    const uint32_t done = atomicAdd(ws + 1, 1u);
+    if ((int)done == nChunks - 1) {
+      __hip_atomic_store(ws, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(ws + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(ws + 2, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
 }
 
-int launch_sample_pixels(const isdf_sample_args& a, const isdf_sample_out& o, hipStream_t st) {
-  hipLaunchKernelGGL(sample_pixels_kernel, dim3(1), dim3(1024), 0, st, a, o);
-  return isdf_launch_status();
-}
-int launch_sample_along_rays(const isdf_sample_args& a, const isdf_sample_out& o, hipStream_t st) {
-  const int64_t maxPts = (int64_t)a.n_frames * a.n_rays * (a.n_strat + a.n_surf);
-  hipLaunchKernelGGL(sample_along_rays_kernel, dim3((unsigned)((maxPts + 255) / 256)), dim3(256), 0, st, a, o);
+int64_t sample_scan_bytes(int64_t max_rays) { return 16 + 8 * ((max_rays + SMP_CHUNK - 1) / SMP_CHUNK); }
+
+int launch_sample_rays(const isdf_sample_args& a, const isdf_sample_out& o, void* scan_ws, hipStream_t st) {
+  const int total = a.n_frames * a.n_rays;
+  const int nChunks = (total + SMP_CHUNK - 1) / SMP_CHUNK;
+  hipLaunchKernelGGL(sample_rays_kernel, dim3((unsigned)nChunks), dim3(SMP_THREADS), 0, st, a, o, (uint32_t*)scan_ws, nChunks);
   return isdf_launch_status();
 }
 

@@ -70,6 +70,12 @@ def gather_surface_points(pc, n_valid, group=None):
     if group is None and not (torch.distributed.is_available() and torch.distributed.is_initialized()):
         return surf
     world = torch.distributed.get_world_size(group)
+    if torch.distributed.get_backend(group) == "gloo" and surf.is_cuda:
+        # gloo moves device tensors only for broadcast / all_reduce: stage the 12 KB through the host (functional
+        # tests of the N>1 path on a box with fewer GPUs than ranks; RCCL takes the branch below)
+        host = torch.empty(world * R0, 3, dtype=surf.dtype)
+        torch.distributed.all_gather_into_tensor(host, surf.cpu(), group=group)
+        return host.to(surf.device)
     out = torch.empty(world * R0, 3, dtype=surf.dtype, device=surf.device)
     torch.distributed.all_gather_into_tensor(out, surf, group=group)
     return out

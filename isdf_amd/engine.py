@@ -135,6 +135,7 @@ class Engine:
         self.shadow = torch.zeros(int(sb), dtype=torch.uint8, device=self.device)
         self._ws = None
         self._ws_key = None
+        self._scan_ws = None      # sampler look-back state (zero on first use, self re-arming afterwards)
         self.reduce_buf = None
         self.opt_step = 0
         self.slices = {}
@@ -174,7 +175,7 @@ class Engine:
     # ---- K1 sampler ---------------------------------------------------------
     def sample(self, depth_batch, T_WC_batch, normal_batch, frame_idx, normal_idx, sc: SampleConfig,
                draws=None, seed=0, offset=0, want_T=False):
-        """Pass 1 + pass 2 of the sampler.  draws: dict(indices_h, indices_w, U, N_off)
+        """The sampler (one launch).  draws: dict(indices_h, indices_w, U, N_off)
         of device tensors in the reference's shapes (parity mode) or None (Philox)."""
         dev = self.device
         F = int(frame_idx.numel())
@@ -203,7 +204,7 @@ class Engine:
             a.rng_mode = 1
             a.seed, a.offset = int(seed), int(offset)
         out = dict(
-            n_valid=torch.empty(1, dtype=torch.int32, device=dev),   # always written by sample_pixels (no fill launch)
+            n_valid=torch.empty(1, dtype=torch.int32, device=dev),   # always written by the sampler (no fill launch)
             indices_b=torch.empty(R0, dtype=torch.int64, device=dev),
             indices_h=torch.empty(R0, dtype=torch.int64, device=dev),
             indices_w=torch.empty(R0, dtype=torch.int64, device=dev),
@@ -218,8 +219,11 @@ class Engine:
         o = _ffi.SampleOut()
         for k, v in out.items():
             setattr(o, k, None if v is None else v.data_ptr())
-        _ffi.check(self.lib.isdf_sample_pixels(C.byref(a), C.byref(o), _stream()), "isdf_sample_pixels")
-        _ffi.check(self.lib.isdf_sample_along_rays(C.byref(a), C.byref(o), _stream()), "isdf_sample_along_rays")
+        need = int(self.lib.isdf_sample_scan_bytes(R0))
+        if self._scan_ws is None or self._scan_ws.numel() < need:
+            self._scan_ws = torch.zeros(max(need, 4096), dtype=torch.uint8, device=dev)
+        _ffi.check(self.lib.isdf_sample_rays(C.byref(a), C.byref(o), _ffi.ptr(self._scan_ws), self._scan_ws.numel(),
+                                             _stream()), "isdf_sample_rays")
         out["max_rays"] = R0
         out["S"] = S
         out["n_frames"] = F

@@ -52,7 +52,7 @@ def test_invalid_arguments_are_reported_not_crashed(lib):
     from isdf_amd.engine import NetConfig
     bad = NetConfig(blocks=0).to_c()
     assert lib.isdf_param_count(C.byref(bad)) == -1
-    assert lib.isdf_sample_pixels(None, None, None) == -1
+    assert lib.isdf_sample_rays(None, None, None, 0, None) == -1
     assert lib.isdf_adamw(C.byref(NetConfig().to_c()), None, None, None, None, None, 1.0, 1e-3, 0.9, 0.999,
                           1e-8, 0.0, 1, None, None) == -1
 

@@ -1,0 +1,163 @@
+"""The data-parallel step with the REAL kernels under world_size 2 on ONE GPU (`-m gpu`).  RCCL refuses two
+ranks on one device, so the two ranks share cuda:0 and talk over gloo (the collective is the only difference to
+the 8-GPU path: same kernels, same buffers, same call sequence).  Checked:
+
+  * engine level: two ranks, each sampler -> isdf_train_step -> all_reduce(sum) -> isdf_adamw -> frame averages
+    on ITS half of the rays, against ONE process running the union of the two ray sets in a single batch
+    (sums + reduced count reproduce the single-process mean); bounds_method "ray" and "pc"
+    (all-gathered surface set);
+  * trainer level: `HipTrainer(dist_group=...)`: weights broadcast at graft time, rank-0 window indices, one
+    virtual clock, per-frame broadcast in add_frame, rank-independent keyframe test -- the ranks stay
+    bit-identical through steps, a keyframe decision and a frame ingest.
+"""
+import os
+import socket
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+F, NR, H, W = 3, 96, 120, 160
+CAM = dict(H=H, W=W, fx=150.0, fy=150.0, cx=79.5, cy=59.5)
+N_STEPS = 3
+
+
+def _inputs():
+    from isdf_amd import synthetic
+    depth, normal, T = synthetic.keyframes(F, CAM, seed=3, stride=60)
+    rng = np.random.RandomState(17)
+    S = 27
+    # per (step, rank, frame, slot) draws; along-ray draws are assigned to ray SLOTS and compacted by validity
+    # rank 0 draws even columns, rank 1 odd ones: a pixel hit by BOTH ranks would be de-duplicated by the union
+    # run's block bins (loss.py:225-229: last ray wins, counted once) but not across ranks
+    w = 2 * rng.randint(0, W // 2, (N_STEPS, 2, F, NR)) + np.arange(2)[None, :, None, None]
+    draws = dict(h=rng.randint(0, H, (N_STEPS, 2, F, NR)), w=w,
+                 U=rng.uniform(size=(N_STEPS, 2, F, NR, 19)).astype(np.float32),
+                 N=(0.1 * rng.standard_normal((N_STEPS, 2, F, NR, 7))).astype(np.float32),
+                 noise=(0.04 * rng.standard_normal((N_STEPS, 2, F, NR, S))).astype(np.float32))
+    return depth, normal, T, draws
+
+
+def _valid(depth, normal, h, w):
+    f = np.arange(F)[:, None]
+    d = depth[f, h, w]
+    return (d != 0) & ~np.isnan(normal[f, h, w, 0])
+
+
+def _batch(depth, normal, draws, st, ranks):
+    """draw tensors of one step for the given ranks' rays, frame-major (rank-major inside a frame)"""
+    h = np.concatenate([draws["h"][st, r] for r in ranks], axis=1)          # [F, len(ranks)*NR]
+    w = np.concatenate([draws["w"][st, r] for r in ranks], axis=1)
+    ok = _valid(depth, normal, h, w)
+    cat = lambda k: np.concatenate([draws[k][st, r] for r in ranks], axis=1)[ok]
+    return dict(indices_h=h.reshape(-1).astype(np.int64), indices_w=w.reshape(-1).astype(np.int64),
+                U=cat("U"), N_off=cat("N"), noise=cat("noise"))
+
+
+def _run_engine(bounds, ranks, group, out):
+    from isdf_amd.engine import Engine, NetConfig, LossConfig, SampleConfig
+    from isdf_amd import synthetic, dp
+    import oracle.isdf_oracle as orc
+    depth, normal, T, draws = _inputs()
+    eng = Engine(NetConfig(transform=synthetic.bounds_transform()), "cuda:0")
+    eng.load_params(orc.init_params(256, 2, 6, np.random.RandomState(9)))
+    dev = lambda a: torch.as_tensor(np.ascontiguousarray(a)).cuda()
+    d, n, Tt = dev(depth), dev(normal), dev(T)
+    idx = torch.arange(F, dtype=torch.int32, device="cuda")
+    sc = SampleConfig(n_rays=NR * len(ranks), **CAM)
+    lc = LossConfig(bounds_method=bounds)
+    fal = torch.zeros(F, device="cuda")
+    for st in range(N_STEPS):
+        b = _batch(depth, normal, draws, st, ranks)
+        s = eng.sample(d, Tt, n, idx, idx, sc, draws={k: dev(v) for k, v in b.items() if k != "noise"})
+        eng.train_step(s, lc, sc, noise=dev(b["noise"]), surf_group=group if bounds == "pc" else None)
+        if group is not None:
+            dp.allreduce_(eng.reduce_buf, group)
+        eng.frame_avg(F, out=fal, index=idx)
+        eng.adamw()
+    torch.cuda.synchronize()
+    out.update(params=eng.params.cpu().numpy(), m=eng.exp_avg.cpu().numpy(), v=eng.exp_avg_sq.cpu().numpy(),
+               fal=fal.cpu().numpy(), ls=eng.loss_sums().cpu().numpy())
+
+
+def _run_trainer(rank, group, out):
+    import contextlib, io
+    from isdf_amd.trainer import HipTrainer
+    from isdf_amd import synthetic
+    from tests.accuracy_experiment import config
+    cfg = config(CAM)
+    cfg["sample"].update(n_rays=64, n_rays_is_kf=128)
+    cfg["model"].update(iters_per_kf=4, iters_per_frame=2)
+    np.random.seed(100 + rank); torch.manual_seed(100 + rank)        # DIFFERENT host seeds per rank on purpose
+    tr = HipTrainer("cuda:0", cfg, inv_bounds_transform=synthetic.bounds_transform(), rng="philox", seed=4,
+                    dist_group=group)
+    traj = synthetic.trajectory(40)
+    rng = np.random.RandomState(7 + rank)                              # ... and rank-different sensor noise:
+    with contextlib.redirect_stdout(io.StringIO()):                   # rank 0's frame must win (C2 broadcast)
+        for k in range(7):
+            fr = tr.make_frame(k * 5, synthetic.render_depth(traj[k * 5], CAM, rng, noise_std=0.01), traj[k * 5])
+            tr.last_is_keyframe = True
+            tr.add_frame(fr)
+            tr.noise_std = tr.noise_kf
+            for _ in range(3):
+                losses, ms = tr.step()
+        tr.last_is_keyframe = False
+        fr = tr.make_frame(36, synthetic.render_depth(traj[36], CAM, rng, noise_std=0.01), traj[36])
+        tr.add_frame(fr)
+        for _ in range(2):
+            tr.step()
+        add_new = tr.check_keyframe_latest()                          # keyframe test on the frozen net
+    torch.cuda.synchronize()
+    out.update(t_params=tr.engine.params.cpu().numpy(), t_depth_sum=float(tr.frames.depth_batch.double().sum()),
+               t_clock=tr.tot_step_time, t_idxs=np.asarray(tr.active_idxs), t_add_new=bool(add_new),
+               t_kf=bool(tr.last_is_keyframe), t_fal=tr.frames.frame_avg_losses.cpu().numpy(), t_K=len(tr.frames))
+
+
+def _worker(rank, world, port, path):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
+    group = torch.distributed.group.WORLD
+    out = {}
+    for bounds in ("ray", "pc"):
+        o = {}
+        _run_engine(bounds, [rank], group, o)
+        out.update({"%s_%s" % (bounds, k): v for k, v in o.items()})
+    _run_trainer(rank, group, out)
+    np.savez(path % rank, **out)
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_two_ranks_on_one_gpu_match_the_single_process_union_batch():
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    tmp = tempfile.mkdtemp()
+    path = os.path.join(tmp, "rank%d.npz")
+    mp.spawn(_worker, args=(2, port, path), nprocs=2, join=True)
+    r0, r1 = dict(np.load(path % 0)), dict(np.load(path % 1))
+    rel = lambda a, b: float(np.linalg.norm(a.astype(np.float64) - b) / max(np.linalg.norm(b.astype(np.float64)), 1e-30))
+    for bounds in ("ray", "pc"):
+        for k in ("params", "m", "v", "fal", "ls"):                       # replicas stay bit-identical
+            assert np.array_equal(r0["%s_%s" % (bounds, k)], r1["%s_%s" % (bounds, k)]), (bounds, k)
+        single = {}
+        _run_engine(bounds, [0, 1], None, single)                         # ONE process, union of the two ray sets
+        assert single["ls"][4] == r0[bounds + "_ls"][4]                   # same reduced element count
+        np.testing.assert_allclose(r0[bounds + "_ls"][:4], single["ls"][:4], rtol=2e-5)
+        np.testing.assert_allclose(r0[bounds + "_fal"], single["fal"], rtol=2e-4, atol=1e-7)
+        assert rel(r0[bounds + "_m"], single["m"]) < 1e-5, (bounds, rel(r0[bounds + "_m"], single["m"]))
+        assert rel(r0[bounds + "_v"], single["v"]) < 2e-5
+        diff = np.abs(r0[bounds + "_params"] - single["params"])
+        assert (diff > 1e-6).mean() < 1e-3 and diff.max() <= 2 * N_STEPS * 0.0013 + 1e-7, (bounds, (diff > 1e-6).mean(), diff.max())
+    # trainer level: both ranks hold the same network, keyframes (rank 0's frames), clock, window and decisions
+    for k in ("t_params", "t_depth_sum", "t_clock", "t_idxs", "t_add_new", "t_kf", "t_fal", "t_K"):
+        assert np.array_equal(r0[k], r1[k]), k
+    assert int(r0["t_K"]) >= 7 and np.isfinite(r0["t_params"]).all()
