@@ -129,3 +129,91 @@ def train_step(net, opt, depth, T_WC, normals, cam, sc, lc, noise_std, gen):
         p.grad = None
     losses["total_loss"] = total.item()
     return losses, fa
+
+
+class PortTrainer:
+    """The reference `Trainer` as the drivers see it (train.py:86-136), on torch CPU and in-memory frames --
+    TEST INFRASTRUCTURE: the accuracy CONTROL for the HIP path under the reference's own frame schedule
+    (tests/accuracy_experiment.py --backend port --reference-schedule).  Method names, state fields and decision
+    logic follow trainer.py:574-674,951-1016; the arithmetic is the op chain above."""
+
+    def __init__(self, cfg, cam, transform, seed, virtual_step_ms, fps=30):
+        m, s, lo = cfg["model"], cfg["sample"], cfg["loss"]
+        self.cam, self.fps, self.virtual_step_ms = cam, fps, virtual_step_ms
+        self.sc = dict(n_rays=s["n_rays"], n_strat=s["n_strat_samples"], n_surf=s["n_surf_samples"],
+                       min_depth=s["depth_range"][0], dist_behind_surf=s["dist_behind_surf"])
+        self.n_rays_is_kf = s["n_rays_is_kf"]
+        self.lc = dict(trunc_distance=lo["trunc_distance"], loss_type=lo["loss_type"], trunc_weight=lo["trunc_weight"],
+                       eik_apply_dist=lo["eik_apply_dist"], eik_weight=lo["eik_weight"], grad_weight=lo["grad_weight"])
+        self.window_size, self.iters_per_kf, self.iters_per_frame = m["window_size"], m["iters_per_kf"], m["iters_per_frame"]
+        self.noise_std, self.noise_kf, self.noise_frame = m["noise_std"], m["noise_kf"], m["noise_frame"]
+        self.kf_dist_th, self.kf_pixel_ratio = m["kf_dist_th"], m["kf_pixel_ratio"]
+        self.frac_time_perception = m["frac_time_perception"]
+        self.net = PortNet(m["hidden_feature_size"], m["hidden_layers_block"], m["embedding"]["n_embed_funcs"] + 1,
+                           m["embedding"]["scale_input"], m["scale_output"], transform)
+        self.opt = torch.optim.AdamW(self.net.parameters(), lr=cfg["optimiser"]["lr"],
+                                     weight_decay=cfg["optimiser"]["weight_decay"])
+        self.gen = torch.Generator().manual_seed(seed)
+        self.tot_step_time, self.steps_since_frame, self.optim_frames, self.last_is_keyframe = 0.0, 0, 0, False
+        self.frame_id, self.depth, self.T, self.normals = [], None, None, None
+        self.fal = torch.zeros(0)
+        self.frozen = None
+
+    def get_latest_frame_id(self):
+        return int(self.tot_step_time * self.fps)
+
+    def add_frame(self, frame):
+        """frame = (id, depth [H,W], T_WC [4,4], normals [H,W,3]) as torch tensors"""
+        import copy
+        if self.last_is_keyframe:
+            self.frozen = copy.deepcopy(self.net)
+        fid, d, T, n = frame
+        replace = self.last_is_keyframe is False and len(self.frame_id) > 0
+        if replace:
+            self.frame_id[-1] = fid; self.depth[-1] = d; self.T[-1] = T; self.normals[-1] = n; self.fal[-1] = 0.0
+        else:
+            cat = lambda a, b: b[None] if a is None else torch.cat((a, b[None]))
+            self.frame_id.append(fid)
+            self.depth, self.T, self.normals = cat(self.depth, d), cat(self.T, T), cat(self.normals, n)
+            self.fal = torch.cat((self.fal, torch.zeros(1)))
+        self.steps_since_frame, self.last_is_keyframe = 0, False
+        self.optim_frames, self.noise_std = self.iters_per_frame, self.noise_frame
+
+    def is_keyframe(self):
+        from .isdf_oracle import keyframe_ratio
+        sc = dict(self.sc, n_rays=self.n_rays_is_kf, dist_behind_surf=0.8)
+        s = sample_step(self.depth[-1:], self.T[-1:], self.normals[-1:], self.cam, sc, self.gen)
+        with torch.no_grad():
+            noise = None if self.noise_std is None else torch.randn(s["pc"].shape[:-1], generator=self.gen) * self.noise_std
+            sdf = self.frozen(s["pc"], noise)
+        ratio, _ = keyframe_ratio(s["z"].numpy(), sdf.numpy(), s["depth"].numpy(), self.kf_dist_th)
+        return ratio < self.kf_pixel_ratio
+
+    def check_keyframe_latest(self):
+        add_new_frame = False
+        if self.last_is_keyframe:
+            add_new_frame = True
+        else:
+            self.last_is_keyframe = bool(self.is_keyframe())
+            if self.tot_step_time - self.frame_id[-2] / 30. > 5.:
+                self.last_is_keyframe = True
+            if self.last_is_keyframe:
+                self.optim_frames, self.noise_std = self.iters_per_kf, self.noise_kf
+            else:
+                add_new_frame = True
+        return add_new_frame
+
+    def step(self):
+        K = len(self.frame_id)
+        if K > self.window_size:       # select_keyframes, trainer.py:652-674
+            p = (self.fal[:-2] / self.fal[:-2].sum()).numpy()
+            idxs = [*np.random.choice(np.arange(0, K - 2), size=self.window_size - 2, replace=False, p=p), K - 2, K - 1]
+        else:
+            idxs = list(range(K))
+        # quirk q4: normals come from the un-windowed batch with window-local indices
+        losses, fa = train_step(self.net, self.opt, self.depth[idxs], self.T[idxs], self.normals[:len(idxs)], self.cam,
+                                self.sc, self.lc, self.noise_std, self.gen)
+        self.fal[idxs] = fa
+        self.tot_step_time += (1 / self.frac_time_perception) * self.virtual_step_ms / 1000.0
+        self.steps_since_frame += 1
+        return losses, self.virtual_step_ms

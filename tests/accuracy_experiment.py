@@ -112,6 +112,37 @@ def run_hip_reference_schedule(seed, cam, n_steps=1200, virtual_step_ms=20.0, n_
     return fn, float(losses["total_loss"]), depth, T, ids, n
 
 
+def run_port_reference_schedule(seed, cam, n_steps=1200, virtual_step_ms=20.0, n_frames=600, threads=None):
+    """CONTROL for run_hip_reference_schedule: the reference's op chain on torch CPU (oracle/torch_port.PortTrainer)
+    under the same driver loop, stream, seeds and pinned virtual clock."""
+    import contextlib, io
+    import oracle.isdf_oracle as orc
+    from oracle.torch_port import PortTrainer
+    from tests.driver_loop import run_train_loop
+    if threads:
+        torch.set_num_threads(threads)
+    np.random.seed(seed); torch.manual_seed(seed)
+    torch.set_flush_denormal(True)
+    tr = PortTrainer(config(cam), cam, synthetic.bounds_transform(), seed, virtual_step_ms)
+    traj = synthetic.trajectory(n_frames)
+    rng = np.random.RandomState(seed)
+    seen = {}
+
+    def frame(i):
+        if i not in seen:
+            seen[i] = synthetic.render_depth(traj[i], cam, rng, noise_std=0.01)
+        pc = orc.pointcloud_from_depth(seen[i], cam["fx"], cam["fy"], cam["cx"], cam["cy"])
+        nrm = orc.estimate_pointcloud_normals(pc).astype(np.float32)
+        return (i, torch.from_numpy(seen[i]), torch.from_numpy(traj[i]), torch.from_numpy(nrm))
+    with contextlib.redirect_stdout(io.StringIO()):
+        n, ingests, losses = run_train_loop(tr, frame, n_frames, n_steps)
+    ids = [int(i) for i in tr.frame_id]
+    depth = np.stack([seen[i] for i in ids]); T = np.stack([traj[i] for i in ids])
+    with torch.no_grad():
+        fn = lambda p: tr.net(torch.from_numpy(p.astype(np.float32))).detach().numpy()
+    return fn, float(losses["total_loss"]), depth, T, ids, n
+
+
 def run_port(seed, depth, normal, T, cam, steps_per_kf):
     from oracle import torch_port as tp
     np.random.seed(seed); torch.manual_seed(seed)
@@ -151,7 +182,7 @@ def main():
     ap.add_argument("--steps-per-kf", type=int, default=60)
     ap.add_argument("--out", default=None)
     ap.add_argument("--reference-schedule", action="store_true",
-                    help="hip only: reference driver frame scheduling + keyframe test instead of the pinned schedule")
+                    help="reference driver frame scheduling + keyframe test (train.py:86-136) instead of the pinned schedule")
     ap.add_argument("--steps", type=int, default=1200)
     ap.add_argument("--virtual-step-ms", type=float, default=20.0)
     a = ap.parse_args()
@@ -159,9 +190,11 @@ def main():
     res = []
     if a.reference_schedule:
         for seed in a.seeds:
-            fn, last, depth, T, ids, n = run_hip_reference_schedule(seed, cam, a.steps, a.virtual_step_ms)
+            run = run_hip_reference_schedule if a.backend == "hip" else run_port_reference_schedule
+            fn, last, depth, T, ids, n = run(seed, cam, a.steps, a.virtual_step_ms)
             pts, surf = eval_points(depth, T, cam, np.random.RandomState(1000 + seed), n_per_frame=8000)
-            r = dict(backend="hip", schedule="reference", seed=seed, steps=n, keyframe_ids=ids,
+            r = dict(backend=a.backend, schedule="reference", seed=seed, steps=n, virtual_step_ms=a.virtual_step_ms,
+                     keyframe_ids=ids,
                      l1_visible_m=round(float(np.abs(fn(pts) - synthetic.gt_sdf(pts)).mean()), 5),
                      l1_surface_m=round(float(np.abs(fn(surf) - synthetic.gt_sdf(surf)).mean()), 5),
                      final_total_loss=round(last, 5))

@@ -1,0 +1,33 @@
+"""numpy model of the chain kernel's FORWARD numerics (TEST INFRASTRUCTURE): every GEMM operand -- weights,
+embedding, activations -- rounded to the 16-bit MFMA operand type, fp32 accumulation, fp32 element-wise math,
+the output layer as an fp32 dot product (isdf_amd/csrc/chain.hip).  It separates "the kernel computes what its
+design says" (HIP vs this model: accumulation order and transcendental approximations only) from the operand
+rounding floor of that design (this model vs the fp32 reference)."""
+import numpy as np
+
+import oracle.isdf_oracle as orc
+
+
+def f16(x):
+    return np.asarray(x, np.float32).astype(np.float16).astype(np.float32)
+
+
+def bf16(x):
+    x = np.ascontiguousarray(x, np.float32)
+    u = x.view(np.uint32)
+    r = (u + 0x7fff + ((u >> 16) & 1)) & 0xffff0000
+    return r.astype(np.uint32).view(np.float32)
+
+
+def forward(params, cfg, x, operand="fp16"):
+    q = f16 if operand == "fp16" else bf16
+    x = np.asarray(x, np.float32).reshape(-1, 3)
+    e = q(orc.positional_encoding(x, cfg.transform, cfg.scale_input, cfg.n_freqs))
+    a = e
+    for li, n in enumerate(cfg.names):
+        inp = np.concatenate([a, e], -1) if li == cfg.cat else a
+        z = inp @ q(params[n + ".weight"]).T + params[n + ".bias"]
+        af = orc.softplus(z)
+        a = q(af)
+    raw = af @ params["out_alpha.weight"][0] + params["out_alpha.bias"][0]
+    return raw * np.float32(cfg.scale_output)

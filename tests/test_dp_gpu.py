@@ -79,6 +79,8 @@ def _run_engine(bounds, ranks, group, out):
         if group is not None:
             dp.allreduce_(eng.reduce_buf, group)
         eng.frame_avg(F, out=fal, index=idx)
+        if st == 0:
+            out.update(g1=eng.reduce_buf[:eng.n_params].cpu().numpy())      # first-step gradient SUMS
         eng.adamw()
     torch.cuda.synchronize()
     out.update(params=eng.params.cpu().numpy(), m=eng.exp_avg.cpu().numpy(), v=eng.exp_avg_sq.cpu().numpy(),
@@ -146,17 +148,24 @@ def test_two_ranks_on_one_gpu_match_the_single_process_union_batch():
     r0, r1 = dict(np.load(path % 0)), dict(np.load(path % 1))
     rel = lambda a, b: float(np.linalg.norm(a.astype(np.float64) - b) / max(np.linalg.norm(b.astype(np.float64)), 1e-30))
     for bounds in ("ray", "pc"):
-        for k in ("params", "m", "v", "fal", "ls"):                       # replicas stay bit-identical
+        for k in ("params", "m", "v", "fal", "ls", "g1"):                 # replicas stay bit-identical
             assert np.array_equal(r0["%s_%s" % (bounds, k)], r1["%s_%s" % (bounds, k)]), (bounds, k)
         single = {}
         _run_engine(bounds, [0, 1], None, single)                         # ONE process, union of the two ray sets
         assert single["ls"][4] == r0[bounds + "_ls"][4]                   # same reduced element count
         np.testing.assert_allclose(r0[bounds + "_ls"][:4], single["ls"][:4], rtol=2e-5)
         np.testing.assert_allclose(r0[bounds + "_fal"], single["fal"], rtol=2e-4, atol=1e-7)
-        assert rel(r0[bounds + "_m"], single["m"]) < 1e-5, (bounds, rel(r0[bounds + "_m"], single["m"]))
-        assert rel(r0[bounds + "_v"], single["v"]) < 2e-5
+        # first step: the all-reduced gradient sums ARE the union batch's sums up to fp32 re-association (the
+        # per-point terms are bit-identical, the tile partition differs)
+        assert rel(r0[bounds + "_g1"], single["g1"]) < 2e-5, (bounds, rel(r0[bounds + "_g1"], single["g1"]))
+        # three steps: AdamW's early updates are ~lr*sign(g), so a 1e-6 relative difference in a near-zero gradient
+        # element can move that parameter by up to 2*lr and the trajectories drift apart at the 1e-4 level
+        # (measured 1.5e-4 on exp_avg); judged on the moments, which are linear / quadratic in the gradients
+        assert rel(r0[bounds + "_m"], single["m"]) < 1e-3, (bounds, rel(r0[bounds + "_m"], single["m"]))
+        assert rel(r0[bounds + "_v"], single["v"]) < 2e-3
         diff = np.abs(r0[bounds + "_params"] - single["params"])
-        assert (diff > 1e-6).mean() < 1e-3 and diff.max() <= 2 * N_STEPS * 0.0013 + 1e-7, (bounds, (diff > 1e-6).mean(), diff.max())
+        assert diff.max() <= 2 * N_STEPS * 0.0013 + 1e-7 and rel(r0[bounds + "_params"], single["params"]) < 1e-3, \
+            (bounds, diff.max(), rel(r0[bounds + "_params"], single["params"]))
     # trainer level: both ranks hold the same network, keyframes (rank 0's frames), clock, window and decisions
     for k in ("t_params", "t_depth_sum", "t_clock", "t_idxs", "t_add_new", "t_kf", "t_fal", "t_K"):
         assert np.array_equal(r0[k], r1[k]), k
