@@ -31,6 +31,12 @@ namespace isdf {
 #ifndef GEMM_ROLLING_REFILL
 #define GEMM_ROLLING_REFILL 0
 #endif
+#ifndef ISDF_PRIO_MODE
+#define ISDF_PRIO_MODE 0
+#endif
+#ifndef ISDF_NT_DW_TENSORS
+#define ISDF_NT_DW_TENSORS 1   // 0: the tensors only the dW kernel re-reads (GB, ZB) are stored with the default cache policy
+#endif
 #ifndef GEMM_LDS_DEPTH
 #define GEMM_LDS_DEPTH 1   // k-steps of activation-operand LDS reads in flight ahead of the MFMAs
 #endif
@@ -103,14 +109,26 @@ __device__ __forceinline__ i32x4 make_srd(const void* base, uint32_t bytes) {
 }
 #define ISDF_BSTORE16_NT(IMM) \
   asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen offset:" #IMM " nt\n\ts_nop 1" ::"v"(v), "v"(voff), "s"(srd), "s"(soff) : "memory")
+#define ISDF_BSTORE16_DF(IMM) \
+  asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen offset:" #IMM "\n\ts_nop 1" ::"v"(v), "v"(voff), "s"(srd), "s"(soff) : "memory")
+template <bool NT = true>
 __device__ __forceinline__ void bstore16_nt(uint4 x, i32x4 srd, int voff, int soff, int c) {
   u32x4 v; v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w;
   soff += (c >> 2) * 4096;
-  switch (c & 3) {
-    case 0: ISDF_BSTORE16_NT(0); break;
-    case 1: ISDF_BSTORE16_NT(1024); break;
-    case 2: ISDF_BSTORE16_NT(2048); break;
-    default: ISDF_BSTORE16_NT(3072); break;
+  if (NT) {
+    switch (c & 3) {
+      case 0: ISDF_BSTORE16_NT(0); break;
+      case 1: ISDF_BSTORE16_NT(1024); break;
+      case 2: ISDF_BSTORE16_NT(2048); break;
+      default: ISDF_BSTORE16_NT(3072); break;
+    }
+  } else {
+    switch (c & 3) {
+      case 0: ISDF_BSTORE16_DF(0); break;
+      case 1: ISDF_BSTORE16_DF(1024); break;
+      case 2: ISDF_BSTORE16_DF(2048); break;
+      default: ISDF_BSTORE16_DF(3072); break;
+    }
   }
 }
 
@@ -322,6 +340,24 @@ __global__ __launch_bounds__(chain_nw(HD) * 64, (HD <= 256 && EP == HD && chain_
     ++tsn;
   };
   TS();
+  // Issue priority between the two workgroups of a CU (A/B switch ISDF_PRIO_MODE): with equal priority
+  // the OLDER workgroup's waves win VALU/MFMA arbitration all the way, finish ~33 us early and leave the younger one
+  // to run the rest alone at the poor single-workgroup rate.  `gen` = which round of 256 workgroups this one was
+  // dispatched in (the second workgroup of a CU when the grid is <= 512).
+  const bool genOdd = (blockIdx.x >> 8) & 1;
+  auto PRIO = [&](int phase) {   // phase 0 fwd, 1 first reverse, 2 adjoint, 3 reverse
+#if ISDF_PRIO_MODE == 1
+    if (genOdd) { if (phase == 1 || phase == 2) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
+#elif ISDF_PRIO_MODE == 2
+    if (genOdd) __builtin_amdgcn_s_setprio(1);
+#elif ISDF_PRIO_MODE == 3
+    if (genOdd) { if (phase >= 2) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
+#elif ISDF_PRIO_MODE == 4
+    if (genOdd) { if (phase == 0 || phase == 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
+#endif
+    (void)phase;
+  };
+  PRIO(0);
   // debug: wall-clock (s_memrealtime, 100 MHz) start/end of every 4th workgroup -> slots 128..511
   if (p.dbg_times && tid == 0 && (blockIdx.x & 3) == 0 && blockIdx.x < 4 * 190)
     p.dbg_times[128 + blockIdx.x / 2] = __builtin_amdgcn_s_memrealtime();
@@ -470,6 +506,11 @@ __global__ __launch_bounds__(chain_nw(HD) * 64, (HD <= 256 && EP == HD && chain_
     const uint2 a = pack4<false>(v[0], v[1], v[2], v[3]), b = pack4<false>(v[4], v[5], v[6], v[7]);
     bstore16_nt(make_uint4(a.x, a.y, b.x, b.y), srdS, lane16, sbase(tensorOff), cidx(fb, pb, qp));
   };
+  // tensors that only the dW kernel re-reads (GB, ZB): cache policy is an A/B switch
+  auto store_tile8_dw = [&](int64_t tensorOff, int fb, int pb, int qp, const float (&v)[8]) {
+    const uint2 a = pack4<false>(v[0], v[1], v[2], v[3]), b = pack4<false>(v[4], v[5], v[6], v[7]);
+    bstore16_nt<ISDF_NT_DW_TENSORS != 0>(make_uint4(a.x, a.y, b.x, b.y), srdS, lane16, sbase(tensorOff), cidx(fb, pb, qp));
+  };
   auto put_x = [&](bool f16, int fb, int pb, int qp, const float (&v)[8], int colElemBase) {
     uint2 a, b;
     if (f16) { a = pack4<true>(v[0], v[1], v[2], v[3]); b = pack4<true>(v[4], v[5], v[6], v[7]); }
@@ -560,6 +601,7 @@ __global__ __launch_bounds__(chain_nw(HD) * 64, (HD <= 256 && EP == HD && chain_
   if (MODE == 0) return;
 
   // ------------------------------------------------------------------ first reverse sweep
+  PRIO(1);
   for (int li = L.L - 1; li >= 1; --li) {
     Pre preA;
     zero_acc(acc);
@@ -849,6 +891,7 @@ __global__ __launch_bounds__(chain_nw(HD) * 64, (HD <= 256 && EP == HD && chain_
   // The top layer's epilogue also IS the top of the ordinary reverse sweep (zbar_L needs only a_L, the
   // injection just computed and sbar*w_out), so INJ[L-1] never leaves registers and the reverse sweep
   // starts at layer L-2 with its operand already in the X tile.
+  PRIO(2);
   auto adj_gemm = [&](int li, auto&& pf0, auto&& pf) {
     zero_acc(acc);
     refresh();
@@ -879,7 +922,7 @@ __global__ __launch_bounds__(chain_nw(HD) * 64, (HD <= 256 && EP == HD && chain_
       }
       store_tile8(p.sp.INJ[li], fb, pb, qp, inj);
       put_x(false, fb, pb, qp, qb, 0);
-      store_tile8(p.sp.GB[li + 1], fb, pb, qp, qb);
+      store_tile8_dw(p.sp.GB[li + 1], fb, pb, qp, qb);
     });
     TS();
     lds_barrier();
@@ -915,7 +958,7 @@ __global__ __launch_bounds__(chain_nw(HD) * 64, (HD <= 256 && EP == HD && chain_
         bsum[e] += zb[e];
         wsum[e] += sb * a[e];
       }
-      store_tile8(p.sp.ZB[li], fb, pb, qp, zb);
+      store_tile8_dw(p.sp.ZB[li], fb, pb, qp, zb);
       if (li > 0) put_x(false, fb, pb, qp, zb, 0);
     }, [&](int fb, int qp) {
 #pragma unroll
@@ -933,6 +976,7 @@ __global__ __launch_bounds__(chain_nw(HD) * 64, (HD <= 256 && EP == HD && chain_
   }
 
   // ------------------------------------------------------------------ ordinary reverse sweep with injection
+  PRIO(3);
   for (int li = L.L - 2; li >= 0; --li) {
     Pre preA, preI;
     auto pf0 = [&] { prefetch(p.sp.A[li + 1], preA); };
@@ -956,7 +1000,7 @@ __global__ __launch_bounds__(chain_nw(HD) * 64, (HD <= 256 && EP == HD && chain_
         zb[e] = acc[fb][pb][8 * qp + e] * s1_from_a(a[e]) + inj[e];
         bsum[e] += zb[e];
       }
-      store_tile8(p.sp.ZB[li], fb, pb, qp, zb);
+      store_tile8_dw(p.sp.ZB[li], fb, pb, qp, zb);
       if (li > 0) put_x(false, fb, pb, qp, zb, 0);
     }, [&](int fb, int qp) {
 #pragma unroll

@@ -12,21 +12,27 @@
 // ONE launch.  A workgroup (256 threads) takes a chunk of 64 drawn rays: wave 0
 // draws / reads the pixel, gathers depth + normal (one 4-B and one 12-B random
 // read per ray -- the only reads of the keyframe buffers), decides validity and
-// compacts with a ballot; the chunk's offset in the ORDERED output comes from a
-// decoupled look-back over the chunks before it (8-byte {epoch, flag, count}
-// granules, agent-scope stores / polls; chunk ids are handed out by an atomic
-// ticket so a chunk never waits for one that has not started).  All four waves
+// compacts with a ballot; the chunk's offset in the ORDERED output comes, at
+// streaming sizes, from a decoupled look-back over the chunks before it (8-byte
+// {epoch, flag, count} granules, agent-scope stores / polls; chunk ids are
+// handed out by an atomic ticket so a chunk never waits for one that has not
+// started) and, at the reference batch size (<= 4096 rays), from the workgroup
+// re-counting the valid rays before its chunk itself (no communication, one
+// memory round trip).  All four waves
 // then expand the chunk's valid rays into their S samples (z values + world
 // points) with consecutive lanes on consecutive points, i.e. fully coalesced
 // 4-B / 12-B stores: that is where 86 % of the bytes go (432 of 500 B per ray).
 // At the reference batch (1000 rays) this is 16 workgroups and latency-bound;
 // at >= 1e6 rays it is a streaming kernel (bench.py --sampler-scale).
+#include <cstdlib>
 #include "isdf_common.h"
 
 namespace isdf {
 
 constexpr int SMP_CHUNK = 64;      // rays per workgroup (one wave gathers and compacts them)
-constexpr int SMP_THREADS = 256;   // all four waves expand the samples
+constexpr int SMP_THREADS = 256;   // streaming mode: all four waves expand the samples
+constexpr int SMP_THREADS_SMALL = 1024;   // reference-batch mode: 16 waves re-count the preceding rays in one round
+constexpr int SMP_SMALL_SLOTS = 4;        // rays per thread in that count => up to 4096 rays
 
 __device__ __forceinline__ uint4 ray_random(const isdf_sample_args& a, uint32_t ray, uint32_t slot) {
   return philox4x32_10(make_uint4(ray, slot, (uint32_t)a.offset, (uint32_t)(a.offset >> 32)),
@@ -41,28 +47,56 @@ __device__ __forceinline__ unsigned long long st_pack(uint32_t epoch, unsigned l
   return ((unsigned long long)(epoch & 0x3fffffffu) << 34) | (flag << 32) | v;
 }
 
-__global__ __launch_bounds__(SMP_THREADS) void sample_rays_kernel(const isdf_sample_args a, const isdf_sample_out o,
+// validity of drawn ray r (the pixel draw and the two gathers of sample.py:11-55) -- what decides the compaction
+__device__ __forceinline__ bool ray_valid(const isdf_sample_args& a, int r) {
+  const int b = r / a.n_rays;
+  int h, wq;
+  if (a.rng_mode == 0) { h = (int)a.draw_h[r]; wq = (int)a.draw_w[r]; }
+  else { const uint4 u = ray_random(a, (uint32_t)r, 0u); h = (int)(u.x % (uint32_t)a.H); wq = (int)(u.y % (uint32_t)a.W); }
+  const int64_t pix = (int64_t)h * a.W + wq;
+  const float d = a.depth_batch[(int64_t)a.frame_idx[b] * a.H * a.W + pix];
+  bool valid = d != 0.f;
+  if (a.normal_batch) {
+    const float n0 = a.normal_batch[((int64_t)a.normal_idx[b] * a.H * a.W + pix) * 3];
+    valid = valid && !(n0 != n0);
+  }
+  return valid;
+}
+
+// SMALL: the reference batch (a few thousand rays, latency-bound): chunk id = blockIdx and every workgroup
+// counts the valid rays BEFORE its chunk itself (waves 1-3 re-gather the preceding rays while wave 0 gathers the
+// chunk: ONE memory round trip, no inter-workgroup traffic, no workspace).  !SMALL: streaming sizes: atomic
+// ticket + decoupled look-back.
+template <bool SMALL>
+__global__ __launch_bounds__(SMALL ? SMP_THREADS_SMALL : SMP_THREADS) void sample_rays_kernel(const isdf_sample_args a, const isdf_sample_out o,
                                                                   uint32_t* __restrict__ ws, int nChunks) {
+  constexpr int NT = SMALL ? SMP_THREADS_SMALL : SMP_THREADS;
   __shared__ int sChunk, sBase, sCnt;
   __shared__ uint32_t sEpoch;
+  __shared__ int sPre[SMP_THREADS_SMALL / 64];
   __shared__ float sRay[SMP_CHUNK][8];   // depth, origin xyz, dirs_W xyz, pad  (compacted order within the chunk)
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   unsigned long long* state = (unsigned long long*)(ws + 4);
-  if (tid == 0) {
-    sEpoch = __hip_atomic_load(ws + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
-    sChunk = (int)atomicAdd(ws, 1u);      // dynamic chunk id: logical order == start order
-  }
-  __syncthreads();
-  const int c = sChunk;
-  const uint32_t epoch = sEpoch;
   const int total = a.n_frames * a.n_rays;
   const int S = a.n_strat + a.n_surf;
+  int c = blockIdx.x;
+  uint32_t epoch = 0;
+  if (!SMALL) {
+    if (tid == 0) {
+      sEpoch = __hip_atomic_load(ws + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+      sChunk = (int)atomicAdd(ws, 1u);      // dynamic chunk id: logical order == start order
+    }
+    __syncthreads();
+    c = sChunk;
+    epoch = sEpoch;
+  }
 
+  // ---- wave 0: the chunk's own rays
+  bool valid = false;
+  int b = 0, h = 0, wq = 0, before = 0, cnt = 0; float d = 0.f, n0 = 0.f, n1 = 0.f, n2 = 0.f;
+  const float* T = a.T_WC_batch;
   if (wv == 0) {
     const int r = c * SMP_CHUNK + lane;
-    bool valid = false;
-    int b = 0, h = 0, wq = 0; float d = 0.f, n0 = 0.f, n1 = 0.f, n2 = 0.f;
-    const float* T = a.T_WC_batch;
     if (r < total) {
       b = r / a.n_rays;  // indices_b = arange(F).repeat_interleave(n_rays), sample.py:18-19
       if (a.rng_mode == 0) { h = (int)a.draw_h[r]; wq = (int)a.draw_w[r]; }
@@ -76,15 +110,36 @@ __global__ __launch_bounds__(SMP_THREADS) void sample_rays_kernel(const isdf_sam
       valid = d != 0.f;                                       // sample.py:39-40
       if (np) valid = valid && !(n0 != n0);                   // sample.py:47-49
     }
-    // ordered compaction inside the chunk ...
+    // ordered compaction inside the chunk
     const unsigned long long m = __ballot(valid);
-    const int before = __popcll(m & ((1ull << lane) - 1ull));
-    const int cnt = __popcll(m);
-    // ... and across chunks: decoupled look-back
+    before = __popcll(m & ((1ull << lane) - 1ull));
+    cnt = __popcll(m);
+  }
+  if (SMALL) {
+    // ---- all 16 waves: how many of the c*64 rays before this chunk are valid.  Fixed slots, straight-line code:
+    // every thread's (up to 4) pixel reads and gathers are in flight together with wave 0's own -- one round trip
+    int n = 0;
+#pragma unroll
+    for (int k = 0; k < SMP_SMALL_SLOTS; ++k) {
+      const int r = tid + k * NT;
+      if (r < c * SMP_CHUNK) n += ray_valid(a, r) ? 1 : 0;
+    }
+#pragma unroll
+    for (int k = 32; k >= 1; k >>= 1) n += __shfl_xor(n, k, 64);
+    if (lane == 0) sPre[wv] = n;
+    __syncthreads();
+  }
+
+  if (wv == 0) {
     int base = 0;
-    if (c == 0) {
+    if (SMALL) {
+      int v = lane < NT / 64 ? sPre[lane] : 0;
+#pragma unroll
+      for (int k = 8; k >= 1; k >>= 1) v += __shfl_xor(v, k, 64);
+      base = __shfl(v, 0, 64);
+    } else if (c == 0) {
       if (lane == 0) __hip_atomic_store(state, st_pack(epoch, ST_INC, (uint32_t)cnt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else {
+    } else {   // decoupled look-back over the chunks before this one
       if (lane == 0) __hip_atomic_store(state + c, st_pack(epoch, ST_AGG, (uint32_t)cnt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       int pos = c - 1;
       while (true) {
@@ -143,8 +198,8 @@ __global__ __launch_bounds__(SMP_THREADS) void sample_rays_kernel(const isdf_sam
 
   // ---- along-ray samples of the chunk's valid rays: point p of the chunk -> (ray j, sample s); consecutive
   // threads write consecutive points (sample.py:131-178)
-  const int base = sBase, cnt = sCnt;
-  for (int p = tid; p < cnt * S; p += SMP_THREADS) {
+  const int base = sBase, cnt_ = sCnt;
+  for (int p = tid; p < cnt_ * S; p += NT) {
     const int j = p / S, s = p - j * S;
     const int64_t r = (int64_t)base + j;             // compacted ray index: the draws are indexed by it
     const float* sr = sRay[j];
@@ -183,6 +238,7 @@ __global__ __launch_bounds__(SMP_THREADS) void sample_rays_kernel(const isdf_sam
       o.pc[n * 3 + i] = __fadd_rn(sr[1 + i], __fmul_rn(sr[4 + i], z));
   }
 
+  if (SMALL) return;
   // ---- the last chunk to finish re-arms the workspace for the next launch
   __syncthreads();
   if (tid == 0) {
@@ -195,12 +251,17 @@ __global__ __launch_bounds__(SMP_THREADS) void sample_rays_kernel(const isdf_sam
   }
 }
 
+constexpr int SMP_SMALL_MAX_CHUNKS = SMP_THREADS_SMALL * SMP_SMALL_SLOTS / SMP_CHUNK;   // <= 4096 rays
+
 int64_t sample_scan_bytes(int64_t max_rays) { return 16 + 8 * ((max_rays + SMP_CHUNK - 1) / SMP_CHUNK); }
 
 int launch_sample_rays(const isdf_sample_args& a, const isdf_sample_out& o, void* scan_ws, hipStream_t st) {
   const int total = a.n_frames * a.n_rays;
   const int nChunks = (total + SMP_CHUNK - 1) / SMP_CHUNK;
-  hipLaunchKernelGGL(sample_rays_kernel, dim3((unsigned)nChunks), dim3(SMP_THREADS), 0, st, a, o, (uint32_t*)scan_ws, nChunks);
+  if (nChunks <= SMP_SMALL_MAX_CHUNKS && !getenv("ISDF_SAMPLER_FORCE_LOOKBACK"))
+    hipLaunchKernelGGL(sample_rays_kernel<true>, dim3((unsigned)nChunks), dim3(SMP_THREADS_SMALL), 0, st, a, o, (uint32_t*)scan_ws, nChunks);
+  else
+    hipLaunchKernelGGL(sample_rays_kernel<false>, dim3((unsigned)nChunks), dim3(SMP_THREADS), 0, st, a, o, (uint32_t*)scan_ws, nChunks);
   return isdf_launch_status();
 }
 
