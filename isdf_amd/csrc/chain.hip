@@ -32,10 +32,13 @@ namespace isdf {
 #define GEMM_ROLLING_REFILL 0
 #endif
 #ifndef ISDF_PRIO_MODE
-#define ISDF_PRIO_MODE 0
+#define ISDF_PRIO_MODE 1
 #endif
 #ifndef ISDF_NT_DW_TENSORS
-#define ISDF_NT_DW_TENSORS 1   // 0: the tensors only the dW kernel re-reads (GB, ZB) are stored with the default cache policy
+#define ISDF_NT_DW_TENSORS 0   // 0: the tensors only the dW kernel re-reads (GB, ZB) are stored with the default cache policy
+#endif
+#ifndef ISDF_NT_P
+#define ISDF_NT_P 1            // 0: P (d sdf / d z) stored with the default cache policy
 #endif
 #ifndef GEMM_LDS_DEPTH
 #define GEMM_LDS_DEPTH 1   // k-steps of activation-operand LDS reads in flight ahead of the MFMAs
@@ -354,6 +357,12 @@ __global__ __launch_bounds__(chain_nw(HD) * 64, (HD <= 256 && EP == HD && chain_
     if (genOdd) { if (phase >= 2) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
 #elif ISDF_PRIO_MODE == 4
     if (genOdd) { if (phase == 0 || phase == 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
+#elif ISDF_PRIO_MODE == 5
+    if (genOdd) { if (phase >= 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
+#elif ISDF_PRIO_MODE == 6
+    if (genOdd) { if (phase <= 2) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
+#elif ISDF_PRIO_MODE == 7
+    if (genOdd) { if (phase == 1 || phase == 3) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
 #endif
     (void)phase;
   };
@@ -506,6 +515,10 @@ __global__ __launch_bounds__(chain_nw(HD) * 64, (HD <= 256 && EP == HD && chain_
     const uint2 a = pack4<false>(v[0], v[1], v[2], v[3]), b = pack4<false>(v[4], v[5], v[6], v[7]);
     bstore16_nt(make_uint4(a.x, a.y, b.x, b.y), srdS, lane16, sbase(tensorOff), cidx(fb, pb, qp));
   };
+  auto store_tile8_p = [&](int64_t tensorOff, int fb, int pb, int qp, const float (&v)[8]) {
+    const uint2 a = pack4<false>(v[0], v[1], v[2], v[3]), b = pack4<false>(v[4], v[5], v[6], v[7]);
+    bstore16_nt<ISDF_NT_P != 0>(make_uint4(a.x, a.y, b.x, b.y), srdS, lane16, sbase(tensorOff), cidx(fb, pb, qp));
+  };
   // tensors that only the dW kernel re-reads (GB, ZB): cache policy is an A/B switch
   auto store_tile8_dw = [&](int64_t tensorOff, int fb, int pb, int qp, const float (&v)[8]) {
     const uint2 a = pack4<false>(v[0], v[1], v[2], v[3]), b = pack4<false>(v[4], v[5], v[6], v[7]);
@@ -566,7 +579,7 @@ __global__ __launch_bounds__(chain_nw(HD) * 64, (HD <= 256 && EP == HD && chain_
         if (MODE >= 1) {
           store_tile8(p.sp.A[li + 1], fb, pb, qp, a);
           put_x(F16, fb, pb, qp, pl, 0);
-          if (MODE == 2) store_tile8(p.sp.P[li], fb, pb, qp, pl);
+          if (MODE == 2) store_tile8_p(p.sp.P[li], fb, pb, qp, pl);
         }
       }, [](int, int) {});
     }
@@ -620,7 +633,7 @@ __global__ __launch_bounds__(chain_nw(HD) * 64, (HD <= 256 && EP == HD && chain_
       for (int e = 0; e < 8; ++e) pv[e] = acc[fb][pb][8 * qp + e] * s1_from_a(a[e]);
       put_x(F16, fb, pb, qp, pv, 0);
       if (toR2) put_x(F16, fb, pb, qp, pv, HD);
-      if (MODE == 2) store_tile8(p.sp.P[li - 1], fb, pb, qp, pv);
+      if (MODE == 2) store_tile8_p(p.sp.P[li - 1], fb, pb, qp, pv);
     });
     TS();
     lds_barrier();

@@ -191,11 +191,15 @@ def _check_losses(eng, N, ref, tol=TOL_LOSS, keys=("sdf_loss", "grad_loss", "eik
 
 
 def _check_grads_vs_oracle(eng, N, grads, tol=TOL_DW):
+    worst = (0.0, 1.0, "")
     for k in grads:
         got = (eng.grad_view(k).cpu().numpy().astype(np.float64) / N).reshape(-1)
         ref = grads[k].astype(np.float64).reshape(-1)
         cos = got @ ref / (np.linalg.norm(got) * np.linalg.norm(ref))
         assert cos > 0.999 and gu.rel_err(got, ref) < tol, (k, cos, gu.rel_err(got, ref))
+        if gu.rel_err(got, ref) > worst[0]:
+            worst = (gu.rel_err(got, ref), cos, k)
+    print("weight gradients vs oracle (N=%d): worst rel-L2 %.2e (cos %.6f) at %s" % ((N,) + worst))
 
 
 def _check_grads_vs_reference_digest(eng, N, g, tol=TOL_DW):

@@ -34,6 +34,16 @@ if len(se):
     print("workgroups sampled %d: start us min/med/max %.1f %.1f %.1f  end us min/med/max %.1f %.1f %.1f  duration us min/med/max %.1f %.1f %.1f"
           % (len(se), st.min(), float(sorted(st)[len(st) // 2]), st.max(), en.min(), float(sorted(en)[len(en) // 2]), en.max(),
              (en - st).min(), float(sorted(en - st)[len(st) // 2]), (en - st).max()))
+    idx4 = [4 * i for i in range(len(se))]
+    grp = lambda lo, hi: [e for i, e in zip(idx4, en) if lo <= i < hi]
+    nt = int(-(-int(s["n_valid"].item()) * sc.S // 64))
+    second = nt - 256
+    if second > 0:
+        import numpy as np
+        print("SUMMARY tiles %d: first-of-pair end %.1f us, lone end %.1f us, second-of-pair end %.1f us (max %.1f)" % (
+            nt, np.mean(grp(0, second)), np.mean(grp(second, 256)), np.mean(grp(256, nt)), max(en)))
+    if os.environ.get("TIMELINE_BRIEF"):
+        sys.exit(0)
     k = list(se[:, 0]).index(se[:, 0].min())
     for i in range(0, len(se), max(1, len(se) // 24)):
         print("  wg %4d  start %7.1f  end %7.1f" % (4 * i, st[i], en[i]))
