@@ -29,10 +29,10 @@
 
 namespace isdf {
 
-constexpr int SMP_CHUNK = 64;      // rays per workgroup (one wave gathers and compacts them)
-constexpr int SMP_THREADS = 256;   // streaming mode: all four waves expand the samples
-constexpr int SMP_THREADS_SMALL = 1024;   // reference-batch mode: 16 waves re-count the preceding rays in one round
-constexpr int SMP_SMALL_SLOTS = 4;        // rays per thread in that count => up to 4096 rays
+constexpr int SMP_NT = 1024;            // threads per workgroup (both modes)
+constexpr int SMP_CHUNK_SMALL = 64;     // rays per workgroup at the reference batch size (16 workgroups for 1000 rays)
+constexpr int SMP_CHUNK_STREAM = 1024;  // rays per workgroup at streaming sizes (one ray per thread)
+constexpr int SMP_SMALL_SLOTS = 4;      // rays per thread in the small mode's predecessor count => up to 4096 rays
 
 __device__ __forceinline__ uint4 ray_random(const isdf_sample_args& a, uint32_t ray, uint32_t slot) {
   return philox4x32_10(make_uint4(ray, slot, (uint32_t)a.offset, (uint32_t)(a.offset >> 32)),
@@ -63,18 +63,22 @@ __device__ __forceinline__ bool ray_valid(const isdf_sample_args& a, int r) {
   return valid;
 }
 
-// SMALL: the reference batch (a few thousand rays, latency-bound): chunk id = blockIdx and every workgroup
-// counts the valid rays BEFORE its chunk itself (waves 1-3 re-gather the preceding rays while wave 0 gathers the
-// chunk: ONE memory round trip, no inter-workgroup traffic, no workspace).  !SMALL: streaming sizes: atomic
-// ticket + decoupled look-back.
-template <bool SMALL>
-__global__ __launch_bounds__(SMALL ? SMP_THREADS_SMALL : SMP_THREADS) void sample_rays_kernel(const isdf_sample_args a, const isdf_sample_out o,
-                                                                  uint32_t* __restrict__ ws, int nChunks) {
-  constexpr int NT = SMALL ? SMP_THREADS_SMALL : SMP_THREADS;
-  __shared__ int sChunk, sBase, sCnt;
+// One kernel body, two instantiations (1024 threads each):
+//   CHUNK = 64   the reference batch (<= 4096 rays, latency-bound): wave 0 gathers the chunk's rays while ALL 16 waves
+//                re-count the valid rays BEFORE the chunk themselves (fixed slots, straight-line code: every gather of
+//                the workgroup is in flight together) -- one memory round trip, no inter-workgroup traffic, no workspace.
+//   CHUNK = 1024 streaming sizes: every thread gathers one ray; chunk ids come from an atomic ticket (a chunk never
+//                waits for one that has not started) and the chunk's offset from a decoupled look-back over the
+//                aggregates of the chunks before it (64 predecessors per poll round).
+template <int CHUNK>
+__global__ __launch_bounds__(SMP_NT) void sample_rays_kernel(const isdf_sample_args a, const isdf_sample_out o,
+                                                              uint32_t* __restrict__ ws, int nChunks) {
+  constexpr bool SMALL = CHUNK == SMP_CHUNK_SMALL;
+  constexpr int NT = SMP_NT, NW = NT / 64, GW = CHUNK / 64;   // gather waves
+  __shared__ int sChunk, sBase;
   __shared__ uint32_t sEpoch;
-  __shared__ int sPre[SMP_THREADS_SMALL / 64];
-  __shared__ float sRay[SMP_CHUNK][8];   // depth, origin xyz, dirs_W xyz, pad  (compacted order within the chunk)
+  __shared__ int sPre[NW], sWaveCnt[NW];
+  __shared__ float sRay[CHUNK][8];   // depth, origin xyz, dirs_W xyz, pad  (compacted order within the chunk)
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   unsigned long long* state = (unsigned long long*)(ws + 4);
   const int total = a.n_frames * a.n_rays;
@@ -91,12 +95,12 @@ __global__ __launch_bounds__(SMALL ? SMP_THREADS_SMALL : SMP_THREADS) void sampl
     epoch = sEpoch;
   }
 
-  // ---- wave 0: the chunk's own rays
+  // ---- gather waves: the chunk's own rays, one per lane
   bool valid = false;
-  int b = 0, h = 0, wq = 0, before = 0, cnt = 0; float d = 0.f, n0 = 0.f, n1 = 0.f, n2 = 0.f;
+  int b = 0, h = 0, wq = 0, before = 0; float d = 0.f, n0 = 0.f, n1 = 0.f, n2 = 0.f;
   const float* T = a.T_WC_batch;
-  if (wv == 0) {
-    const int r = c * SMP_CHUNK + lane;
+  if (wv < GW) {
+    const int r = c * CHUNK + wv * 64 + lane;
     if (r < total) {
       b = r / a.n_rays;  // indices_b = arange(F).repeat_interleave(n_rays), sample.py:18-19
       if (a.rng_mode == 0) { h = (int)a.draw_h[r]; wq = (int)a.draw_w[r]; }
@@ -110,30 +114,34 @@ __global__ __launch_bounds__(SMALL ? SMP_THREADS_SMALL : SMP_THREADS) void sampl
       valid = d != 0.f;                                       // sample.py:39-40
       if (np) valid = valid && !(n0 != n0);                   // sample.py:47-49
     }
-    // ordered compaction inside the chunk
+    // ordered compaction inside the wave
     const unsigned long long m = __ballot(valid);
     before = __popcll(m & ((1ull << lane) - 1ull));
-    cnt = __popcll(m);
+    if (lane == 0) sWaveCnt[wv] = __popcll(m);
   }
   if (SMALL) {
-    // ---- all 16 waves: how many of the c*64 rays before this chunk are valid.  Fixed slots, straight-line code:
-    // every thread's (up to 4) pixel reads and gathers are in flight together with wave 0's own -- one round trip
+    // ---- all 16 waves: how many of the c*64 rays before this chunk are valid
     int n = 0;
 #pragma unroll
     for (int k = 0; k < SMP_SMALL_SLOTS; ++k) {
       const int r = tid + k * NT;
-      if (r < c * SMP_CHUNK) n += ray_valid(a, r) ? 1 : 0;
+      if (r < c * CHUNK) n += ray_valid(a, r) ? 1 : 0;
     }
 #pragma unroll
     for (int k = 32; k >= 1; k >>= 1) n += __shfl_xor(n, k, 64);
     if (lane == 0) sPre[wv] = n;
-    __syncthreads();
   }
+  __syncthreads();
 
+  // ---- wave 0: the chunk's offset in the ordered output
   if (wv == 0) {
+    int cnt = lane < GW ? sWaveCnt[lane] : 0;
+#pragma unroll
+    for (int k = 8; k >= 1; k >>= 1) cnt += __shfl_xor(cnt, k, 64);
+    cnt = __shfl(cnt, 0, 64);
     int base = 0;
     if (SMALL) {
-      int v = lane < NT / 64 ? sPre[lane] : 0;
+      int v = lane < NW ? sPre[lane] : 0;
 #pragma unroll
       for (int k = 8; k >= 1; k >>= 1) v += __shfl_xor(v, k, 64);
       base = __shfl(v, 0, 64);
@@ -164,41 +172,48 @@ __global__ __launch_bounds__(SMALL ? SMP_THREADS_SMALL : SMP_THREADS) void sampl
       }
       if (lane == 0) __hip_atomic_store(state + c, st_pack(epoch, ST_INC, (uint32_t)(base + cnt)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (lane == 0) { sBase = base; sCnt = cnt; }
+    if (lane == 0) sBase = base;
     if (c == nChunks - 1 && lane == 0) *o.n_valid = base + cnt;
-    if (valid) {
-      const int64_t q = base + before;
-      o.indices_b[q] = b; o.indices_h[q] = h; o.indices_w[q] = wq;
-      o.depth_sample[q] = d;
-      if (o.norm_sample) { o.norm_sample[q * 3] = n0; o.norm_sample[q * 3 + 1] = n1; o.norm_sample[q * 3 + 2] = n2; }
-      // ray_dirs_C, transform.py:13-33 ('z' depth)
-      const float dx = ((float)wq - a.cx) / a.fx, dy = ((float)h - a.cy) / a.fy, dz = 1.f;
-      o.dirs_C_sample[q * 3] = dx; o.dirs_C_sample[q * 3 + 1] = dy; o.dirs_C_sample[q * 3 + 2] = dz;
-      float Tm[12];
+  }
+  __syncthreads();
+
+  // ---- gather waves: per-ray outputs at the compacted position
+  int wbase = 0, cnt_ = 0;
 #pragma unroll
-      for (int k = 0; k < 12; ++k) Tm[k] = T[k];
-      if (o.T_WC_sample) {
-        float4* dst = (float4*)(o.T_WC_sample + q * 16);
-        dst[0] = make_float4(Tm[0], Tm[1], Tm[2], Tm[3]); dst[1] = make_float4(Tm[4], Tm[5], Tm[6], Tm[7]);
-        dst[2] = make_float4(Tm[8], Tm[9], Tm[10], Tm[11]); dst[3] = make_float4(T[12], T[13], T[14], T[15]);
-      }
-      // origin_dirs_W, transform.py:36-41: (R * d).sum(-1), no fused multiply-add
-      float* sr = sRay[before];
-      sr[0] = d;
+  for (int k = 0; k < GW; ++k) { const int n = sWaveCnt[k]; if (k < wv) wbase += n; cnt_ += n; }
+  const int base = sBase;
+  if (wv < GW && valid) {
+    const int jl = wbase + before;
+    const int64_t q = (int64_t)base + jl;
+    o.indices_b[q] = b; o.indices_h[q] = h; o.indices_w[q] = wq;
+    o.depth_sample[q] = d;
+    if (o.norm_sample) { o.norm_sample[q * 3] = n0; o.norm_sample[q * 3 + 1] = n1; o.norm_sample[q * 3 + 2] = n2; }
+    // ray_dirs_C, transform.py:13-33 ('z' depth)
+    const float dx = ((float)wq - a.cx) / a.fx, dy = ((float)h - a.cy) / a.fy, dz = 1.f;
+    o.dirs_C_sample[q * 3] = dx; o.dirs_C_sample[q * 3 + 1] = dy; o.dirs_C_sample[q * 3 + 2] = dz;
+    float Tm[12];
 #pragma unroll
-      for (int i = 0; i < 3; ++i) {
-        const float s = __fadd_rn(__fadd_rn(__fmul_rn(Tm[i * 4], dx), __fmul_rn(Tm[i * 4 + 1], dy)), __fmul_rn(Tm[i * 4 + 2], dz));
-        o.dirs_W_sample[q * 3 + i] = s;
-        sr[1 + i] = Tm[i * 4 + 3];
-        sr[4 + i] = s;
-      }
+    for (int k = 0; k < 12; ++k) Tm[k] = T[k];
+    if (o.T_WC_sample) {
+      float4* dst = (float4*)(o.T_WC_sample + q * 16);
+      dst[0] = make_float4(Tm[0], Tm[1], Tm[2], Tm[3]); dst[1] = make_float4(Tm[4], Tm[5], Tm[6], Tm[7]);
+      dst[2] = make_float4(Tm[8], Tm[9], Tm[10], Tm[11]); dst[3] = make_float4(T[12], T[13], T[14], T[15]);
+    }
+    // origin_dirs_W, transform.py:36-41: (R * d).sum(-1), no fused multiply-add
+    float* sr = sRay[jl];
+    sr[0] = d;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const float s = __fadd_rn(__fadd_rn(__fmul_rn(Tm[i * 4], dx), __fmul_rn(Tm[i * 4 + 1], dy)), __fmul_rn(Tm[i * 4 + 2], dz));
+      o.dirs_W_sample[q * 3 + i] = s;
+      sr[1 + i] = Tm[i * 4 + 3];
+      sr[4 + i] = s;
     }
   }
   __syncthreads();
 
   // ---- along-ray samples of the chunk's valid rays: point p of the chunk -> (ray j, sample s); consecutive
   // threads write consecutive points (sample.py:131-178)
-  const int base = sBase, cnt_ = sCnt;
   for (int p = tid; p < cnt_ * S; p += NT) {
     const int j = p / S, s = p - j * S;
     const int64_t r = (int64_t)base + j;             // compacted ray index: the draws are indexed by it
@@ -251,17 +266,19 @@ __global__ __launch_bounds__(SMALL ? SMP_THREADS_SMALL : SMP_THREADS) void sampl
   }
 }
 
-constexpr int SMP_SMALL_MAX_CHUNKS = SMP_THREADS_SMALL * SMP_SMALL_SLOTS / SMP_CHUNK;   // <= 4096 rays
+constexpr int SMP_SMALL_MAX_RAYS = SMP_NT * SMP_SMALL_SLOTS;   // 4096
 
-int64_t sample_scan_bytes(int64_t max_rays) { return 16 + 8 * ((max_rays + SMP_CHUNK - 1) / SMP_CHUNK); }
+int64_t sample_scan_bytes(int64_t max_rays) { return 16 + 8 * ((max_rays + SMP_CHUNK_STREAM - 1) / SMP_CHUNK_STREAM); }
 
 int launch_sample_rays(const isdf_sample_args& a, const isdf_sample_out& o, void* scan_ws, hipStream_t st) {
   const int total = a.n_frames * a.n_rays;
-  const int nChunks = (total + SMP_CHUNK - 1) / SMP_CHUNK;
-  if (nChunks <= SMP_SMALL_MAX_CHUNKS && !getenv("ISDF_SAMPLER_FORCE_LOOKBACK"))
-    hipLaunchKernelGGL(sample_rays_kernel<true>, dim3((unsigned)nChunks), dim3(SMP_THREADS_SMALL), 0, st, a, o, (uint32_t*)scan_ws, nChunks);
-  else
-    hipLaunchKernelGGL(sample_rays_kernel<false>, dim3((unsigned)nChunks), dim3(SMP_THREADS), 0, st, a, o, (uint32_t*)scan_ws, nChunks);
+  if (total <= SMP_SMALL_MAX_RAYS && !getenv("ISDF_SAMPLER_FORCE_LOOKBACK")) {
+    const int nChunks = (total + SMP_CHUNK_SMALL - 1) / SMP_CHUNK_SMALL;
+    hipLaunchKernelGGL(sample_rays_kernel<SMP_CHUNK_SMALL>, dim3((unsigned)nChunks), dim3(SMP_NT), 0, st, a, o, (uint32_t*)scan_ws, nChunks);
+  } else {
+    const int nChunks = (total + SMP_CHUNK_STREAM - 1) / SMP_CHUNK_STREAM;
+    hipLaunchKernelGGL(sample_rays_kernel<SMP_CHUNK_STREAM>, dim3((unsigned)nChunks), dim3(SMP_NT), 0, st, a, o, (uint32_t*)scan_ws, nChunks);
+  }
   return isdf_launch_status();
 }
 

@@ -468,7 +468,7 @@ def frame_avg(tot_loss_mat, indices_b, indices_h, indices_w, n_frames, H, W, fac
 # ----------------------------------------------------------------------------
 
 def loss_and_grads(params, cfg, lc, pc, z_vals, depth_sample, dirs_C_sample, T_WC_sample,
-                   norm_sample, noise=None, want_intermediates=False):
+                   norm_sample, noise=None, want_intermediates=False, adjoints_from=None):
     """`Trainer.sdf_eval_and_loss` (`trainer.py:768-868`) + `total_loss.backward()`
     (`trainer.py:981`).  pc [R,S,3].  Returns (terms dict, grads dict) where
     grads has the 14 state_dict keys.
@@ -483,6 +483,11 @@ def loss_and_grads(params, cfg, lc, pc, z_vals, depth_sample, dirs_C_sample, T_W
       ordinary reverse with the injected term:
                   ab_L = sbar*so*w_out; zb_l = ab_l*sp'(z_l) + zb_l(inj)
                   dW_l += zb_l^T I_l; db_l = sum zb_l; ab_{l-1} = (zb_l W_l)[:, :H]
+
+    adjoints_from = (sdf, sdf_grad): evaluate the loss adjoints (sbar, gbar) at THESE outputs instead of this
+    function's own (the backward pass is linear in the adjoints; the loss is not smooth -- L1 / eikonal signs,
+    free-space branch -- so a checker that wants to judge a 16-bit implementation's BACKWARD arithmetic feeds it the
+    adjoints that implementation actually used; tests/test_gpu_parity.py).
     """
     R, S = z_vals.shape
     dt = pc.dtype
@@ -511,7 +516,12 @@ def loss_and_grads(params, cfg, lc, pc, z_vals, depth_sample, dirs_C_sample, T_W
 
     terms = loss_terms(sdf, sdf_grad, bounds, grad_vec, norm_sample, lc)
     terms.update(sdf=sdf, sdf_grad=sdf_grad, bounds=bounds, grad_vec=grad_vec)
-    sbar, gbar = loss_adjoints(sdf, sdf_grad if do_grad else np.zeros((R, S, 3), dt), bounds,
+    if adjoints_from is None:
+        adj_sdf, adj_grad = sdf, sdf_grad
+    else:
+        adj_sdf = np.asarray(adjoints_from[0], dt).reshape(R, S)
+        adj_grad = None if adjoints_from[1] is None else np.asarray(adjoints_from[1], dt).reshape(R, S, 3)
+    sbar, gbar = loss_adjoints(adj_sdf, adj_grad if do_grad else np.zeros((R, S, 3), dt), bounds,
                                grad_vec, norm_sample, lc)
     sbar = sbar.reshape(-1)
 

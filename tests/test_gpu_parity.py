@@ -873,12 +873,30 @@ def test_realsense_config_nets_match_oracle(blocks, n_freqs, E):
     s_ = _sample_hip(eng, g, sc)
     R = g["depth_sample"].shape[0]
     noise = g["draw_noise"].reshape(R, -1) * np.float32(0.08)
-    eng.train_step(s_, lc, sc, noise=_dev(noise))
-    terms, grads = orc.loss_and_grads(params, cfg, gu.loss_of(g), g["pc"], g["z_vals"], g["depth_sample"],
-                                      g["dirs_C_sample"], g["T_WC_sample"], g["norm_sample"], noise=noise)
+    dbg = eng.train_step(s_, lc, sc, noise=_dev(noise), debug=True)
+    oargs = (params, cfg, gu.loss_of(g), g["pc"], g["z_vals"], g["depth_sample"], g["dirs_C_sample"], g["T_WC_sample"],
+             g["norm_sample"])
+    terms, grads = orc.loss_and_grads(*oargs, noise=noise)
     N = R * g["z_vals"].shape[1]
     _check_losses(eng, N, terms)
-    _check_grads_vs_oracle(eng, N, grads)
+    # Weight gradients.  The loss is NOT smooth (L1 / eikonal signs, free-space branch, loss.py:122-164,
+    # trainer.py:814-816): with 9-12 PE octaves the random-init field oscillates so fast that the 1e-3 forward
+    # rounding of ANY 16-bit-operand implementation flips enough of those signs to move the summed gradient by
+    # 1-8 % (numpy model of fp16 operands everywhere: 8.3e-2 for this net; HIP 8.4e-2) although the backward
+    # arithmetic itself is accurate.  So the backward pass -- linear in the loss adjoints -- is judged with the
+    # adjoints evaluated at the outputs the kernel itself produced: 1e-2 / 1.5e-2 like everywhere else ...
+    hip_out = (dbg["sdf"][:R].cpu().numpy(), dbg["sdf_grad"][:R].cpu().numpy())
+    _, grads_lin = orc.loss_and_grads(*oargs, noise=noise, adjoints_from=hip_out)
+    _check_grads_vs_oracle(eng, N, grads_lin, tol=1.5 * TOL_DW)
+    # ... and end to end (adjoints from the oracle's own fp32 forward) by direction
+    worst_cos, worst_rel = 1.0, 0.0
+    for k in grads:
+        got = (eng.grad_view(k).cpu().numpy().astype(np.float64) / N).reshape(-1)
+        ref_ = grads[k].astype(np.float64).reshape(-1)
+        worst_cos = min(worst_cos, got @ ref_ / (np.linalg.norm(got) * np.linalg.norm(ref_)))
+        worst_rel = max(worst_rel, gu.rel_err(got, ref_))
+    print("realsense net end-to-end gradients vs fp32 oracle: worst cos %.5f, worst rel-L2 %.2e" % (worst_cos, worst_rel))
+    assert worst_cos > 0.99 and worst_rel < 0.12, (worst_cos, worst_rel)
     # fused tail on this layout: AdamW + incrementally maintained operand copies == from-scratch repack
     eng.train_step(s_, lc, sc, noise=_dev(noise), optim=dict(lr=0.0013, weight_decay=0.012))
     kept = eng.shadow.clone()
