@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libisdf_hip.so")
+# ISDF_HIP_LIB: development override (A/B variants and the instrumented build of tools/build_variants.py)
+LIB_PATH = os.environ.get("ISDF_HIP_LIB") or os.path.join(HERE, "libisdf_hip.so")
 
 ABI_VERSION = 3
 

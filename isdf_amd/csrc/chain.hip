@@ -31,6 +31,9 @@ namespace isdf {
 #ifndef GEMM_ROLLING_REFILL
 #define GEMM_ROLLING_REFILL 0
 #endif
+#ifndef ISDF_DEBUG_HOOKS
+#define ISDF_DEBUG_HOOKS 0     // 1: development build (tools/build_variants.py dbg=-DISDF_DEBUG_HOOKS=1): phase time stamps,
+#endif                         //    spill aliasing and start staggering switches; the shipped kernel carries none of it
 #ifndef ISDF_PRIO_MODE
 #define ISDF_PRIO_MODE 1
 #endif
@@ -333,6 +336,7 @@ __global__ __launch_bounds__(chain_nw(HD) * 64, (HD <= 256 && EP == HD && chain_
   if (n0 >= P) return;
   const int nf = L.n_freqs;
   const float so = L.scale_output;
+#if ISDF_DEBUG_HOOKS
   if (p.dbg_stagger && (blockIdx.x & 1)) {   // experiment: de-phase odd tiles (L2-bound vs HBM-bound sweeps)
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
     while (__builtin_amdgcn_s_memtime() - t0 < (unsigned long long)p.dbg_stagger * 1000ull) __builtin_amdgcn_s_sleep(64);
@@ -342,6 +346,9 @@ __global__ __launch_bounds__(chain_nw(HD) * 64, (HD <= 256 && EP == HD && chain_
     if (p.dbg_times && blockIdx.x == 100 && tid == 0) p.dbg_times[tsn] = __builtin_amdgcn_s_memtime();
     ++tsn;
   };
+#else
+  auto TS = [] {};
+#endif
   TS();
   // Issue priority between the two workgroups of a CU (A/B switch ISDF_PRIO_MODE): with equal priority
   // the OLDER workgroup's waves win VALU/MFMA arbitration all the way, finish ~33 us early and leave the younger one
@@ -367,14 +374,20 @@ __global__ __launch_bounds__(chain_nw(HD) * 64, (HD <= 256 && EP == HD && chain_
     (void)phase;
   };
   PRIO(0);
+#if ISDF_DEBUG_HOOKS
   // debug: wall-clock (s_memrealtime, 100 MHz) start/end of every 4th workgroup -> slots 128..511
   if (p.dbg_times && tid == 0 && (blockIdx.x & 3) == 0 && blockIdx.x < 4 * 190)
     p.dbg_times[128 + blockIdx.x / 2] = __builtin_amdgcn_s_memrealtime();
+#endif
 
   // element offsets of the four shadow weight sets inside the shadow buffer
   const int64_t setFwdA = L.setFwdA, setFwdB = L.setFwdB, setBwdA = L.setBwdA, setBwdB = L.setBwdB;
   // this tile's block of the spill buffer ([tile][tensor][BM*HD] bf16)
+#if ISDF_DEBUG_HOOKS
   uint16_t* spillTile = p.spill + (int64_t)(p.dbg_alias ? (blockIdx.x % p.dbg_alias) : blockIdx.x) * p.sp.tileStride;
+#else
+  uint16_t* spillTile = p.spill + (int64_t)blockIdx.x * p.sp.tileStride;
+#endif
   const rsrc_t rsW = make_rsrc(p.shadow, 0x7fffffffu);
   const rsrc_t rsS = make_rsrc(spillTile, (uint32_t)(p.sp.tileStride * 2));   // loads (compiler-tracked)
   const i32x4 srdS = make_srd(spillTile, (uint32_t)(p.sp.tileStride * 2));     // stores (bstore16_nt)
@@ -1026,8 +1039,10 @@ __global__ __launch_bounds__(chain_nw(HD) * 64, (HD <= 256 && EP == HD && chain_
     lds_barrier();
     TS();
   }
+#if ISDF_DEBUG_HOOKS
   if (p.dbg_times && tid == 0 && (blockIdx.x & 3) == 0 && blockIdx.x < 4 * 190)
     p.dbg_times[129 + blockIdx.x / 2] = __builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 // ---------------------------------------------------------------------------

@@ -25,9 +25,10 @@ struct ChainParams {
   float* vec_part;            // [nTiles][vecStride] bias / out-layer gradient partials (no atomics)
   int32_t vecStride;
   uint16_t* spill; SpillLayout sp;
-  int32_t dbg_alias;          // timing experiments only (ISDF_DEBUG_ALIAS_SPILL): alias tiles' spills
-  int32_t dbg_stagger;        // experiment: odd tiles start this many kilo-cycles late (ISDF_DEBUG_STAGGER)
-  unsigned long long* dbg_times;  // optional [256] s_memtime stamps of one workgroup (ISDF_DEBUG_TIMELINE)
+  // development builds only (-DISDF_DEBUG_HOOKS=1; the shipped kernel ignores them)
+  int32_t dbg_alias;          // ISDF_DEBUG_ALIAS_SPILL: alias tiles' spills (timing experiments)
+  int32_t dbg_stagger;        // ISDF_DEBUG_STAGGER: odd tiles start this many kilo-cycles late
+  unsigned long long* dbg_times;  // ISDF_DEBUG_TIMELINE: [256] s_memtime stamps of one workgroup
 };
 
 struct DwParams {

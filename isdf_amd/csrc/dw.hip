@@ -162,7 +162,7 @@ __global__ __launch_bounds__(512, 2) void dw_kernel(const DwParams p) {
   }
 
   // partial slab [o][i]
-  float* slab = p.dwPart + ((int64_t)unit * DW_SPLITK + split) * DW_BLK * DW_BLK;
+  slab_t* slab = (slab_t*)p.dwPart + ((int64_t)unit * DW_SPLITK + split) * DW_BLK * DW_BLK;
 #pragma unroll
   for (int ob = 0; ob < 2; ++ob)
 #pragma unroll
@@ -171,7 +171,14 @@ __global__ __launch_bounds__(512, 2) void dw_kernel(const DwParams p) {
       for (int r = 0; r < 16; ++r) {
         const int o = wo * 64 + ob * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
         const int i = wi * 128 + ib * 32 + (lane & 31);
+#if ISDF_SLAB_BF16
+        // neighbouring lanes hold neighbouring columns: pair them (quad_perm [1,0,3,2]) so even lanes store 4 bytes
+        const float v = acc[ob][ib][r];
+        const float nb = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));
+        if (!(lane & 1)) *(uint32_t*)(slab + o * DW_BLK + i) = pack4<false>(v, nb, 0.f, 0.f).x;
+#else
         slab[o * DW_BLK + i] = acc[ob][ib][r];
+#endif
       }
 }
 

@@ -20,6 +20,16 @@ constexpr int chain_nw(int hd) { return hd == 256 ? CHAIN_NW : 8; }
 // weight fragments a wave requests at once: 8 (32 VGPRs) at the 128-VGPR budget of 8-wave workgroups, 16 at 4 waves
 constexpr int chain_chunk_frags(int nw) { return nw == 8 ? 8 : 16; }
 constexpr int DW_SPLITK = 36;  // K-splits per dW unit (7 units x 36 = 252 workgroups)
+#ifndef ISDF_SLAB_BF16
+#define ISDF_SLAB_BF16 0       // 1: the K-split partial slabs are stored as bf16 (half the slab traffic of dW + step tail)
+#endif
+typedef
+#if ISDF_SLAB_BF16
+    uint16_t
+#else
+    float
+#endif
+    slab_t;
 
 // Vector types for the 16-bit MFMA operands.
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;

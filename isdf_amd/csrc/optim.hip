@@ -250,9 +250,15 @@ __global__ __launch_bounds__(1024) void step_tail_kernel(const TailParams p) {
     float s = 0.f;
     if (PHASE == 2) s = p.grad[pi];
     else {
-      const float* src = p.dwPart + (int64_t)unit * DW_SPLITK * perUnit + rem;
+      const slab_t* src = (const slab_t*)p.dwPart + (int64_t)unit * DW_SPLITK * perUnit + rem;
 #pragma unroll 4
-      for (int k = 0; k < DW_SPLITK; ++k) s += src[(int64_t)k * perUnit];
+      for (int k = 0; k < DW_SPLITK; ++k) {
+#if ISDF_SLAB_BF16
+        s += __uint_as_float((uint32_t)src[(int64_t)k * perUnit] << 16);
+#else
+        s += src[(int64_t)k * perUnit];
+#endif
+      }
       p.grad[pi] = s;
       if (PHASE == 1) return;
     }

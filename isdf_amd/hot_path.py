@@ -186,7 +186,8 @@ class HotPath:
         N_off = torch.normal(torch.zeros(R, max(sc.n_surf - 1, 0)), 0.1).to(dev)
         return dict(indices_h=ih, indices_w=iw, U=U, N_off=N_off)
 
-    def _sample_raw(self, depth_batch, T_WC_batch, norm_batch, frame_idx, normal_idx, sc, want_T, shared_key=False):
+    def _sample_raw(self, depth_batch, T_WC_batch, norm_batch, frame_idx, normal_idx, sc, want_T, shared_key=False,
+                    reuse=False):
         """sampler launch; returns the engine's capacity-sized output dict (rows >= n_valid are undefined).
         shared_key: use the rank-INDEPENDENT Philox key (keyframe test under data parallelism: every rank
         must reach the same decision)."""
@@ -201,11 +202,11 @@ class HotPath:
                 return int(ok.sum().item())
             draws = self._draws_torch(frame_idx.numel(), sc, n_valid)
             return eng.sample(depth_batch, T_WC_batch, norm_batch, frame_idx, normal_idx, sc, draws=draws,
-                              want_T=want_T)
+                              want_T=want_T, reuse=reuse)
         hip.draw_count += 1
         seed = hip.seed if shared_key else dp.rank_seed(hip.seed, self._rank())
         return eng.sample(depth_batch, T_WC_batch, norm_batch, frame_idx, normal_idx, sc,
-                          seed=seed, offset=hip.draw_count, want_T=want_T)
+                          seed=seed, offset=hip.draw_count, want_T=want_T, reuse=reuse)
 
     def sample_points(self, depth_batch, T_WC_batch, norm_batch=None, active_loss_approx=None, n_rays=None,
                       dist_behind_surf=None, n_strat_samples=None, n_surf_samples=None, _shared_key=False):
@@ -344,7 +345,7 @@ class HotPath:
         sc = self._sample_cfg()
         # no depth_batch[idxs] copy (trainer.py:965: 16 MB at 680x1200x5): the sampler takes the window indices
         s = self._sample_raw(self.frames.depth_batch, self.frames.T_WC_batch, norm_batch, fidx,
-                             nidx if norm_batch is not None else None, sc, want_T=False)
+                             nidx if norm_batch is not None else None, sc, want_T=False, reuse=True)
         self.active_pixels = _LazyCut(s)
 
         fal = self.frames.frame_avg_losses
@@ -466,6 +467,9 @@ class HotPath:
             torch.cuda.set_rng_state(r["torch_cuda"], hip.device)
 
 
+ENGINE_FACTORY = None      # host-logic tests on GPU-less machines install an oracle-backed stand-in here; never set by the product
+
+
 UNSUPPORTED_HINT = ("isdf_amd hot path: %s (the reference's own Python path is the CPU / fallback path; "
                     "this build ships no second implementation)")
 
@@ -484,6 +488,8 @@ def graft(trainer, rng="philox", seed=1, dist_group=None, fix_normal_window=Fals
     engine_factory: tests only (a stand-in engine for hosts without a GPU)."""
     if isinstance(trainer, HotPath) and getattr(trainer, "_hip", None) is not None:
         return trainer
+    if engine_factory is None:
+        engine_factory = ENGINE_FACTORY
     dev = torch.device(trainer.device)
     if engine_factory is None and dev.type != "cuda":
         raise _ffi.IsdfError(UNSUPPORTED_HINT % ("device %r is not a HIP device" % (trainer.device,)))

@@ -47,7 +47,7 @@ class FakeEngine:
 
     # ---- sampler (capacity-sized outputs, rows >= n_valid undefined)
     def sample(self, depth_batch, T_WC_batch, normal_batch, frame_idx, normal_idx, sc, draws=None, seed=0, offset=0,
-               want_T=False):
+               want_T=False, reuse=False):
         F = int(frame_idx.numel())
         R0, S = F * sc.n_rays, sc.S
         fi = frame_idx.long().numpy()

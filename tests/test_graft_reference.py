@@ -95,6 +95,30 @@ def test_grafted_reference_trainer_reproduces_reference_step_trajectory(ref_mods
         assert float(st[i]["step"]) == 3.0
 
 
+@needs_ref
+def test_integration_md_snippet_runs_on_the_reference_trainer(ref_mods, monkeypatch):
+    """The code block INTEGRATION.md tells a maintainer to add is executed VERBATIM on a real reference Trainer
+    (the engine stand-in is installed through the module hook, because this container has no GPU)."""
+    import re
+    import isdf_amd.hot_path as hp
+    mg, mods = ref_mods
+    md = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "INTEGRATION.md")).read()
+    blocks = re.findall(r"```python graft-snippet\n(.*?)```", md, re.S)
+    assert len(blocks) == 1
+    g = gu.load("step_small_k3")
+    isdf_trainer = _reference_trainer(mg, mods, g)
+    ref_cls = type(isdf_trainer)
+    monkeypatch.setattr(hp, "ENGINE_FACTORY", FakeEngine)
+    with contextlib.redirect_stdout(io.StringIO()):
+        exec(blocks[0], {"isdf_trainer": isdf_trainer})
+        np.random.seed(1); torch.manual_seed(1)
+        losses, ms = isdf_trainer.step()
+    assert isinstance(isdf_trainer, ref_cls) and isinstance(isdf_trainer, hp.HotPath)
+    assert set(losses.keys()) == {"sdf_loss", "grad_loss", "eikonal_loss", "total_loss"}
+    assert isdf_trainer.steps_since_frame == 1 and isdf_trainer.tot_step_time > 0
+    "{:.6f}".format(losses["total_loss"]); losses["total_loss"].item()            # train.py:138,215
+
+
 class _Dataset:
     """minimal scene_dataset for Trainer.get_data (trainer.py:530-562): dicts with image / depth / T"""
 

@@ -1,6 +1,10 @@
-"""Dev tool: print the in-kernel phase timeline of one chain workgroup (ISDF_DEBUG_TIMELINE=1)."""
+"""Dev tool: print the in-kernel phase timeline of one chain workgroup.  Needs the instrumented build:
+    python tools/build_variants.py dbg="-DISDF_DEBUG_HOOKS=1"   ->  variants/lib_dbg.so   (used automatically)"""
 import os, sys
 os.environ["ISDF_DEBUG_TIMELINE"] = "1"
+_dbg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "variants", "lib_dbg.so")
+if not os.environ.get("ISDF_HIP_LIB") and os.path.exists(_dbg):
+    os.environ["ISDF_HIP_LIB"] = _dbg
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from isdf_amd.engine import Engine, NetConfig, LossConfig, SampleConfig
