@@ -271,8 +271,13 @@ def main():
     # ---- untimed clock ramp: the driver's `--steps 20 --warmup 5` is 8 ms of GPU work in a fresh process, i.e. measured
     # at idle clocks with first-touch allocations inside the timed region (BENCH_r01: chain 223 us vs 197 us steady)
     ramp_steps, t_r = 0, time.perf_counter()
-    while time.perf_counter() - t_r < args.ramp_seconds:
-        for _ in range(20):
+    if group is None:
+        while time.perf_counter() - t_r < args.ramp_seconds:
+            for _ in range(20):
+                one_step(1 << 20 | ramp_steps); ramp_steps += 1
+            torch.cuda.synchronize()
+    else:   # every rank must issue the SAME number of collectives: a fixed count instead of a time budget
+        for _ in range(int(1000 * args.ramp_seconds)):
             one_step(1 << 20 | ramp_steps); ramp_steps += 1
         torch.cuda.synchronize()
     for i in range(W):

@@ -6,8 +6,8 @@
  * (isdf/modules/trainer.py:951-1016) and the two methods it calls,
  * `Trainer.sample_points` (:683-766) and `Trainer.sdf_eval_and_loss` (:768-868).
  * This header is what a ctypes binding inside those methods binds to; the
- * reference-side stub is shown in INTEGRATION.md, the in-repo host mirror is
- * isdf_amd/trainer.py.
+ * reference-side binding (graft(trainer)) is shown in INTEGRATION.md and lives in
+ * isdf_amd/hot_path.py.
  *
  * Conventions
  *   - extern "C", plain pointers and sizes, no torch types.  All pointers are

@@ -99,6 +99,9 @@ __global__ __launch_bounds__(SMP_NT) void sample_rays_kernel(const isdf_sample_a
   bool valid = false;
   int b = 0, h = 0, wq = 0, before = 0; float d = 0.f, n0 = 0.f, n1 = 0.f, n2 = 0.f;
   const float* T = a.T_WC_batch;
+  float Tm[12];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) Tm[k] = 0.f;
   if (wv < GW) {
     const int r = c * CHUNK + wv * 64 + lane;
     if (r < total) {
@@ -108,9 +111,11 @@ __global__ __launch_bounds__(SMP_NT) void sample_rays_kernel(const isdf_sample_a
       const int64_t pix = (int64_t)h * a.W + wq;
       const int fi = a.frame_idx[b];
       const float* np = a.normal_batch ? a.normal_batch + ((int64_t)a.normal_idx[b] * a.H * a.W + pix) * 3 : nullptr;
-      d = a.depth_batch[(int64_t)fi * a.H * a.W + pix];       // both gathers in flight together
+      d = a.depth_batch[(int64_t)fi * a.H * a.W + pix];       // both gathers in flight together ...
       if (np) { n0 = np[0]; n1 = np[1]; n2 = np[2]; }
       T += (int64_t)fi * 16;
+#pragma unroll
+      for (int k = 0; k < 12; ++k) Tm[k] = T[k];              // ... with the pose (L2-resident), not behind them
       valid = d != 0.f;                                       // sample.py:39-40
       if (np) valid = valid && !(n0 != n0);                   // sample.py:47-49
     }
@@ -191,9 +196,6 @@ __global__ __launch_bounds__(SMP_NT) void sample_rays_kernel(const isdf_sample_a
     // ray_dirs_C, transform.py:13-33 ('z' depth)
     const float dx = ((float)wq - a.cx) / a.fx, dy = ((float)h - a.cy) / a.fy, dz = 1.f;
     o.dirs_C_sample[q * 3] = dx; o.dirs_C_sample[q * 3 + 1] = dy; o.dirs_C_sample[q * 3 + 2] = dz;
-    float Tm[12];
-#pragma unroll
-    for (int k = 0; k < 12; ++k) Tm[k] = T[k];
     if (o.T_WC_sample) {
       float4* dst = (float4*)(o.T_WC_sample + q * 16);
       dst[0] = make_float4(Tm[0], Tm[1], Tm[2], Tm[3]); dst[1] = make_float4(Tm[4], Tm[5], Tm[6], Tm[7]);
