@@ -386,9 +386,14 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(depth, normal, T, cam, cfg)
             res["speedup_vs_cpu_baseline"] = round(res["value"] / res["cpu_baseline"]["value"], 1)
-        print(json.dumps(res), flush=True)
     if group is not None:
         torch.distributed.destroy_process_group()
+    try:      # RCCL prints its version banner through C stdio, which is flushed at exit when stdout is a pipe:
+        ctypes.CDLL(None).fflush(None)          # push it out now so that the JSON line is the LAST line of stdout
+    except Exception:
+        pass
+    if rank == 0:
+        print(json.dumps(res), flush=True)
 
 
 if __name__ == "__main__":
