@@ -8,7 +8,7 @@ for f in variants/lib_*.so; do
   python bench.py --steps 300 --warmup 50 --no-cpu-baseline "$@" 2>/dev/null | tail -1 | python -c "
 import sys,json
 j=json.loads(sys.stdin.read()); print('%-28s rep$rep  %8.1f steps/s  %.4f ms  %s  sync %.4f loss %.5f' % ('$f'.split('lib_')[1][:-3], j['value'], j['ms_per_step'], j['kernel_ms'], j['trainer_step_sync_ms'], j['final_total_loss']))"
-  if [ $rep = 1 ]; then TIMELINE_BRIEF=1 python tools/timeline.py 2>/dev/null | grep SUMMARY; fi
+
 done
 done
 cp /tmp/lib_keep.so isdf_amd/libisdf_hip.so
