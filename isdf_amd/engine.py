@@ -110,8 +110,31 @@ class SampleConfig:
         return self.n_strat + self.n_surf
 
 
+_PINNED_STREAM = None      # (torch.cuda.Stream, c_void_p) while a caller has pinned the launch stream
+
+
 def _stream():
+    """hipStream_t of torch's current stream.  `torch.cuda.current_stream()` costs ~5 us of host time per call (it
+    re-derives the device index through torch.cuda.is_available() -> os.getenv), which sits in front of every launch of
+    a device-synchronised step: `pinned_stream()` looks it up once per step instead."""
+    if _PINNED_STREAM is not None:
+        return _PINNED_STREAM[1]
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class pinned_stream:
+    """with pinned_stream() as st: every Engine call inside launches on `st` (torch's current stream at entry)."""
+
+    def __enter__(self):
+        global _PINNED_STREAM
+        self.prev = _PINNED_STREAM
+        st = torch.cuda.current_stream()
+        _PINNED_STREAM = (st, C.c_void_p(st.cuda_stream))
+        return st
+
+    def __exit__(self, *exc):
+        global _PINNED_STREAM
+        _PINNED_STREAM = self.prev
 
 
 class Engine:

@@ -85,7 +85,7 @@ class StepLosses(dict):
     (loss.py:187-200); the values are snapshotted at construction, so a later step cannot change them."""
 
     def __init__(self, loss_sums_host, has_grad, has_eik):
-        ls = [float(v) for v in loss_sums_host]
+        ls = loss_sums_host.tolist()        # (iterating a tensor goes through unbind(): ~20 us)
         n = max(ls[_ffi.LS_COUNT], 1.0)
         super().__init__()
         self["sdf_loss"] = ls[_ffi.LS_SDF] / n
@@ -300,29 +300,38 @@ class HotPath:
         return total_loss, losses, loss_approx, frame_avg_loss
 
     # ------------------------------------------------------------------ step (trainer.py:951-1016)
-    def _timing_start(self):
-        """metrics.start_timing (metrics.py:13-22): device-synchronised, CUDA(HIP) events"""
-        if self._hip.device.type == "cuda":
-            torch.cuda.synchronize()
+    def _timing_start(self, st):
+        """metrics.start_timing (metrics.py:13-22): device-synchronised, CUDA(HIP) events.  `st` is the stream all of
+        the step's work is launched on; synchronising it is the reference's device synchronisation for this path
+        (torch.cuda.synchronize() itself costs ~5 us of host time per call in index / env lookups)."""
+        if st is not None:
+            st.synchronize()
             start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            start.record()
+            start.record(st)
             return start, end
         import time
         return time.perf_counter(), None
 
-    def _timing_end(self, start, end):
+    def _timing_end(self, st, start, end):
         """metrics.end_timing (metrics.py:25-38), milliseconds"""
-        if self._hip.device.type == "cuda":
-            torch.cuda.synchronize()
-            end.record()
-            torch.cuda.synchronize()
+        if st is not None:
+            st.synchronize()
+            end.record(st)
+            st.synchronize()
             return start.elapsed_time(end)
         import time
         return (time.perf_counter() - start) * 1000.0
 
     def step(self):
+        if self._hip.device.type != "cuda":
+            return self._step(None)
+        from .engine import pinned_stream
+        with pinned_stream() as st:
+            return self._step(st)
+
+    def _step(self, st):
         hip = self._hip
-        start, end = self._timing_start()
+        start, end = self._timing_start(st)
 
         K = self.frames.T_WC_batch.shape[0]
         if len(self.frames) > self.window_size and self.incremental:
@@ -363,7 +372,7 @@ class HotPath:
             self.optimiser.step()                      # AdamW on the (all-reduced) gradient sums
         hip.loss_host.copy_(eng.loss_sums(), non_blocking=True)   # rides on the closing synchronisation
 
-        step_time = self._timing_end(start, end)
+        step_time = self._timing_end(st, start, end)
         if hip.virtual_step_ms is not None:            # pinned schedule (parity / accuracy runs)
             step_time = float(hip.virtual_step_ms)
         if hip.dist_group is not None:                 # ONE virtual clock for all ranks (frame schedule)
