@@ -958,3 +958,56 @@ def test_sampler_ordered_compaction_at_a_million_rays():
         assert (s["pc"][:R, 0] - pc0).abs().max() < 4e-6
         zs = s["z_vals"][:R, sc.n_surf:]                                            # stratified: one per bin, in order
         assert bool((zs[:, 1:] >= zs[:, :-1]).all()) and float(zs.min()) >= sc.min_depth
+
+
+def test_public_seams_match_step_and_autograd_callers_work():
+    """The secondary seams of SURVEY 8b on the real kernels: (i) the reference's own step body written against the
+    PUBLIC methods -- sample_points -> sdf_eval_and_loss -> total_loss.backward() -> optimiser.step() (trainer.py:
+    968-986) -- leaves the same network as step() does for the same draws; (ii) a caller-assembled sample dict (no
+    private fields) is accepted; (iii) `fc_map.gradient`-style autograd through trainer.sdf_map returns d sdf / d x."""
+    from isdf_amd.trainer import HipTrainer, FrameData
+    from isdf_amd import synthetic
+    import bench
+    cam = dict(synthetic.SCANNET_CAM)
+    cfg = bench.reference_config()
+    cfg["dataset"]["camera"] = {"w": cam["W"], "h": cam["H"], "fx": cam["fx"], "fy": cam["fy"], "cx": cam["cx"], "cy": cam["cy"]}
+    depth, normal, T = synthetic.keyframes(4, cam, seed=6, stride=30)
+
+    def fresh():
+        np.random.seed(2); torch.manual_seed(2)
+        tr = HipTrainer("cuda", cfg, inv_bounds_transform=synthetic.bounds_transform(), rng="philox", seed=9)
+        tr.frames = FrameData(frame_id=np.arange(4), depth_batch=_dev(depth), T_WC_batch=_dev(T), normal_batch=_dev(normal),
+                              frame_avg_losses=torch.zeros(4, device="cuda"))
+        tr.noise_std = 0.0
+        return tr
+    a, b = fresh(), fresh()
+    for _ in range(3):
+        la, _ = a.step()
+        # the reference's step body on the public surface (same Philox counters: one sampler draw, one noise draw)
+        sp = b.sample_points(b.frames.depth_batch, b.frames.T_WC_batch, norm_batch=b.frames.normal_batch)
+        assert sp["pc"].shape[0] == sp["depth_sample"].shape[0] == sp["indices_b"].shape[0] and sp["binary_masks"] is None
+        total, lb, loss_approx, frame_avg = b.sdf_eval_and_loss(sp, do_avg_loss=True)
+        b.frames.frame_avg_losses[np.arange(4)] = frame_avg
+        total.backward()                       # no-op: the backward pass ran inside the native call
+        b.optimiser.step()
+        for pg in b.optimiser.param_groups:
+            for prm in pg["params"]:
+                prm.grad = None
+        assert abs(float(total.detach()) - float(la["total_loss"])) < 1e-6 * abs(float(total.detach()))
+        assert set(lb.keys()) == set(la.keys()) and abs(lb["sdf_loss"] - la["sdf_loss"]) < 1e-6
+    assert torch.equal(a.engine.params, b.engine.params) and torch.equal(a.engine.exp_avg_sq, b.engine.exp_avg_sq)
+    assert torch.allclose(a.frames.frame_avg_losses, b.frames.frame_avg_losses, rtol=1e-6, atol=0)
+    # (ii) caller-assembled dict: the 11 public tensors only
+    pub = {k: v for k, v in sp.items() if not k.startswith("_")}
+    total2, l2, _, _ = b.sdf_eval_and_loss(pub, do_avg_loss=False)
+    total3, l3, _, _ = b.sdf_eval_and_loss(sp, do_avg_loss=False)
+    assert abs(float(total2) - float(total3)) < 2e-6 * abs(float(total3))
+    # (iii) autograd callers (fc_map.gradient, render.render_normals): first-order input gradient
+    x = (torch.rand(500, 3, device="cuda") * 2 - 1).requires_grad_()
+    sdf = b.sdf_map(x)
+    g = torch.autograd.grad(sdf, x, torch.ones_like(sdf))[0]
+    sdf_k, g_k = b.sdf_map.forward_with_grad(x.detach())
+    assert torch.equal(sdf.detach(), sdf_k) and torch.equal(g, g_k)
+    eps = 0.05      # (the 2e-5 fp16-operand noise of the outputs rules out a small step)
+    fd = (b.sdf_map(x.detach() + torch.tensor([eps, 0, 0], device="cuda")) - b.sdf_map(x.detach() - torch.tensor([eps, 0, 0], device="cuda"))) / (2 * eps)
+    assert float((fd - g[:, 0]).abs().max()) < 5e-2 * float(g[:, 0].abs().max())
