@@ -34,6 +34,19 @@ namespace isdf {
 #ifndef ISDF_DEBUG_HOOKS
 #define ISDF_DEBUG_HOOKS 0     // 1: development build (tools/build_variants.py dbg=-DISDF_DEBUG_HOOKS=1): phase time stamps,
 #endif                         //    spill aliasing and start staggering switches; the shipped kernel carries none of it
+// what-if experiments (timing only, results wrong; never set in a shipped build)
+#ifndef ISDF_EXP_HALF_LDS
+#define ISDF_EXP_HALF_LDS 0
+#endif
+#ifndef ISDF_EXP_NO_WLOAD
+#define ISDF_EXP_NO_WLOAD 0
+#endif
+#ifndef ISDF_EXP_NO_BARRIER
+#define ISDF_EXP_NO_BARRIER 0
+#endif
+#ifndef ISDF_EXP_CHEAP_EPI
+#define ISDF_EXP_CHEAP_EPI 0
+#endif
 #ifndef ISDF_PRIO_MODE
 #define ISDF_PRIO_MODE 1
 #endif
@@ -82,7 +95,9 @@ struct Tile {
 // __syncthreads() would drain them (s_waitcnt vmcnt(0)) at every layer.
 __device__ __forceinline__ void lds_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#if !ISDF_EXP_NO_BARRIER   // what-if (results wrong): waves of a workgroup run unsynchronised
   __builtin_amdgcn_s_barrier();
+#endif
   asm volatile("" ::: "memory");
 }
 
@@ -161,6 +176,10 @@ struct WRef { int soff; int rb; };   // byte offset of a wave's slice of a packe
 template <int FBN, int CKF>
 __device__ __forceinline__ void preload_w(WChunk<FBN, CKF>& wq, rsrc_t rw, WRef r, int lane16) {
   constexpr int CK = CKF / FBN;
+#if ISDF_EXP_NO_WLOAD      // what-if (results wrong): weight fragments are never fetched
+  asm volatile("" : "+v"(wq.v[0][0].x));
+  return;
+#endif
 #pragma unroll
   for (int s = 0; s < CK; ++s)
 #pragma unroll
@@ -194,8 +213,12 @@ __device__ __forceinline__ void gemm(f32x16 (&acc)[FBN][PBN], WChunk<FBN, CKF>& 
     asm volatile("" : "+v"(xch));
     auto readb = [&](int s, v8 (&b)[PBN]) {
 #pragma unroll
-      for (int pb = 0; pb < PBN; ++pb)
+      for (int pb = 0; pb < PBN; ++pb) {
+#if ISDF_EXP_HALF_LDS    // what-if (results wrong): one operand read feeds both point blocks
+        if (pb > 0) { b[pb] = b[0]; continue; }
+#endif
         b[pb] = __builtin_bit_cast(v8, *(const uint4*)(xl + ((xch ^ (s * 32)) + pb * 32 * ROWB)));
+      }
     };
     constexpr int D = GEMM_LDS_DEPTH < CK ? GEMM_LDS_DEPTH : CK - 1;
     v8 b[D + 1][PBN];
@@ -219,7 +242,7 @@ __device__ __forceinline__ void gemm(f32x16 (&acc)[FBN][PBN], WChunk<FBN, CKF>& 
 #endif
       __builtin_amdgcn_sched_barrier(0);
     }
-#if !GEMM_ROLLING_REFILL
+#if !GEMM_ROLLING_REFILL && !ISDF_EXP_NO_WLOAD
     if (decltype(refill)::value) {
 #pragma unroll
       for (int s = 0; s < CK; ++s)
@@ -292,6 +315,9 @@ __device__ __forceinline__ void half_wave_store(float v, float* dst, int lane) {
 constexpr float kC1 = kBeta * 1.4426950408889634f;   // beta * log2(e)
 constexpr float kC2 = 0.6931471805599453f / kBeta;   // ln2 / beta
 __device__ __forceinline__ float softplus_f(float z) {
+#if ISDF_EXP_CHEAP_EPI     // what-if (results wrong): no transcendental math in the epilogues
+  return fmaxf(z, 0.f);
+#endif
   const float t = __builtin_amdgcn_exp2f(fminf(kC1 * z, 30.f));
   return fmaxf(z, kC2 * __builtin_amdgcn_logf(1.f + t));
 }
@@ -302,7 +328,12 @@ __device__ __forceinline__ float softplus_s1(float z, float& s1) {   // also sig
   return fmaxf(z, kC2 * __builtin_amdgcn_logf(u));
 }
 // sigma'(z) recovered from the stored activation: 1 - exp(-beta a)
-__device__ __forceinline__ float s1_from_a(float a) { return 1.f - __builtin_amdgcn_exp2f(-kC1 * a); }
+__device__ __forceinline__ float s1_from_a(float a) {
+#if ISDF_EXP_CHEAP_EPI
+  return a;
+#endif
+  return 1.f - __builtin_amdgcn_exp2f(-kC1 * a);
+}
 
 template <int HD, int EP, bool F16, int MODE>
 __global__ __launch_bounds__(chain_nw(HD) * 64, (HD <= 256 && EP == HD && chain_nw(HD) == 8 ? 4 : 2)) void chain_kernel(const ChainParams p) {
