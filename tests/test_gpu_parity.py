@@ -1011,3 +1011,35 @@ def test_public_seams_match_step_and_autograd_callers_work():
     eps = 0.05      # (the 2e-5 fp16-operand noise of the outputs rules out a small step)
     fd = (b.sdf_map(x.detach() + torch.tensor([eps, 0, 0], device="cuda")) - b.sdf_map(x.detach() - torch.tensor([eps, 0, 0], device="cuda"))) / (2 * eps)
     assert float((fd - g[:, 0]).abs().max()) < 5e-2 * float(g[:, 0].abs().max())
+
+
+@pytest.mark.parametrize("F,n", [(1, 1), (1, 63), (1, 64), (3, 65), (5, 200), (4, 1024), (1, 4096), (1, 4097), (5, 1000), (3, 23457)])
+def test_sampler_ray_count_sweep(F, n):
+    """both compaction modes (<= 4096 rays: per-workgroup re-count; above: ticket + look-back) at awkward sizes, several
+    launches in a row on the same workspace: count, order and gathers against torch on the same draws"""
+    from isdf_amd.engine import Engine, NetConfig, SampleConfig
+    cam = dict(H=120, W=160, fx=150.0, fy=150.0, cx=79.5, cy=59.5)
+    depth, normal, T = gu.synth_frames_exact(50 + F, F, cam["H"], cam["W"])
+    eng = Engine(NetConfig(), "cuda")
+    sc = SampleConfig(n_rays=n, **cam)
+    d, nm, Tt = _dev(depth), _dev(normal), _dev(T)
+    idx = torch.arange(F, dtype=torch.int32, device="cuda")
+    ib = torch.arange(F, device="cuda").repeat_interleave(n)
+    gen = torch.Generator(device="cuda").manual_seed(n)
+    for rep in range(3):
+        ih = torch.randint(0, cam["H"], (F * n,), device="cuda", generator=gen)
+        iw = torch.randint(0, cam["W"], (F * n,), device="cuda", generator=gen)
+        U = torch.rand(F * n, sc.n_strat, device="cuda", generator=gen)
+        N_off = 0.1 * torch.randn(F * n, sc.n_surf - 1, device="cuda", generator=gen)
+        s = eng.sample(d, Tt, nm, idx, idx, sc, draws=dict(indices_h=ih, indices_w=iw, U=U, N_off=N_off), want_T=True)
+        torch.cuda.synchronize()
+        ds = d[ib, ih, iw]
+        ok = (ds != 0) & ~torch.isnan(nm[ib, ih, iw, 0])
+        R = int(ok.sum().item())
+        assert int(s["n_valid"].item()) == R
+        assert torch.equal(s["indices_b"][:R], ib[ok]) and torch.equal(s["indices_h"][:R], ih[ok]) and torch.equal(s["indices_w"][:R], iw[ok])
+        assert torch.equal(s["depth_sample"][:R], ds[ok]) and torch.equal(s["T_WC_sample"][:R], Tt[ib[ok]])
+        if R:
+            near = torch.clamp(ds[ok][:, None] + N_off[:R], min=sc.min_depth)
+            near = torch.minimum(near, (ds[ok] + sc.dist_behind_surf)[:, None])
+            assert torch.equal(s["z_vals"][:R, 0], ds[ok]) and torch.allclose(s["z_vals"][:R, 1:sc.n_surf], near, rtol=0, atol=1e-6)
