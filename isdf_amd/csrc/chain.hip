@@ -20,13 +20,16 @@
 // B = the activation tile in LDS ([point][k], 16-B XOR swizzle, ds_read_b128).
 // In the C layout a lane owns one point and 4 consecutive features per
 // register quad, so epilogues write 8-byte packed pieces back to the LDS tile.
-#include "isdf_common.h"
-#include "chain_params.h"
+#include "chain_dev.h"
+#include <stdlib.h>
 
 namespace isdf {
 
 #ifndef GEMM_HOOK_BEFORE_LAST_CHUNK
 #define GEMM_HOOK_BEFORE_LAST_CHUNK 0   // 1: request one spill tensor before the last chunk (measured +15 us, 16 spilled VGPRs)
+#endif
+#ifndef GEMM_HOOKS_FIRST
+#define GEMM_HOOKS_FIRST 0
 #endif
 #ifndef GEMM_ROLLING_REFILL
 #define GEMM_ROLLING_REFILL 0
@@ -40,12 +43,6 @@ namespace isdf {
 #endif
 #ifndef ISDF_EXP_NO_WLOAD
 #define ISDF_EXP_NO_WLOAD 0
-#endif
-#ifndef ISDF_EXP_NO_BARRIER
-#define ISDF_EXP_NO_BARRIER 0
-#endif
-#ifndef ISDF_EXP_CHEAP_EPI
-#define ISDF_EXP_CHEAP_EPI 0
 #endif
 #ifndef ISDF_PRIO_MODE
 #define ISDF_PRIO_MODE 1
@@ -62,8 +59,6 @@ namespace isdf {
 #ifndef GEMM_LDS_DEPTH
 #define GEMM_LDS_DEPTH 1   // k-steps of activation-operand LDS reads in flight ahead of the MFMAs
 #endif
-constexpr float kHalfPi = 1.5707963267948966f;
-constexpr float kBeta = 100.f;
 
 template <int HD, int EP>
 struct Tile {
@@ -88,75 +83,6 @@ struct Tile {
   static constexpr int OFF_EG = (OFF_RED + (BM / 64) * 32 + 32 + 1023) / 1024 * 1024;   // fp32 [32][HD], 1 KB-aligned rows
   static constexpr int LDS_BYTES = WIDE_E ? OFF_EG + 32 * HD * 4 : OFF_RED + (BM / 64) * 32 + 32;
 };
-
-// Workgroup barrier that only waits for this wave's LDS traffic.  The global
-// spill tiles are thread-private (the lane that stores a piece is the lane that
-// re-reads it), so global stores/loads may stay in flight across the barrier;
-// __syncthreads() would drain them (s_waitcnt vmcnt(0)) at every layer.
-__device__ __forceinline__ void lds_barrier() {
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#if !ISDF_EXP_NO_BARRIER   // what-if (results wrong): waves of a workgroup run unsynchronised
-  __builtin_amdgcn_s_barrier();
-#endif
-  asm volatile("" ::: "memory");
-}
-
-// All global traffic of the hot loops goes through buffer descriptors: address = SGPR descriptor + SGPR offset +
-// ONE per-lane VGPR (lane*16) + immediate.  With flat 64-bit addresses the compiler kept a VGPR pair per matrix /
-// spill tensor alive across the layer loops, spilled them, and reloaded them inside the MFMA stream behind
-// s_waitcnt vmcnt(0).
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-typedef __amdgpu_buffer_rsrc_t rsrc_t;
-__device__ __forceinline__ rsrc_t make_rsrc(const void* base, uint32_t bytes) {
-  return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, bytes, 0x00020000);
-}
-constexpr int kAuxNT = 2;   // non-temporal: the spill stream must not evict the L2-resident weight copies
-template <int AUX> __device__ __forceinline__ uint4 bload16(rsrc_t r, int voff, int soff) {
-  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, AUX);
-  return make_uint4(v[0], v[1], v[2], v[3]);
-}
-// 16-byte non-temporal store of frag16 piece `c` (byte c*1024 past soff; c&3 goes into the immediate).
-// Hand-issued: with an SGPR soffset the compiler inserts NO wait state between a buffer_store_dwordx4 and a
-// following VALU write of its data registers (it assumes that form is exempt from the >64-bit store-data hazard).
-// On gfx950 it is not: a v_pk_mul_f32 scheduled right behind the store corrupted bytes 4-5 of lanes 12-15 of
-// every 16 in memory (found as NaN weight gradients; the same code through global_store_dwordx4 was clean).
-// srd = {base_lo, base_hi, bytes, 0x00020000} in SGPRs.  The compiler's vmcnt bookkeeping does not see this
-// store; an uncounted store can only make its later counted waits stricter, never too weak.
-typedef int i32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ i32x4 make_srd(const void* base, uint32_t bytes) {
-  const unsigned long long b = (unsigned long long)base;
-  i32x4 d;
-  d[0] = __builtin_amdgcn_readfirstlane((int)(uint32_t)b);
-  d[1] = __builtin_amdgcn_readfirstlane((int)(uint32_t)(b >> 32)) & 0xffff;
-  d[2] = (int)bytes; d[3] = 0x00020000;
-  return d;
-}
-#define ISDF_BSTORE16_NT(IMM) \
-  asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen offset:" #IMM " nt\n\ts_nop 1" ::"v"(v), "v"(voff), "s"(srd), "s"(soff) : "memory")
-#define ISDF_BSTORE16_DF(IMM) \
-  asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen offset:" #IMM "\n\ts_nop 1" ::"v"(v), "v"(voff), "s"(srd), "s"(soff) : "memory")
-template <bool NT = true>
-__device__ __forceinline__ void bstore16_nt(uint4 x, i32x4 srd, int voff, int soff, int c) {
-  u32x4 v; v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w;
-  soff += (c >> 2) * 4096;
-  if (NT) {
-    switch (c & 3) {
-      case 0: ISDF_BSTORE16_NT(0); break;
-      case 1: ISDF_BSTORE16_NT(1024); break;
-      case 2: ISDF_BSTORE16_NT(2048); break;
-      default: ISDF_BSTORE16_NT(3072); break;
-    }
-  } else {
-    switch (c & 3) {
-      case 0: ISDF_BSTORE16_DF(0); break;
-      case 1: ISDF_BSTORE16_DF(1024); break;
-      case 2: ISDF_BSTORE16_DF(2048); break;
-      default: ISDF_BSTORE16_DF(3072); break;
-    }
-  }
-}
-
-__device__ __forceinline__ int swz(int row, int colbytes) { return colbytes ^ ((row & 15) << 4); }
 
 // C[FB*32 feats][PB*32 pts] += Wpacked[feat][k] * X[pt][k]  over KSTEPS*16 k.
 // Measured: a workgroup's time is a serial latency chain, and a staged
@@ -202,6 +128,11 @@ __device__ __forceinline__ void gemm(f32x16 (&acc)[FBN][PBN], WChunk<FBN, CKF>& 
   const int xlane = j * ROWB + ((hi * 16) ^ ((j & 15) << 4));   // byte offset from the tile base (kept an offset so the LDS address space survives)
   const int lane16 = lane * 16;
   preload_w(wq, rw, wr, lane16);
+#if GEMM_HOOKS_FIRST
+  earlyHook();
+  lateHook();
+  __builtin_amdgcn_sched_barrier(0);
+#endif
   // One chunk: the activation operand is read GEMM_LDS_DEPTH k-steps ahead of the MFMAs that consume it, and
   // (REFILL) each weight fragment register is re-requested for the next chunk as soon as its MFMAs have issued,
   // so CK fragment loads stay in flight across the chunk boundary with no extra registers.
@@ -259,7 +190,9 @@ __device__ __forceinline__ void gemm(f32x16 (&acc)[FBN][PBN], WChunk<FBN, CKF>& 
   // behind the last weight request, because vmcnt retires in order and a prefetch in front of a weight load
   // would put its HBM round trip into the MFMA stream -- so the last chunk's MFMAs cover its latency; the
   // rest goes out after the last MFMA, when the weight registers are dead (both early = 111 spilled VGPRs).
-#if GEMM_HOOK_BEFORE_LAST_CHUNK
+#if GEMM_HOOKS_FIRST   // what-if at a 256-VGPR budget (one workgroup per CU): the epilogue's tiles are requested behind chunk 0's weights
+  chunk(NCH - 1, std::false_type{});
+#elif GEMM_HOOK_BEFORE_LAST_CHUNK
   earlyHook();
   __builtin_amdgcn_sched_barrier(0);
   chunk(NCH - 1, std::false_type{});
@@ -267,7 +200,9 @@ __device__ __forceinline__ void gemm(f32x16 (&acc)[FBN][PBN], WChunk<FBN, CKF>& 
   chunk(NCH - 1, std::false_type{});
   earlyHook();
 #endif
+#if !GEMM_HOOKS_FIRST
   lateHook();
+#endif
 }
 
 template <int FBN, int PBN> __device__ __forceinline__ void zero_acc(f32x16 (&acc)[FBN][PBN]) {
@@ -285,58 +220,8 @@ __device__ __forceinline__ int frag16_off(int w, int fb, int pb, int qp, int lan
   return ((((w * FBN + fb) * PBN + pb) * 2 + qp) * 64 + lane) * 8;
 }
 
-// sum v over the 32 lanes that share `hi`; lane j==0 of each half stores it.  Each
-// (layer, feature) has exactly ONE owner half-wave per workgroup, so the
-// per-workgroup partial needs no atomics (same-address global atomics from 422
-// workgroups serialise at ~12 ns each and dominated the first version).
-template <int CTRL> __device__ __forceinline__ float dpp_mov(float v) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
-}
-__device__ __forceinline__ float half_wave_sum(float v) {
-  // butterfly over 32 lanes on the VALU: quad_perm xor1, xor2, row_half_mirror (8), row_mirror (16 lanes),
-  // then one swizzle for the 16<->16 exchange (__shfl_xor = 5 dependent ds_bpermute round trips:
-  // the reverse-sweep epilogues took ~15 k cycles with it, ~8 k with this)
-  v += dpp_mov<0xB1>(v);      // quad_perm [1,0,3,2]
-  v += dpp_mov<0x4E>(v);      // quad_perm [2,3,0,1]
-  v += dpp_mov<0x141>(v);     // row_half_mirror: quads 0<->1, 2<->3 (values are quad-uniform)
-  v += dpp_mov<0x140>(v);     // row_mirror: lower 8 <-> upper 8 of each 16-lane row
-  v += __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x401F));   // xor 16 within 32 lanes
-  return v;
-}
-__device__ __forceinline__ void half_wave_store(float v, float* dst, int lane) {
-  v = half_wave_sum(v);
-  if ((lane & 31) == 0) *dst = v;
-}
-
-// Softplus(beta=100, threshold=20) on the hardware's base-2 transcendental units:
-//   a = max(z, ln2/beta * log2(1 + 2^(beta*log2e*z)))
-// (softplus(z) > z always, and torch's threshold branch returns z where the
-// two differ by < 2e-11, so max() reproduces it without a select).
-constexpr float kC1 = kBeta * 1.4426950408889634f;   // beta * log2(e)
-constexpr float kC2 = 0.6931471805599453f / kBeta;   // ln2 / beta
-__device__ __forceinline__ float softplus_f(float z) {
-#if ISDF_EXP_CHEAP_EPI     // what-if (results wrong): no transcendental math in the epilogues
-  return fmaxf(z, 0.f);
-#endif
-  const float t = __builtin_amdgcn_exp2f(fminf(kC1 * z, 30.f));
-  return fmaxf(z, kC2 * __builtin_amdgcn_logf(1.f + t));
-}
-__device__ __forceinline__ float softplus_s1(float z, float& s1) {   // also sigma'(z) = t/(1+t)
-  const float t = __builtin_amdgcn_exp2f(fminf(kC1 * z, 30.f));
-  const float u = 1.f + t;
-  s1 = t * __builtin_amdgcn_rcpf(u);
-  return fmaxf(z, kC2 * __builtin_amdgcn_logf(u));
-}
-// sigma'(z) recovered from the stored activation: 1 - exp(-beta a)
-__device__ __forceinline__ float s1_from_a(float a) {
-#if ISDF_EXP_CHEAP_EPI
-  return a;
-#endif
-  return 1.f - __builtin_amdgcn_exp2f(-kC1 * a);
-}
-
 template <int HD, int EP, bool F16, int MODE>
-__global__ __launch_bounds__(chain_nw(HD) * 64, (HD <= 256 && EP == HD && chain_nw(HD) == 8 ? 4 : 2)) void chain_kernel(const ChainParams p) {
+__global__ __launch_bounds__(chain_nw(HD) * 64, (HD <= 256 && EP == HD && chain_nw(HD) == 8 && TILE_PTS == 64 ? 4 : 2)) void chain_kernel(const ChainParams p) {
   typedef Tile<HD, EP> T;
   static_assert(EP == HD || EP == 2 * HD, "padded embedding width is one or two hidden widths");
   constexpr bool WIDE_E = T::WIDE_E;
@@ -452,7 +337,11 @@ __global__ __launch_bounds__(chain_nw(HD) * 64, (HD <= 256 && EP == HD && chain_
   // embedding in the forward operand type; region 1 a bf16 copy staged for the
   // spill (dW operand A_0).
   {
+#if ISDF_PE_MAP   // a wave = (BM / NW points) x (direction slices): rows 1 KB apart land on 8 banks, so 64 points per wave was 8-way conflicted
+    const int pt = (tid % (BM / T::NW)) + (BM / T::NW) * (tid / 64), prt = (tid % 64) / (BM / T::NW);
+#else
     const int pt = tid & (BM - 1), prt = tid / BM;
+#endif
     constexpr int NPART = (T::NW * 64) / BM;
     const int64_t n = n0 + pt;
     float x0 = 0.f, x1 = 0.f, x2 = 0.f;
@@ -750,7 +639,11 @@ __global__ __launch_bounds__(chain_nw(HD) * 64, (HD <= 256 && EP == HD && chain_
     }
   lds_barrier();
   {
+#if ISDF_PE_MAP   // a wave = (BM / NW points) x (direction slices): rows 1 KB apart land on 8 banks, so 64 points per wave was 8-way conflicted
+    const int pt = (tid % (BM / T::NW)) + (BM / T::NW) * (tid / 64), prt = (tid % 64) / (BM / T::NW);
+#else
     const int pt = tid & (BM - 1), prt = tid / BM;
+#endif
     constexpr int NPART = T::NPART;
     const float y0 = xs[pt * 4], y1 = xs[pt * 4 + 1], y2 = xs[pt * 4 + 2];
     const char* row = X + pt * ROWB;
@@ -941,7 +834,11 @@ __global__ __launch_bounds__(chain_nw(HD) * 64, (HD <= 256 && EP == HD && chain_
   // ------------------------------------------------------------------ Ebar = J_pe gbar  -> region 2 (bf16)
   if (tid < HD / 4) ((float4*)part)[tid] = ((const float4*)(p.params + L.offWout))[tid];   // w_out for the top epilogue
   {
+#if ISDF_PE_MAP   // a wave = (BM / NW points) x (direction slices): rows 1 KB apart land on 8 banks, so 64 points per wave was 8-way conflicted
+    const int pt = (tid % (BM / T::NW)) + (BM / T::NW) * (tid / 64), prt = (tid % 64) / (BM / T::NW);
+#else
     const int pt = tid & (BM - 1), prt = tid / BM;
+#endif
     constexpr int NPART = (T::NW * 64) / BM;
     const float y0 = xs[pt * 4], y1 = xs[pt * 4 + 1], y2 = xs[pt * 4 + 2];
     const float b0 = gbs[pt * 4], b1 = gbs[pt * 4 + 1], b2 = gbs[pt * 4 + 2];
@@ -1119,9 +1016,17 @@ static int launch_mode(const ChainParams& p, int64_t nTiles, hipStream_t st) {
   return p.lay.fwd_f16 ? launch_one<512, 512, true, MODE>(p, nTiles, st) : launch_one<512, 512, false, MODE>(p, nTiles, st);
 }
 
+bool pair_supported(const NetLayout& l);
+int launch_chain_pair(const ChainParams& p, int64_t nTiles, hipStream_t st);
+
 int launch_chain(const ChainParams& p, int mode, int64_t nTiles, hipStream_t st) {
   if (!layout_supported(p.lay)) return ISDF_EUNSUPPORTED;
   if (nTiles <= 0) return ISDF_OK;
+  // ISDF_CHAIN_PAIR=1: train mode of the 256-wide nets with a 256-wide padded embedding goes through the pair-tile
+  // kernel (chain_pair.hip: one workgroup per CU owning two tiles, shared weight fetches, requests a stage ahead).
+  // Measured 208 vs 193 us on the BASELINE batch, so it is opt-in; same results (tests/test_gpu_parity.py).
+  const char* e = getenv("ISDF_CHAIN_PAIR");
+  if (mode == 2 && TILE_PTS == 64 && e && e[0] == '1' && pair_supported(p.lay)) return launch_chain_pair(p, nTiles, st);
   switch (mode) {
     case 0: return launch_mode<0>(p, nTiles, st);
     case 1: return launch_mode<1>(p, nTiles, st);

@@ -1,0 +1,150 @@
+// Device helpers shared by the tile kernels (chain.hip: one 64-point tile per workgroup, two workgroups per CU;
+// chain_pair.hip: two tiles per workgroup, one workgroup per CU): LDS-only barrier, buffer-descriptor loads and the
+// hand-issued spill store, swizzle, DPP half-wave reductions, Softplus(beta = 100) on the base-2 units.
+#pragma once
+#include "isdf_common.h"
+#include "chain_params.h"
+
+namespace isdf {
+
+// what-if experiments (timing only, results wrong; never set in a shipped build)
+#ifndef ISDF_EXP_NO_BARRIER
+#define ISDF_EXP_NO_BARRIER 0
+#endif
+#ifndef ISDF_EXP_CHEAP_EPI
+#define ISDF_EXP_CHEAP_EPI 0
+#endif
+#ifndef ISDF_BSTORE_REUNIFORM
+#define ISDF_BSTORE_REUNIFORM 0
+#endif
+#ifndef ISDF_PE_MAP
+#define ISDF_PE_MAP 1      // thread mapping of the PE-shaped stages (0: one point per lane, the round-1/2 mapping)
+#endif
+constexpr float kHalfPi = 1.5707963267948966f;
+constexpr float kBeta = 100.f;
+
+// Workgroup barrier that only waits for this wave's LDS traffic.  The global
+// spill tiles are thread-private (the lane that stores a piece is the lane that
+// re-reads it), so global stores/loads may stay in flight across the barrier;
+// __syncthreads() would drain them (s_waitcnt vmcnt(0)) at every layer.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#if !ISDF_EXP_NO_BARRIER   // what-if (results wrong): waves of a workgroup run unsynchronised
+  __builtin_amdgcn_s_barrier();
+#endif
+  asm volatile("" ::: "memory");
+}
+
+// All global traffic of the hot loops goes through buffer descriptors: address = SGPR descriptor + SGPR offset +
+// ONE per-lane VGPR (lane*16) + immediate.  With flat 64-bit addresses the compiler kept a VGPR pair per matrix /
+// spill tensor alive across the layer loops, spilled them, and reloaded them inside the MFMA stream behind
+// s_waitcnt vmcnt(0).
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+__device__ __forceinline__ rsrc_t make_rsrc(const void* base, uint32_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, bytes, 0x00020000);
+}
+constexpr int kAuxNT = 2;   // non-temporal: the spill stream must not evict the L2-resident weight copies
+template <int AUX> __device__ __forceinline__ uint4 bload16(rsrc_t r, int voff, int soff) {
+  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, AUX);
+  return make_uint4(v[0], v[1], v[2], v[3]);
+}
+// 16-byte non-temporal store of frag16 piece `c` (byte c*1024 past soff; c&3 goes into the immediate).
+// Hand-issued: with an SGPR soffset the compiler inserts NO wait state between a buffer_store_dwordx4 and a
+// following VALU write of its data registers (it assumes that form is exempt from the >64-bit store-data hazard).
+// On gfx950 it is not: a v_pk_mul_f32 scheduled right behind the store corrupted bytes 4-5 of lanes 12-15 of
+// every 16 in memory (found as NaN weight gradients; the same code through global_store_dwordx4 was clean).
+// srd = {base_lo, base_hi, bytes, 0x00020000} in SGPRs.  The compiler's vmcnt bookkeeping does not see this
+// store; an uncounted store can only make its later counted waits stricter, never too weak.
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ i32x4 make_srd(const void* base, uint32_t bytes) {
+  const unsigned long long b = (unsigned long long)base;
+  i32x4 d;
+  d[0] = __builtin_amdgcn_readfirstlane((int)(uint32_t)b);
+  d[1] = __builtin_amdgcn_readfirstlane((int)(uint32_t)(b >> 32)) & 0xffff;
+  d[2] = (int)bytes; d[3] = 0x00020000;
+  return d;
+}
+#define ISDF_BSTORE16_NT(IMM) \
+  asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen offset:" #IMM " nt\n\ts_nop 1" ::"v"(v), "v"(voff), "s"(srd), "s"(soff) : "memory")
+#define ISDF_BSTORE16_DF(IMM) \
+  asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen offset:" #IMM "\n\ts_nop 1" ::"v"(v), "v"(voff), "s"(srd), "s"(soff) : "memory")
+template <bool NT = true>
+__device__ __forceinline__ void bstore16_nt(uint4 x, i32x4 srd, int voff, int soff, int c) {
+  u32x4 v; v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w;
+  soff += (c >> 2) * 4096;
+#if ISDF_BSTORE_REUNIFORM   // the descriptor may have been moved to VGPRs under SGPR pressure: bring it back for the "s" operands
+  srd[0] = __builtin_amdgcn_readfirstlane(srd[0]); srd[1] = __builtin_amdgcn_readfirstlane(srd[1]);
+  srd[2] = __builtin_amdgcn_readfirstlane(srd[2]); srd[3] = __builtin_amdgcn_readfirstlane(srd[3]);
+  soff = __builtin_amdgcn_readfirstlane(soff);
+#endif
+  if (NT) {
+    switch (c & 3) {
+      case 0: ISDF_BSTORE16_NT(0); break;
+      case 1: ISDF_BSTORE16_NT(1024); break;
+      case 2: ISDF_BSTORE16_NT(2048); break;
+      default: ISDF_BSTORE16_NT(3072); break;
+    }
+  } else {
+    switch (c & 3) {
+      case 0: ISDF_BSTORE16_DF(0); break;
+      case 1: ISDF_BSTORE16_DF(1024); break;
+      case 2: ISDF_BSTORE16_DF(2048); break;
+      default: ISDF_BSTORE16_DF(3072); break;
+    }
+  }
+}
+
+__device__ __forceinline__ int swz(int row, int colbytes) { return colbytes ^ ((row & 15) << 4); }
+
+// sum v over the 32 lanes that share `hi`; lane j==0 of each half stores it.  Each
+// (layer, feature) has exactly ONE owner half-wave per workgroup, so the
+// per-workgroup partial needs no atomics (same-address global atomics from 422
+// workgroups serialise at ~12 ns each and dominated the first version).
+template <int CTRL> __device__ __forceinline__ float dpp_mov(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float half_wave_sum(float v) {
+  // butterfly over 32 lanes on the VALU: quad_perm xor1, xor2, row_half_mirror (8), row_mirror (16 lanes),
+  // then one swizzle for the 16<->16 exchange (__shfl_xor = 5 dependent ds_bpermute round trips:
+  // the reverse-sweep epilogues took ~15 k cycles with it, ~8 k with this)
+  v += dpp_mov<0xB1>(v);      // quad_perm [1,0,3,2]
+  v += dpp_mov<0x4E>(v);      // quad_perm [2,3,0,1]
+  v += dpp_mov<0x141>(v);     // row_half_mirror: quads 0<->1, 2<->3 (values are quad-uniform)
+  v += dpp_mov<0x140>(v);     // row_mirror: lower 8 <-> upper 8 of each 16-lane row
+  v += __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x401F));   // xor 16 within 32 lanes
+  return v;
+}
+__device__ __forceinline__ void half_wave_store(float v, float* dst, int lane) {
+  v = half_wave_sum(v);
+  if ((lane & 31) == 0) *dst = v;
+}
+
+// Softplus(beta=100, threshold=20) on the hardware's base-2 transcendental units:
+//   a = max(z, ln2/beta * log2(1 + 2^(beta*log2e*z)))
+// (softplus(z) > z always, and torch's threshold branch returns z where the
+// two differ by < 2e-11, so max() reproduces it without a select).
+constexpr float kC1 = kBeta * 1.4426950408889634f;   // beta * log2(e)
+constexpr float kC2 = 0.6931471805599453f / kBeta;   // ln2 / beta
+__device__ __forceinline__ float softplus_f(float z) {
+#if ISDF_EXP_CHEAP_EPI     // what-if (results wrong): no transcendental math in the epilogues
+  return fmaxf(z, 0.f);
+#endif
+  const float t = __builtin_amdgcn_exp2f(fminf(kC1 * z, 30.f));
+  return fmaxf(z, kC2 * __builtin_amdgcn_logf(1.f + t));
+}
+__device__ __forceinline__ float softplus_s1(float z, float& s1) {   // also sigma'(z) = t/(1+t)
+  const float t = __builtin_amdgcn_exp2f(fminf(kC1 * z, 30.f));
+  const float u = 1.f + t;
+  s1 = t * __builtin_amdgcn_rcpf(u);
+  return fmaxf(z, kC2 * __builtin_amdgcn_logf(u));
+}
+// sigma'(z) recovered from the stored activation: 1 - exp(-beta a)
+__device__ __forceinline__ float s1_from_a(float a) {
+#if ISDF_EXP_CHEAP_EPI
+  return a;
+#endif
+  return 1.f - __builtin_amdgcn_exp2f(-kC1 * a);
+}
+
+}  // namespace isdf

@@ -9,7 +9,10 @@ namespace isdf {
 
 constexpr int MAXL = 16;       // max hidden layers (2B+2)
 constexpr int N_DIRS = 21;     // icosahedron directions, embedding.py:40-62
-constexpr int TILE_PTS = 64;   // points per chain-kernel workgroup (two workgroups per CU)
+#ifndef ISDF_TILE_PTS
+#define ISDF_TILE_PTS 64
+#endif
+constexpr int TILE_PTS = ISDF_TILE_PTS;   // points per chain-kernel workgroup (64: two workgroups per CU)
 constexpr int DW_PTS = 64;     // points per dW-kernel stage (half a chain tile)
 #ifndef ISDF_CHAIN_NW
 #define ISDF_CHAIN_NW 8
@@ -18,7 +21,10 @@ constexpr int CHAIN_NW = ISDF_CHAIN_NW;    // waves per chain-kernel workgroup (
 // the 512-wide instantiation always runs 8 waves (one workgroup per CU)
 constexpr int chain_nw(int hd) { return hd == 256 ? CHAIN_NW : 8; }
 // weight fragments a wave requests at once: 8 (32 VGPRs) at the 128-VGPR budget of 8-wave workgroups, 16 at 4 waves
-constexpr int chain_chunk_frags(int nw) { return nw == 8 ? 8 : 16; }
+#ifndef ISDF_CHUNK_FRAGS
+#define ISDF_CHUNK_FRAGS 8
+#endif
+constexpr int chain_chunk_frags(int nw) { return nw == 8 ? ISDF_CHUNK_FRAGS : 16; }
 constexpr int DW_SPLITK = 36;  // K-splits per dW unit (7 units x 36 = 252 workgroups)
 #ifndef ISDF_SLAB_BF16
 #define ISDF_SLAB_BF16 0       // 1: the K-split partial slabs are stored as bf16 (half the slab traffic of dW + step tail)
@@ -170,6 +176,7 @@ __host__ __device__ inline DwUnit dw_unit(const NetLayout& l, int u) {
 
 inline void make_workspace(const NetLayout& l, int64_t maxPts, int64_t maxRays, bool train, WorkspaceLayout* w) {
   w->nTiles = (maxPts + TILE_PTS - 1) / TILE_PTS;
+  w->nTiles += w->nTiles & 1;   // even: the pair-tile kernel (chain_pair.hip) owns two tiles per workgroup
   SpillLayout& s = w->sp;
   s.tensorElems = TILE_PTS * (int64_t)l.HD;   // offsets below are WITHIN a tile's block
   int64_t o = 0;

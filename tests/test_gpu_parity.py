@@ -710,12 +710,15 @@ def test_base_size_forward_and_input_gradient_vs_reference(case):
     assert gu.rel_err(grad, g["sdf_grad"].reshape(-1, 3)) < TOL_SDF_GRAD
 
 
+@pytest.mark.parametrize("pair", [False, True], ids=["tile", "pair"])
 @pytest.mark.parametrize("case,src", [("eval_base_680x1200_ray", None), ("eval_base_480x640_ray", None),
                                       ("eval_base_680x1200_pc", "eval_base_680x1200_ray")])
-def test_base_size_train_step_vs_reference_and_oracle(case, src):
-    """The training step at BASELINE size -- where the 422-tile grid, the 36 K-splits of the dW kernel and the
+def test_base_size_train_step_vs_reference_and_oracle(case, src, pair, monkeypatch):
+    """(pair: the same through the opt-in pair-tile kernel, csrc/chain_pair.hip, ISDF_CHAIN_PAIR=1.)
+    The training step at BASELINE size -- where the 422-tile grid, the 36 K-splits of the dW kernel and the
     680x1200 bin geometry are exercised -- against what the REAL reference produced (four loss means, per-frame
     block averages, norm / probe / head digests of all 14 gradients) and against the oracle tensor by tensor."""
+    monkeypatch.setenv("ISDF_CHAIN_PAIR", "1" if pair else "0")   # read by launch_chain at every launch
     g = gu.load(case)
     if src is not None:                                  # slim fixture: same seed and draws as its sibling
         full = gu.load(src)
@@ -769,14 +772,16 @@ def _replay_hip_steps(g, eng, lc, sc, n_steps, fused):
     return out
 
 
+@pytest.mark.parametrize("pair", [False, True], ids=["tile", "pair"])
 @pytest.mark.parametrize("fused", [False, True])
-def test_hip_step_x3_default_net_vs_reference_fixture(fused):
+def test_hip_step_x3_default_net_vs_reference_fixture(fused, pair, monkeypatch):
     """`step_full_k7`: the unmodified reference `Trainer.step` x3 with the DEFAULT 6x256 net and K=7 > window
     (select_keyframes windows, quirk q4).  HIP path on the same windows and draws: per-step losses and
     frame_avg_losses vs the reference, the AdamW moments tensor by tensor vs the oracle trajectory (exp_avg is
     linear in the gradients: 1e-2; exp_avg_sq quadratic: 2e-2), and the reference's digests of the parameter
     update and both moments."""
     from tests.test_oracle_golden import replay_step_fixture, check_step_digests
+    monkeypatch.setenv("ISDF_CHAIN_PAIR", "1" if pair else "0")   # pair: the opt-in pair-tile kernel (chain_pair.hip)
     g = gu.load("step_full_k7")
     eng = _engine(g)
     lc, sc = _cfgs(g)
@@ -1043,3 +1048,54 @@ def test_sampler_ray_count_sweep(F, n):
             near = torch.clamp(ds[ok][:, None] + N_off[:R], min=sc.min_depth)
             near = torch.minimum(near, (ds[ok] + sc.dist_behind_surf)[:, None])
             assert torch.equal(s["z_vals"][:R, 0], ds[ok]) and torch.allclose(s["z_vals"][:R, 1:sc.n_surf], near, rtol=0, atol=1e-6)
+
+
+# ---- the opt-in pair-tile chain kernel (csrc/chain_pair.hip, ISDF_CHAIN_PAIR=1): same formats, same results ----------
+def test_pair_kernel_equals_single_tile_kernel(monkeypatch):
+    """Even tiles (first half of a pair) are bit-identical to the one-tile kernel up to the loss stage; every gradient
+    tensor agrees to fp32 re-association + bf16 flips (1e-3), and the pair kernel is deterministic."""
+    g = gu.load("eval_base_680x1200_ray")
+    monkeypatch.setenv("ISDF_CHAIN_PAIR", "0")
+    eng, s, dbg, _, _, R = _run_step(g, oracle=False)
+    ref_grad, ref_sdf = eng.reduce_buf.clone(), dbg["sdf"].clone()
+    monkeypatch.setenv("ISDF_CHAIN_PAIR", "1")
+    outs = []
+    for _ in range(2):
+        eng2, s2, dbg2, _, _, R2 = _run_step(g, oracle=False)
+        outs.append((eng2.reduce_buf.clone(), dbg2["sdf"].clone()))
+    assert R2 == R
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])   # deterministic
+    S = g["z_vals"].shape[1]
+    sdf1, sdf2 = ref_sdf[:R].reshape(-1), outs[0][1][:R].reshape(-1)
+    even = (torch.arange(R * S, device=sdf1.device) // 64) % 2 == 0
+    assert torch.equal(sdf1[even], sdf2[even])                       # first halves: same k order, same bits
+    assert gu.rel_err(sdf2.cpu().numpy(), sdf1.cpu().numpy()) < 1e-6   # second halves too (same k order)
+    for k, (off, shp) in eng.slices.items():
+        n = int(np.prod(shp))
+        a, b = ref_grad[off:off + n].cpu().numpy(), outs[0][0][off:off + n].cpu().numpy()
+        assert gu.rel_err(b, a) < 1e-3, k
+
+
+def test_pair_kernel_ragged_sizes(monkeypatch):
+    """1 .. 26 rays per keyframe x 5 keyframes x 27 points (1 .. 55 tiles, odd and even counts, a lone first half, a
+    partial last tile): loss sums, point count and all gradients of the pair kernel against the one-tile kernel."""
+    import dataclasses
+    g = gu.load("eval_base_680x1200_ray")
+    eng = _engine(g)
+    lc, sc = _cfgs(g)
+    d, T, n = _dev(g["depth_batch"]), _dev(g["T_WC_batch"]), _dev(g["normal_batch"])
+    idx = torch.arange(d.shape[0], dtype=torch.int32, device="cuda")
+    for nr in (1, 2, 3, 5, 13, 26):
+        sc2 = dataclasses.replace(sc, n_rays=nr)
+        s = eng.sample(d, T, n, idx, idx, sc2, seed=3, offset=nr)
+        monkeypatch.setenv("ISDF_CHAIN_PAIR", "0")
+        eng.train_step(s, lc, sc2)
+        a = eng.reduce_buf.clone()
+        monkeypatch.setenv("ISDF_CHAIN_PAIR", "1")
+        eng.train_step(s, lc, sc2)
+        b = eng.reduce_buf.clone()
+        torch.cuda.synchronize()
+        np_ = eng.n_params
+        assert a[np_ + 4].item() > 0 and torch.equal(a[np_ + 4], b[np_ + 4])                  # same point count
+        assert gu.rel_err(b[np_:np_ + 4].cpu().numpy(), a[np_:np_ + 4].cpu().numpy()) < 1e-5, nr
+        assert gu.rel_err(b[:np_].cpu().numpy(), a[:np_].cpu().numpy()) < 2e-3, nr

@@ -16,12 +16,12 @@ def main():
     for name, flags in variants:
         mine = dict(objs)
         jobs = []
-        for src in ("chain.hip", "dw.hip", "optim.hip", "sampler.hip"):
+        for src in ("chain.hip", "chain_pair.hip", "dw.hip", "optim.hip", "sampler.hip"):
             if not flags:
                 continue
             o = os.path.join(ROOT, "variants", "%s_%s.o" % (name, src[:-4]))
             mine[src] = o
-            jobs.append(subprocess.Popen([b._hipcc()] + b.FLAGS + flags.split() + ["-c", os.path.join(b.CSRC, src), "-o", o]))
+            jobs.append(subprocess.Popen([b._hipcc()] + b.FLAGS + b.PER_FILE.get(src, []) + flags.split() + ["-c", os.path.join(b.CSRC, src), "-o", o]))
         procs.append((name, mine, jobs))
     for name, mine, jobs in procs:
         for j in jobs:
