@@ -56,6 +56,15 @@ namespace isdf {
 #ifndef ISDF_NT_P
 #define ISDF_NT_P 1            // 0: P (d sdf / d z) stored with the default cache policy
 #endif
+#ifndef ISDF_VISIBLE_STORES
+#define ISDF_VISIBLE_STORES 0  // 1: spill stores through the builtin with soffset = 0 (compiler-counted; see chain_pair.hip) instead of
+#endif                         //    the hand-issued SGPR-soffset form
+#if ISDF_VISIBLE_STORES
+#define CH_STORE(NT, X, SOFF, C) do { const uint4 x_ = (X); u32x4 v_; v_[0] = x_.x; v_[1] = x_.y; v_[2] = x_.z; v_[3] = x_.w; \
+    __builtin_amdgcn_raw_buffer_store_b128(v_, rsS, lane16 + (SOFF) + (C) * 1024, 0, (NT) ? kAuxNT : 0); } while (0)
+#else
+#define CH_STORE(NT, X, SOFF, C) bstore16_nt<(NT)>((X), srdS, lane16, (SOFF), (C))
+#endif
 #ifndef GEMM_LDS_DEPTH
 #define GEMM_LDS_DEPTH 1   // k-steps of activation-operand LDS reads in flight ahead of the MFMAs
 #endif
@@ -390,7 +399,7 @@ __global__ __launch_bounds__(chain_nw(HD) * 64, (HD <= 256 && EP == HD && chain_
             lo = pack4<false>((float)a[0], (float)a[1], (float)a[2], (float)a[3]);
             hi2 = pack4<false>((float)b[0], (float)b[1], (float)b[2], (float)b[3]);
           }
-          bstore16_nt(make_uint4(lo.x, lo.y, hi2.x, hi2.y), srdS, lane16, sbase(tensorOff), cidx(fb, pb, qp));
+          CH_STORE(true, make_uint4(lo.x, lo.y, hi2.x, hi2.y), sbase(tensorOff), cidx(fb, pb, qp));
         }
   };
   refresh();
@@ -449,16 +458,16 @@ __global__ __launch_bounds__(chain_nw(HD) * 64, (HD <= 256 && EP == HD && chain_
   };
   auto store_tile8 = [&](int64_t tensorOff, int fb, int pb, int qp, const float (&v)[8]) {
     const uint2 a = pack4<false>(v[0], v[1], v[2], v[3]), b = pack4<false>(v[4], v[5], v[6], v[7]);
-    bstore16_nt(make_uint4(a.x, a.y, b.x, b.y), srdS, lane16, sbase(tensorOff), cidx(fb, pb, qp));
+    CH_STORE(true, make_uint4(a.x, a.y, b.x, b.y), sbase(tensorOff), cidx(fb, pb, qp));
   };
   auto store_tile8_p = [&](int64_t tensorOff, int fb, int pb, int qp, const float (&v)[8]) {
     const uint2 a = pack4<false>(v[0], v[1], v[2], v[3]), b = pack4<false>(v[4], v[5], v[6], v[7]);
-    bstore16_nt<ISDF_NT_P != 0>(make_uint4(a.x, a.y, b.x, b.y), srdS, lane16, sbase(tensorOff), cidx(fb, pb, qp));
+    CH_STORE(ISDF_NT_P != 0, make_uint4(a.x, a.y, b.x, b.y), sbase(tensorOff), cidx(fb, pb, qp));
   };
   // tensors that only the dW kernel re-reads (GB, ZB): cache policy is an A/B switch
   auto store_tile8_dw = [&](int64_t tensorOff, int fb, int pb, int qp, const float (&v)[8]) {
     const uint2 a = pack4<false>(v[0], v[1], v[2], v[3]), b = pack4<false>(v[4], v[5], v[6], v[7]);
-    bstore16_nt<ISDF_NT_DW_TENSORS != 0>(make_uint4(a.x, a.y, b.x, b.y), srdS, lane16, sbase(tensorOff), cidx(fb, pb, qp));
+    CH_STORE(ISDF_NT_DW_TENSORS != 0, make_uint4(a.x, a.y, b.x, b.y), sbase(tensorOff), cidx(fb, pb, qp));
   };
   auto put_x = [&](bool f16, int fb, int pb, int qp, const float (&v)[8], int colElemBase) {
     uint2 a, b;

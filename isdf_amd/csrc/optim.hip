@@ -113,7 +113,7 @@ struct FinalizeArgs {
 };
 // binS: 32.32 fixed point -- integer LDS atomics are order-independent, so the bins (hence frame_avg_losses and
 // the keyframe-selection probabilities built from them) are bit-reproducible; float atomics are not
-struct FinalizeLds { float sh[16][8]; unsigned long long binS[64]; float binC[64]; int range[2]; uint32_t keys[FIN_CAP]; };
+struct FinalizeLds { float sh[16][8]; unsigned long long binS[64]; float binC[64]; int range[2]; int cnt[16][2]; uint32_t keys[FIN_CAP]; };
 
 __device__ __forceinline__ void finalize_block(int block, const FinalizeArgs& a, FinalizeLds& lds) {
   const float* __restrict__ wg_loss = a.wg_loss; const int64_t maxTiles = a.maxTiles; const int S = a.S;
@@ -148,13 +148,23 @@ __device__ __forceinline__ void finalize_block(int block, const FinalizeArgs& a,
     return;
   }
   const int f = block - 1;
-  if (tid < 2) {  // lower_bound(indices_b, f + tid): rays are sorted by frame
-    int64_t lo = 0, hi = R;
-    const int64_t key = f + tid;
-    while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (ib[mid] < key) lo = mid + 1; else hi = mid; }
-    range[tid] = (int)lo;
+  // lower_bound(indices_b, f) and lower_bound(indices_b, f + 1): the rays are sorted by frame, so both are COUNTS
+  // (rays of earlier frames / of frames <= f), taken by all threads in one memory round trip.  (A two-thread binary search
+  // here was ten dependent round trips, ~10 us, and set the duration of the whole step-tail launch.)
+  {
+    int c0 = 0, c1 = 0;
+    for (int64_t r = tid; r < R; r += 1024) { const int64_t b = ib[r]; c0 += b < f; c1 += b <= f; }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) { c0 += __shfl_xor(c0, m, 64); c1 += __shfl_xor(c1, m, 64); }
+    if (lane == 0) { lds.cnt[wv][0] = c0; lds.cnt[wv][1] = c1; }
   }
   if (tid < 64) { binS[tid] = 0ull; binC[tid] = 0.f; }
+  __syncthreads();
+  if (tid < 2) {
+    int c = 0;
+    for (int k = 0; k < 16; ++k) c += lds.cnt[k][tid];
+    range[tid] = c;
+  }
   __syncthreads();
   const int lo = range[0], n = range[1] - range[0];
   const bool staged = n <= FIN_CAP;
@@ -221,6 +231,9 @@ __device__ __forceinline__ int64_t packed_elem(int row, int k, int Kp) {
 
 // PHASE 0: everything (single GPU).  PHASE 1: reduction + finalisation only (isdf_train_step: the gradient
 // sums go to the all-reduce).  PHASE 2: AdamW + operand repack from an already reduced gradient (isdf_adamw).
+#ifndef ISDF_TAIL_UNROLL
+#define ISDF_TAIL_UNROLL 36
+#endif
 template <int PHASE>
 __global__ __launch_bounds__(1024) void step_tail_kernel(const TailParams p) {
   __shared__ FinalizeLds lds;
@@ -251,7 +264,9 @@ __global__ __launch_bounds__(1024) void step_tail_kernel(const TailParams p) {
     if (PHASE == 2) s = p.grad[pi];
     else {
       const slab_t* src = (const slab_t*)p.dwPart + (int64_t)unit * DW_SPLITK * perUnit + rem;
-#pragma unroll 4
+      // all K-split slabs of this element in flight at once: with 4 at a time the kernel was nine dependent HBM round
+      // trips long (23-26 us for 88 MB)
+#pragma unroll ISDF_TAIL_UNROLL
       for (int k = 0; k < DW_SPLITK; ++k) {
 #if ISDF_SLAB_BF16
         s += __uint_as_float((uint32_t)src[(int64_t)k * perUnit] << 16);
@@ -290,6 +305,18 @@ __global__ __launch_bounds__(1024) void step_tail_kernel(const TailParams p) {
   float s = 0.f, s2 = 0.f;
   if (dst >= 0) {
     int t = g;
+    for (; t + 112 < nTiles; t += 128) {    // 8 (16 with slotB) independent loads in flight per thread
+      const float* r0 = p.vecPart + (int64_t)t * p.vecStride;
+      float a[8], bb[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) a[q] = r0[(int64_t)(16 * q) * p.vecStride + slotA];
+      if (slotB >= 0) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) bb[q] = r0[(int64_t)(16 * q) * p.vecStride + slotB];
+        s2 += ((bb[0] + bb[1]) + (bb[2] + bb[3])) + ((bb[4] + bb[5]) + (bb[6] + bb[7]));
+      }
+      s += ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+    }
     for (; t + 48 < nTiles; t += 64) {      // 4 independent loads in flight per thread
       const float* r0 = p.vecPart + (int64_t)t * p.vecStride;
       const float a0 = r0[slotA], a1 = r0[(int64_t)16 * p.vecStride + slotA],

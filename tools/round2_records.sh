@@ -15,6 +15,8 @@ done
 python $R/bench.py --sampler-scale 200000 --steps 300 2>/dev/null | tail -1 > $O/bench_sampler_1M.json
 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_sampler -- python $R/bench.py --sampler-scale 200000 --steps 100 > $O/stats_sampler.log 2>&1
 python $R/tools/timeline.py > $O/timeline.txt 2>&1
+ISDF_CHAIN_PAIR=1 python $R/bench.py --steps 300 --warmup 50 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_pair_kernel.json
+python $R/tools/timeline_pair.py > $O/timeline_pair.txt 2>&1
 python $R/bench.py --rays-per-frame 5400 --steps 30 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_729k.json
 python $R/bench.py --wide --steps 30 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_wide.json
 python - <<'PY'
