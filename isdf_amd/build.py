@@ -19,7 +19,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-com
 
 # per-source extra flags: the pair-tile kernel sits at the 256-VGPR budget; the GCN register-pressure trackers halve
 # its spill count (25 -> 0..6 spilled VGPRs)
-PER_FILE = {"chain_pair.hip": ["-mllvm", "-amdgpu-use-amdgpu-trackers=1"]}
+PER_FILE = {"chain_pair.hip": ["-mllvm", "-amdgpu-use-amdgpu-trackers=1", "-Wno-pass-failed"]}
 
 
 def _hipcc():

@@ -37,6 +37,21 @@ namespace isdf {
 #ifndef ISDF_DEBUG_HOOKS
 #define ISDF_DEBUG_HOOKS 0
 #endif
+#ifndef ISDF_PAIR_INTERLEAVE
+#define ISDF_PAIR_INTERLEAVE 0   // 1: a stage's epilogue (VALU, other half) and GEMM (MFMA) are ONE scheduling region, interleaved by
+#endif                           //    sched_group_barrier: the epilogue's VALU issues in the shadow of the MFMAs of the same wave
+#if ISDF_PAIR_INTERLEAVE
+#define PAIR_SB() ((void)0)
+// a VOLATILE asm is ordered against every memory operation: one in front of the GEMM would pin the whole epilogue (its
+// stores, hence its arithmetic) ahead of the GEMM's first LDS read
+#define PAIR_OPAQUE(x) asm("" : "+v"(x))
+#else
+#define PAIR_SB() __builtin_amdgcn_sched_barrier(0)
+#define PAIR_OPAQUE(x) asm volatile("" : "+v"(x))
+#endif
+#ifndef ISDF_PAIR_VALU_PER_MFMA
+#define ISDF_PAIR_VALU_PER_MFMA 12
+#endif
 #ifndef GEMM_PAIR_LDS_DEPTH
 #define GEMM_PAIR_LDS_DEPTH 2
 #endif
@@ -98,7 +113,7 @@ __device__ __forceinline__ void gemm_half(f32x16 (&acc)[2], uint4 (&W)[16], rsrc
 #pragma unroll
   for (int ch = 0; ch < KSTEPS / 8; ++ch) {
     xch[ch] = xlane + ch * 256 + colByteBase;
-    asm volatile("" : "+v"(xch[ch]));   // keep the per-k-step addresses from being hoisted out of the layer loops
+    PAIR_OPAQUE(xch[ch]);   // keep the per-k-step addresses from being hoisted out of the layer loops
   }
   auto readb = [&](int ks, v8 (&o)[2]) {
 #pragma unroll
@@ -106,7 +121,7 @@ __device__ __forceinline__ void gemm_half(f32x16 (&acc)[2], uint4 (&W)[16], rsrc
   };
 #pragma unroll
   for (int ks = 0; ks < D; ++ks) readb(ks, b[ks % (D + 1)]);
-  __builtin_amdgcn_sched_barrier(0);
+  PAIR_SB();
 #pragma unroll
   for (int ks = 0; ks < KSTEPS; ++ks) {
     const int r = ks & 15;
@@ -117,22 +132,31 @@ __device__ __forceinline__ void gemm_half(f32x16 (&acc)[2], uint4 (&W)[16], rsrc
     if (tgt < KSTEPS) W[r] = load_wfrag(rw, cur, lane16, tgt);
     else if (STAGE == 1) { if (r < 8) W[r] = load_wfrag(rw, nxt, lane16, r); }   // upper half: loadW_hi at the start of the next stage
     else if (STAGE == 0 && KSTEPS > 16) W[r] = load_wfrag(rw, cur, lane16, tgt - KSTEPS);
-    __builtin_amdgcn_sched_barrier(0);
+    PAIR_SB();
   }
 }
 
-template <int HD, bool F16>
+// NL / CAT: hidden layers and the index of the cat layer as COMPILE-TIME constants (0: read them from the layout).  With
+// constants the layer loops unroll, every stage is one basic block (no per-layer branches) and ISDF_PAIR_INTERLEAVE can
+// schedule a stage's epilogue and GEMM as one region.
+template <int HD, bool F16, int NL, int CAT>
 __global__ __launch_bounds__(512, 2) void chain_pair_kernel(const ChainParams p) {
   typedef PairTile<HD> T;
   constexpr int BM = T::BM, PB = T::PB, ROWB = T::ROWB, NPART = T::NPART, HB = TILE_PTS;
   static_assert(TILE_PTS == 64, "a half is one 64-point tile of the spill buffer");
-  extern __shared__ __attribute__((aligned(1024))) char smem[];
-  char* X = smem;
-  float* xs = (float*)(smem + T::OFF_XS);
-  float* part = (float*)(smem + T::OFF_PART);
-  float* gbs = (float*)(smem + T::OFF_GB);
-  float* rawL = (float*)(smem + T::OFF_RAW);
-  float* biasL = (float*)(smem + T::OFF_BIAS);
+  // The two halves of the activation tile are SEPARATE LDS objects: a stage's epilogue writes one and its GEMM reads the
+  // other, and only distinct objects let the compiler see that those accesses cannot alias (ISDF_PAIR_INTERLEAVE moves
+  // the GEMM's reads above the epilogue's writes).
+  __shared__ __attribute__((aligned(1024))) char X0s[TILE_PTS * T::ROWB];
+  __shared__ __attribute__((aligned(1024))) char X1s[TILE_PTS * T::ROWB];
+  __shared__ __attribute__((aligned(16))) char smallL[T::LDS_BYTES - T::XBYTES];
+  auto Xh = [&](int h) -> char* { return h ? X1s : X0s; };
+  char* const sm0 = smallL - T::XBYTES;   // the OFF_* constants count from the start of the (former single) array
+  float* xs = (float*)(sm0 + T::OFF_XS);
+  float* part = (float*)(sm0 + T::OFF_PART);
+  float* gbs = (float*)(sm0 + T::OFF_GB);
+  float* rawL = (float*)(sm0 + T::OFF_RAW);
+  float* biasL = (float*)(sm0 + T::OFF_BIAS);
   float* woutL = biasL + T::MAXLP * HD;
 
   const NetLayout& L = p.lay;
@@ -141,7 +165,7 @@ __global__ __launch_bounds__(512, 2) void chain_pair_kernel(const ChainParams p)
   int lane, j, hi, lane16, xw;
   auto refresh = [&] {   // lane constants are re-derived per phase (see chain.hip)
     int t = tid;
-    asm volatile("" : "+v"(t));
+    PAIR_OPAQUE(t);
     lane = t & 63; j = lane & 31; hi = lane >> 5; lane16 = lane * 16;
     xw = j * ROWB + 8 * hi + (((j & 15) << 4) ^ ((w & 3) * 64)) + (w >> 2) * 256;
   };
@@ -151,7 +175,8 @@ __global__ __launch_bounds__(512, 2) void chain_pair_kernel(const ChainParams p)
   if (n0 >= P) return;
   const int nf = L.n_freqs;
   const float so = L.scale_output;
-  const int nL = L.L;
+  const int nL = NL ? NL : L.L;
+  const int catL = NL ? CAT : L.cat;
 #if ISDF_DEBUG_HOOKS   // development build: wave 0 of workgroup 100 stamps every stage end (tools/timeline.py)
   int tsn = 0;
   auto TS = [&]() {   // 32-bit stamps: slots 0..255 of the 1 KB stamp area
@@ -189,7 +214,7 @@ __global__ __launch_bounds__(512, 2) void chain_pair_kernel(const ChainParams p)
 
   // weight fragment window; first unit = forward layer 0
   auto wref = [&](int64_t set, int64_t matOff, int kp) { return PRef{(int)((set + matOff) * 2) + w * (kp / 16) * 1024}; };
-  auto fwdRef = [&](int64_t set, int li) { return wref(set, L.fwdMat[li], li == L.cat ? 2 * HD : HD); };
+  auto fwdRef = [&](int64_t set, int li) { return wref(set, L.fwdMat[li], li == catL ? 2 * HD : HD); };
   auto r1Ref = [&](int li) { return wref(setBwdA, L.bwdMat[li], HD); };
   auto r2Ref = [&](int li) { return wref(setBwdB, L.bwdMat[li + 1], HD); };
   const PRef gRef = wref(setBwdA, L.bwdG, 2 * HD);
@@ -214,7 +239,7 @@ __global__ __launch_bounds__(512, 2) void chain_pair_kernel(const ChainParams p)
     const float y1 = (L.T[4] * x0 + L.T[5] * x1 + L.T[6] * x2 + L.T[7]) * L.scale_input;
     const float y2 = (L.T[8] * x0 + L.T[9] * x1 + L.T[10] * x2 + L.T[11]) * L.scale_input;
     typedef typename Op<F16>::e opT;
-    char* row = X + pt * ROWB;
+    char* row = Xh(pt >> 6) + (pt & 63) * ROWB;
     auto put = [&](int feat, float v) {
       *(opT*)(row + swz(pt, (HD + feat) * 2)) = (opT)v;        // region 2: forward operand
       *(__bf16*)(row + swz(pt, feat * 2)) = (__bf16)v;         // region 1: bf16 copy staged for the spill (dW operand A_0)
@@ -244,9 +269,9 @@ __global__ __launch_bounds__(512, 2) void chain_pair_kernel(const ChainParams p)
       for (int pb = 0; pb < PB; ++pb)
 #pragma unroll
         for (int qp = 0; qp < 2; ++qp) {
-          const int lb = (xw ^ (32 * qp)) + colElemBase * 2 + (h * HB + pb * 32) * ROWB;
-          const uint2 lo = *(const uint2*)(X + lb);
-          const uint2 hi2 = *(const uint2*)(X + (lb ^ 16));
+          const int lb = (xw ^ (32 * qp)) + colElemBase * 2 + pb * 32 * ROWB;
+          const uint2 lo = *(const uint2*)(Xh(h) + lb);
+          const uint2 hi2 = *(const uint2*)(Xh(h) + (lb ^ 16));
           u32x4 v; v[0] = lo.x; v[1] = lo.y; v[2] = hi2.x; v[3] = hi2.y;
           __builtin_amdgcn_raw_buffer_store_b128(v, rsS, lane16 + sbase(tensorOff, h) + (pb * 2 + qp) * 1024, 0, kAuxNT);
         }
@@ -311,23 +336,23 @@ __global__ __launch_bounds__(512, 2) void chain_pair_kernel(const ChainParams p)
     uint2 a, b;
     if (f16) { a = pack4<true>(v[0], v[1], v[2], v[3]); b = pack4<true>(v[4], v[5], v[6], v[7]); }
     else { a = pack4<false>(v[0], v[1], v[2], v[3]); b = pack4<false>(v[4], v[5], v[6], v[7]); }
-    const int lb = (xw ^ (32 * qp)) + colElemBase * 2 + (h * HB + pb * 32) * ROWB;
-    *(uint2*)(X + lb) = a;           // features f0 .. f0+3,  f0 = 32 w + 16 qp + 4 hi
-    *(uint2*)(X + (lb ^ 16)) = b;    // features f0+8 .. f0+11
+    const int lb = (xw ^ (32 * qp)) + colElemBase * 2 + pb * 32 * ROWB;
+    *(uint2*)(Xh(h) + lb) = a;           // features f0 .. f0+3,  f0 = 32 w + 16 qp + 4 hi
+    *(uint2*)(Xh(h) + (lb ^ 16)) = b;    // features f0+8 .. f0+11
   };
   // 8 fp32 values vec[f0 + {0..3, 8..11}] of an LDS-staged parameter vector
   auto ld_vec8 = [&](const float* vec, int qp, float (&o)[8]) {
     const float4 a = *(const float4*)(vec + w * 32 + 16 * qp + 4 * hi), b = *(const float4*)(vec + w * 32 + 16 * qp + 4 * hi + 8);
     o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
   };
-  auto xhalf = [&](int h) { return (const char*)X + h * HB * ROWB; };
+  auto xhalf = [&](int h) { return (const char*)Xh(h); };
 
   // GEMMs (half H; STAGE_B: this is the second half to use the matrix, refill the window from `nxt`)
   auto G_fwd = [&](int H, auto Bc, auto F16c, int64_t set, int li, PRef nxt) {   // forward-orientation matrix of layer li
     constexpr int SB = decltype(Bc)::value; constexpr bool OPF = decltype(F16c)::value;
     refresh();
     const PRef cur = fwdRef(set, li);
-    if (li == L.cat) gemm_half<OPF, 32, SB, ROWB>(acc, W, rsW, cur, nxt, xhalf(H), 0, lane);            // [a | emb], K = 2 HD
+    if (li == catL) gemm_half<OPF, 32, SB, ROWB>(acc, W, rsW, cur, nxt, xhalf(H), 0, lane);            // [a | emb], K = 2 HD
     else gemm_half<OPF, 16, SB, ROWB>(acc, W, rsW, cur, nxt, xhalf(H), li == 0 ? HD * 2 : 0, lane);     // layer 0 reads region 2
   };
   auto G_sq = [&](int H, auto Bc, auto F16c, PRef cur, PRef nxt) {   // K = HD from region 1
@@ -358,7 +383,7 @@ __global__ __launch_bounds__(512, 2) void chain_pair_kernel(const ChainParams p)
           for (int e = 0; e < 8; ++e) a[e] = softplus_f(acc[pb][8 * qp + e] + bv[e]);
           store_tile8(p.sp.A[li + 1], H, pb, qp, a);
           put_x(F16, H, pb, qp, a, 0);
-          __builtin_amdgcn_sched_barrier(0);
+          PAIR_SB();
         }
       }
     } else {
@@ -383,7 +408,7 @@ __global__ __launch_bounds__(512, 2) void chain_pair_kernel(const ChainParams p)
           store_tile8(p.sp.A[li + 1], H, pb, qp, a);
           put_x(F16, H, pb, qp, pl, 0);
           store_tile8_p(p.sp.P[li], H, pb, qp, pl);
-          __builtin_amdgcn_sched_barrier(0);
+          PAIR_SB();
         }
       }
 #pragma unroll
@@ -396,7 +421,7 @@ __global__ __launch_bounds__(512, 2) void chain_pair_kernel(const ChainParams p)
   auto E_r1 = [&](int H, int li, Pre& pA) {   // p_{li-1} = (p_li W_li) * sigma'(z_{li-1});  pA = A[li]
     refresh();
     pin(pA);
-    const bool toR2 = (li - 1 == L.cat);
+    const bool toR2 = (li - 1 == catL);
 #pragma unroll
     for (int qp = 0; qp < 2; ++qp)
 #pragma unroll
@@ -408,18 +433,18 @@ __global__ __launch_bounds__(512, 2) void chain_pair_kernel(const ChainParams p)
         put_x(F16, H, pb, qp, pv, 0);
         if (toR2) put_x(F16, H, pb, qp, pv, HD);
         store_tile8_p(p.sp.P[li - 1], H, pb, qp, pv);
-        __builtin_amdgcn_sched_barrier(0);
+        PAIR_SB();
       }
   };
   auto E_g = [&](int H) {   // Eg -> fp32 [64][HD] over the half's (now idle) rows
     refresh();
 #pragma unroll
     for (int pb = 0; pb < PB; ++pb) {
-      const int row = H * HB + pb * 32 + j;
+      const int row = pb * 32 + j;
 #pragma unroll
       for (int rq = 0; rq < 4; ++rq) {
         const int f0 = w * 32 + 8 * rq + 4 * hi;
-        *(float4*)(X + row * ROWB + swz(row, f0 * 4)) =
+        *(float4*)(Xh(H) + row * ROWB + swz(row, f0 * 4)) =
             make_float4(acc[pb][4 * rq], acc[pb][4 * rq + 1], acc[pb][4 * rq + 2], acc[pb][4 * rq + 3]);
       }
     }
@@ -444,7 +469,7 @@ __global__ __launch_bounds__(512, 2) void chain_pair_kernel(const ChainParams p)
         store_tile8(p.sp.INJ[li], H, pb, qp, inj);
         put_x(false, H, pb, qp, qb, 0);
         store_tile8_dw(p.sp.GB[li + 1], H, pb, qp, qb);
-        __builtin_amdgcn_sched_barrier(0);
+        PAIR_SB();
       }
   };
   auto E_adj_top = [&](int H, Pre& pA, Pre& pB) {   // top layer: also the top of the ordinary reverse sweep (chain.hip)
@@ -474,7 +499,7 @@ __global__ __launch_bounds__(512, 2) void chain_pair_kernel(const ChainParams p)
         }
         store_tile8_dw(p.sp.ZB[li], H, pb, qp, zb);
         put_x(false, H, pb, qp, zb, 0);
-        __builtin_amdgcn_sched_barrier(0);
+        PAIR_SB();
       }
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
@@ -505,7 +530,7 @@ __global__ __launch_bounds__(512, 2) void chain_pair_kernel(const ChainParams p)
         }
         store_tile8_dw(p.sp.ZB[li], H, pb, qp, zb);
         if (li > 0) put_x(false, H, pb, qp, zb, 0);
-        __builtin_amdgcn_sched_barrier(0);
+        PAIR_SB();
       }
 #pragma unroll
       for (int e = 0; e < 8; ++e) vec_store(bsum[e], li * HD + w * 32 + 16 * qp + (e & 3) + 8 * (e >> 2), H);
@@ -515,7 +540,24 @@ __global__ __launch_bounds__(512, 2) void chain_pair_kernel(const ChainParams p)
   // A stage = [epilogue of the previous GEMM] [requests for the NEXT stage's epilogue] [GEMM of the other half] barrier.
   // The epilogue and the GEMM of a stage touch different halves of the tile, so ONE barrier per GEMM is enough (chain.hip
   // needs two) and one accumulator serves both halves; the requests have the GEMM and the barrier to land.
+#if ISDF_PAIR_INTERLEAVE
+  // per MFMA: its operand read, then a slice of the epilogue; every 4th MFMA also one LDS write and one memory instruction
+  auto stage_pattern = [] {
+#pragma unroll
+    for (int i = 0; i < 64; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                        // MFMA
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                        // DS read
+      __builtin_amdgcn_sched_group_barrier(0x002, ISDF_PAIR_VALU_PER_MFMA, 0);  // VALU
+      if ((i & 3) == 3) {
+        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                      // DS write
+        __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);                      // VMEM
+      }
+    }
+  };
+#define PAIR_STAGE(PRE, EPI, PF, GEMM) do { PRE; __builtin_amdgcn_sched_barrier(0); EPI; PF; GEMM; stage_pattern(); TS(); __builtin_amdgcn_sched_barrier(0); lds_barrier(); TS(); } while (0)
+#else
 #define PAIR_STAGE(PRE, EPI, PF, GEMM) do { PRE; EPI; TS(); PF; GEMM; TS(); lds_barrier(); TS(); } while (0)
+#endif
   auto loadW_hi = [&](PRef r) {   // upper half of the fragment window (see gemm_half STAGE 1)
 #pragma unroll
     for (int k = 8; k < 16; ++k) W[k] = load_wfrag(rsW, r, lane16, k);
@@ -545,6 +587,7 @@ __global__ __launch_bounds__(512, 2) void chain_pair_kernel(const ChainParams p)
     }
     if (p.normals) { li_n[0] = p.normals[ray * 3]; li_n[1] = p.normals[ray * 3 + 1]; li_n[2] = p.normals[ray * 3 + 2]; }
   };
+#pragma unroll
   for (int li = 0; li < nL; ++li) {
     const bool last = li == nL - 1;
     PAIR_STAGE(NOP, E_fwd(0, li), NOP, G_fwd(1, stB, opF, setFwdA, li, last ? r1Ref(nL - 1) : fwdRef(setFwdA, li + 1)));
@@ -553,6 +596,7 @@ __global__ __launch_bounds__(512, 2) void chain_pair_kernel(const ChainParams p)
   }
 
   // ------------------------------------------------------------------ first reverse sweep (fc_map.py:12-22)
+#pragma unroll
   for (int li = nL - 1; li >= 1; --li) {
     PAIR_STAGE(NOP, E_r1(0, li, preA), prefetch(p.sp.A[li], 1, preA), G_sq(1, stB, opF, r1Ref(li), li > 1 ? r1Ref(li - 1) : gRef));
     if (li > 1) PAIR_STAGE(loadW_hi(r1Ref(li - 1)), E_r1(1, li, preA), prefetch(p.sp.A[li - 1], 0, preA), G_sq(0, stA, opF, r1Ref(li - 1), none));
@@ -572,7 +616,7 @@ __global__ __launch_bounds__(512, 2) void chain_pair_kernel(const ChainParams p)
     const int pt = tid & (BM - 1), prt = tid / BM;
 #endif
     const float y0 = xs[pt * 4], y1 = xs[pt * 4 + 1], y2 = xs[pt * 4 + 2];
-    const char* row = X + pt * ROWB;
+    const char* row = Xh(pt >> 6) + (pt & 63) * ROWB;
     auto eg = [&](int feat) { return *(const float*)(row + swz(pt, feat * 4)); };
     float g0 = 0.f, g1 = 0.f, g2 = 0.f;
     if (prt == 0) { g0 = eg(0); g1 = eg(1); g2 = eg(2); }
@@ -720,7 +764,7 @@ __global__ __launch_bounds__(512, 2) void chain_pair_kernel(const ChainParams p)
 #endif
     const float y0 = xs[pt * 4], y1 = xs[pt * 4 + 1], y2 = xs[pt * 4 + 2];
     const float b0 = gbs[pt * 4], b1 = gbs[pt * 4 + 1], b2 = gbs[pt * 4 + 2];
-    char* row = X + pt * ROWB;
+    char* row = Xh(pt >> 6) + (pt & 63) * ROWB;
     auto put = [&](int feat, float v) { *(__bf16*)(row + swz(pt, (HD + feat) * 2)) = (__bf16)v; };
     if (prt == 0) {
       put(0, b0); put(1, b1); put(2, b2);
@@ -751,6 +795,7 @@ __global__ __launch_bounds__(512, 2) void chain_pair_kernel(const ChainParams p)
   TS();
   lds_barrier();
   TS();
+#pragma unroll
   for (int li = 0; li < nL - 1; ++li) {
     PAIR_STAGE(NOP, E_adj(0, li, preA, preB), (prefetch(p.sp.A[li + 1], 1, preA), prefetch(p.sp.P[li], 1, preB)),
                G_fwd(1, stB, opB, setFwdB, li, fwdRef(setFwdB, li + 1)));
@@ -769,6 +814,7 @@ __global__ __launch_bounds__(512, 2) void chain_pair_kernel(const ChainParams p)
   PAIR_STAGE(NOP, E_adj_top(1, preA, preB), (loadW(r2Ref(nL - 2)), (prefetch(p.sp.A[nL - 1], 0, preA), prefetch(p.sp.INJ[nL - 2], 0, preB))), G_sq(0, stA, opB, r2Ref(nL - 2), none));
 
   // ------------------------------------------------------------------ ordinary reverse sweep with injection
+#pragma unroll
   for (int li = nL - 2; li >= 1; --li) {
     PAIR_STAGE(NOP, E_r2(0, li, preA, preB), (prefetch(p.sp.A[li + 1], 1, preA), prefetch(p.sp.INJ[li], 1, preB)), G_sq(1, stBlast, opB, r2Ref(li), none));
     PAIR_STAGE(NOP, E_r2(1, li, preA, preB), (loadW(r2Ref(li - 1)), (prefetch(p.sp.A[li], 0, preA), prefetch(p.sp.INJ[li - 1], 0, preB))), G_sq(0, stA, opB, r2Ref(li - 1), none));
@@ -781,12 +827,14 @@ __global__ __launch_bounds__(512, 2) void chain_pair_kernel(const ChainParams p)
 }
 
 // ---------------------------------------------------------------------------
-template <int HD, bool F16>
+#ifndef ISDF_PAIR_UNROLL_LAYERS
+#define ISDF_PAIR_UNROLL_LAYERS ISDF_PAIR_INTERLEAVE   // instantiate <NL, CAT> = <6, 3> / <8, 4> (the shipped 256-wide nets) with unrolled layer loops
+#endif
+template <int HD, bool F16, int NL, int CAT>
 static int launch_pair(const ChainParams& p, int64_t nTiles, hipStream_t st) {
   typedef PairTile<HD> T;
-  auto k = chain_pair_kernel<HD, F16>;
-  if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES) != hipSuccess) return ISDF_EHIP;
-  hipLaunchKernelGGL(k, dim3((unsigned)((nTiles + 1) / 2)), dim3(T::NW * 64), T::LDS_BYTES, st, p);
+  auto k = chain_pair_kernel<HD, F16, NL, CAT>;
+  hipLaunchKernelGGL(k, dim3((unsigned)((nTiles + 1) / 2)), dim3(T::NW * 64), 0, st, p);   // LDS is static (three objects)
   return isdf_launch_status();
 }
 
@@ -796,7 +844,11 @@ static int launch_pair(const ChainParams& p, int64_t nTiles, hipStream_t st) {
 bool pair_supported(const NetLayout& l) { return l.HD == 256 && l.EP == 256 && l.L <= PairTile<256>::MAXLP && l.L >= 3; }
 int launch_chain_pair(const ChainParams& p, int64_t nTiles, hipStream_t st) {
   if (nTiles <= 0) return ISDF_OK;
-  return p.lay.fwd_f16 ? launch_pair<256, true>(p, nTiles, st) : launch_pair<256, false>(p, nTiles, st);
+#if ISDF_PAIR_UNROLL_LAYERS
+  if (p.lay.L == 6 && p.lay.cat == 3)
+    return p.lay.fwd_f16 ? launch_pair<256, true, 6, 3>(p, nTiles, st) : launch_pair<256, false, 6, 3>(p, nTiles, st);
+#endif
+  return p.lay.fwd_f16 ? launch_pair<256, true, 0, 0>(p, nTiles, st) : launch_pair<256, false, 0, 0>(p, nTiles, st);
 }
 
 }  // namespace isdf
