@@ -197,6 +197,9 @@ typedef struct isdf_step_out {
 /* layout of loss_sums inside reduce_buf (after the n_params gradient floats) */
 enum { ISDF_LS_SDF = 0, ISDF_LS_GRAD = 1, ISDF_LS_EIK = 2, ISDF_LS_TOTAL = 3, ISDF_LS_COUNT = 4 };
 
+/* Environment (read at every call, development switch, no effect on results beyond fp32 re-association):
+ *   ISDF_CHAIN_PAIR=1  train mode of 256-wide nets with a 256-wide padded embedding runs the pair-tile chain kernel
+ *                      (csrc/chain_pair.hip) instead of the one-tile kernel (csrc/chain.hip); DESIGN.md 7a.           */
 int isdf_train_step(const isdf_net_cfg* net, const isdf_loss_cfg* loss, const float* params,
                     const void* shadow, const isdf_step_args* a, const isdf_step_out* o,
                     void* workspace, int64_t workspace_bytes, void* stream);
