@@ -171,6 +171,73 @@ def sampler_scale(args, tr, eng, cam, rank):
         print(json.dumps(res), flush=True)
 
 
+def infer_bench(args, tr, eng, rank):
+    """the inference forward at meshing / slice sizes (`fc_map.chunks`, fc_map.py:25-48, feeding
+    `SDFMap.forward`; trainer.py:1426-1444 evaluates 256^3-class grids): one isdf_sdf_eval call over N points (the kernel
+    has no chunking need), and the same with d sdf / d x (render.render_normals, render.py:39-47).  MFMA-bound: 2 M FLOP
+    per point forward, 4 M with the input gradient (M = 458 496 MAC for the default net)."""
+    N = args.infer_points
+    g = torch.Generator(device="cpu"); g.manual_seed(5)
+    pts = ((torch.rand(N, 3, generator=g) - 0.5) * torch.tensor([6.0, 3.0, 5.0])).to(tr.device)   # the synthetic room's extent
+    M = 458496   # MAC per point and pass of the default net (E*Hd + 2B*Hd^2 + (Hd+E)*Hd + Hd, SURVEY 8d)
+    out = {}
+    for name, wg, flop in (("forward", False, 2.0 * M), ("forward_with_input_gradient", True, 4.0 * M)):
+        n = N if not wg else max(N // 4, 1)
+        x = pts[:n]
+        for _ in range(3):
+            eng.sdf_eval(x, want_grad=wg)
+        torch.cuda.synchronize()
+        K = max(args.steps // 30, 5)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(K):
+            r = eng.sdf_eval(x, want_grad=wg)
+        e1.record(); torch.cuda.synchronize()
+        t = e0.elapsed_time(e1) / K * 1e-3
+        out[name] = {"points": n, "ms": round(t * 1e3, 4), "points_per_s": round(n / t, 1),
+                     "TFLOPs": round(flop * n / t / 1e12, 1), "frac_of_mfma_peak": round(flop * n / t / MFMA_PEAK, 4)}
+    f = out["forward"]
+    res = {"metric": "inference points/s (SDFMap.forward on the fused kernel, one call)", "value": f["points_per_s"], "unit": "points/s",
+           "n_gpus": 1, "steps": max(args.steps // 30, 5), "warmup": 3, "ms_per_step": f["ms"], "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "f16 MFMA operands, f32 accumulate", "data": "synthetic",
+           "config": {"workload": "%d uniform points in the synthetic room, default 6x256 net (meshing / slice grid size)" % N},
+           "modes": out,
+           "roofline": {"bound": "mfma", "kernel": "chain_kernel MODE 0 (PE + MLP forward)", "achieved": f["TFLOPs"], "peak": MFMA_PEAK / 1e12,
+                        "unit": "TFLOP/s", "frac": f["frac_of_mfma_peak"], "traffic": None,
+                        "algorithmic_flop_per_launch": 2.0 * M * N}}
+    if rank == 0:
+        print(json.dumps(res), flush=True)
+
+
+def ingest_bench(args, tr, eng, cam, rank):
+    """per-frame ingest = depth -> camera-frame normals (transform.py:169-196,215-270) as ONE stencil
+    kernel.  HBM-bound by construction: 4 B read + 12 B written per pixel (neighbour depths come from L1/L2)."""
+    from isdf_amd.engine import SampleConfig
+    sc = SampleConfig(n_rays=200, **cam)
+    d = tr.frames.depth_batch[0].contiguous()
+    H, W = d.shape
+    for _ in range(5):
+        eng.estimate_normals(d, sc)
+    torch.cuda.synchronize()
+    K = max(args.steps, 100)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(K):
+        n = eng.estimate_normals(d, sc)
+    e1.record(); torch.cuda.synchronize()
+    t = e0.elapsed_time(e1) / K * 1e-3
+    alg = 16.0 * H * W
+    res = {"metric": "ingest frames/s (depth -> normals stencil, one launch per frame incl. the output allocation)", "value": round(1.0 / t, 1),
+           "unit": "frames/s", "n_gpus": 1, "steps": K, "warmup": 5, "ms_per_step": round(t * 1e3, 4), "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "%dx%d synthetic room depth frame" % (H, W)},
+           "roofline": {"bound": "hbm", "kernel": "normals_kernel", "achieved": round(alg / t / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+                        "frac": round(alg / t / 8e12, 4), "traffic": None, "algorithmic_bytes_per_launch": alg,
+                        "note": "13 MB per 680x1200 frame is ~2 us of HBM time: a single frame is launch-latency-bound"}}
+    if rank == 0:
+        print(json.dumps(res), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -185,6 +252,9 @@ def main():
     ap.add_argument("--sampler-scale", type=int, default=0, metavar="RAYS_PER_FRAME",
                     help="instead of the training bench: the sampler alone at 5 x RAYS_PER_FRAME rays (>= 1e6 total rays is "
                          "where it is a streaming kernel, SURVEY 8d) with its HBM roofline")
+    ap.add_argument("--infer-points", type=int, default=0, metavar="N",
+                    help="time the inference forward (and forward + input gradient) on N points instead of the training step")
+    ap.add_argument("--ingest", action="store_true", help="time the per-frame ingest stencil (depth -> normals) instead")
     ap.add_argument("--wide", action="store_true",
                     help="BASELINE configs[4] instead of the metric's configuration: hidden 512, 3 blocks (8 hidden layers), "
                          "n_freqs 10, 8000 rays = 216k points per GPU-step (not the reported bench line)")
@@ -268,6 +338,10 @@ def main():
 
     if args.sampler_scale:
         return sampler_scale(args, tr, eng, cam, rank)
+    if args.infer_points:
+        return infer_bench(args, tr, eng, rank)
+    if args.ingest:
+        return ingest_bench(args, tr, eng, cam, rank)
     # ---- untimed clock ramp: the driver's `--steps 20 --warmup 5` is 8 ms of GPU work in a fresh process, i.e. measured
     # at idle clocks with first-touch allocations inside the timed region (BENCH_r01: chain 223 us vs 197 us steady)
     ramp_steps, t_r = 0, time.perf_counter()

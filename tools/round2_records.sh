@@ -19,6 +19,9 @@ ISDF_CHAIN_PAIR=1 python $R/bench.py --steps 300 --warmup 50 --no-cpu-baseline 2
 python $R/tools/timeline_pair.py > $O/timeline_pair.txt 2>&1
 python $R/bench.py --rays-per-frame 5400 --steps 30 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_729k.json
 python $R/bench.py --wide --steps 30 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_wide.json
+python $R/bench.py --infer-points 8000000 2>/dev/null | tail -1 > $O/bench_inference_8M.json
+python $R/bench.py --ingest 2>/dev/null | tail -1 > $O/bench_ingest.json
+timeout 120 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_ingest -- python $R/bench.py --ingest > $O/stats_ingest.log 2>&1
 python - <<'PY'
 import csv, glob, collections, os, json
 R = os.environ["GRAFT_REPO_ROOT"]; O = R + "/gpurun_out/r2final"
