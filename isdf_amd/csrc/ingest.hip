@@ -5,8 +5,9 @@
 //   Trainer.is_keyframe (sort + ratio)      isdf/modules/trainer.py:597-609
 // The reference runs the normal estimation as ~10 eager ops with a 70 MB index
 // tensor per 680x1200 frame (0.37 s on 8 CPU threads).  Here it is one stencil
-// pass: 4 B read + 12 B written per pixel (neighbour depths come from L1/L2), i.e.
-// HBM-bound at ~13 MB per 680x1200 frame.
+// pass: 4 B read + 12 B written per pixel, 13 MB per 680x1200 frame (2.5 us of HBM
+// time).  Measured 13.5 us: the pass is VALU-bound -- ~600 instructions per pixel (eight
+// correctly rounded sqrt, five IEEE divisions, the argmin with the reference's NaN rule).
 #include "isdf_common.h"
 
 namespace isdf {
@@ -19,42 +20,60 @@ __device__ __forceinline__ void pix_point(const float* __restrict__ depth, int H
   y = __fmul_rn(z, (float)i - cy) / fy;
 }
 
+// One block = 32 x 16 pixels, two per thread (1 594 blocks for a 680x1200 frame: ONE round on 256 CUs x 8 blocks).  The
+// camera-frame points of the block and its 2-pixel halo (36 x 20) are computed ONCE into LDS (two IEEE divisions per
+// point); the 8 neighbours of a pixel are then three LDS reads each.  (The first version recomputed the nine points per
+// pixel -- 18 divisions and 9 global loads per thread -- in 3 188 blocks, i.e. two rounds: 17.0 us per frame = 0.77 TB/s of
+// the 13 MB the frame moves.)  Same arithmetic per point and per pixel: bit-identical normals.
+constexpr int NRM_BH = 16;
 __global__ __launch_bounds__(256) void normals_kernel(const float* __restrict__ depth, int H, int W, float fx,
                                                       float fy, float cx, float cy, float* __restrict__ normals) {
-  const int j = blockIdx.x * 32 + (threadIdx.x & 31);
-  const int i = blockIdx.y * 8 + (threadIdx.x >> 5);
-  if (i >= H || j >= W) return;
+  __shared__ float px[NRM_BH + 4][37], py[NRM_BH + 4][37], pz[NRM_BH + 4][37];
+  const int tx = threadIdx.x & 31, ty0 = threadIdx.x >> 5;
+  const int j0 = blockIdx.x * 32 - 2, i0 = blockIdx.y * NRM_BH - 2;
+  for (int t = threadIdx.x; t < (NRM_BH + 4) * 36; t += 256) {
+    const int li = t / 36, lj = t - li * 36;
+    float x, y, z;
+    pix_point(depth, H, W, i0 + li, j0 + lj, fx, fy, cx, cy, x, y, z);
+    px[li][lj] = x; py[li][lj] = y; pz[li][lj] = z;
+  }
+  __syncthreads();
+  const int j = blockIdx.x * 32 + tx;
   constexpr int d = 2;
   const int ly[8] = {-d, -d, 0, d, d, d, 0, -d}, lx[8] = {0, d, d, d, 0, -d, -d, -d};
-  float p1x, p1y, p1z;
-  pix_point(depth, H, W, i, j, fx, fy, cx, cy, p1x, p1y, p1z);
-  float qx[8], qy[8], qz[8], len[8];
 #pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    float x, y, z;
-    pix_point(depth, H, W, i + ly[k], j + lx[k], fx, fy, cx, cy, x, y, z);
-    qx[k] = x - p1x; qy[k] = y - p1y; qz[k] = z - p1z;
-    len[k] = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(qx[k], qx[k]), __fmul_rn(qy[k], qy[k])), __fmul_rn(qz[k], qz[k])));
-  }
-  float best = 0.f; int bk = 0;
+  for (int half = 0; half < NRM_BH / 8; ++half) {
+    const int ty = ty0 + 8 * half;
+    const int i = blockIdx.y * NRM_BH + ty;
+    if (i >= H || j >= W) continue;
+    const float p1x = px[ty + 2][tx + 2], p1y = py[ty + 2][tx + 2], p1z = pz[ty + 2][tx + 2];
+    float qx[8], qy[8], qz[8], len[8];
 #pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    float s = __fadd_rn(len[k], len[(k + 2) & 7]);
-    if (s != s) s = INFINITY;                       // diff[isnan] = inf, transform.py:259
-    if (k == 0 || s < best) { best = s; bk = k; }   // argmin keeps the first minimum
-  }
-  float ax = 0, ay = 0, az = 0, bx = 0, by = 0, bz = 0;
+    for (int k = 0; k < 8; ++k) {
+      const float x = px[ty + 2 + ly[k]][tx + 2 + lx[k]], y = py[ty + 2 + ly[k]][tx + 2 + lx[k]], z = pz[ty + 2 + ly[k]][tx + 2 + lx[k]];
+      qx[k] = x - p1x; qy[k] = y - p1y; qz[k] = z - p1z;
+      len[k] = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(qx[k], qx[k]), __fmul_rn(qy[k], qy[k])), __fmul_rn(qz[k], qz[k])));
+    }
+    float best = 0.f; int bk = 0;
 #pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    if (k == bk) { ax = qx[k]; ay = qy[k]; az = qz[k]; bx = qx[(k + 2) & 7]; by = qy[(k + 2) & 7]; bz = qz[(k + 2) & 7]; }
+    for (int k = 0; k < 8; ++k) {
+      float s = __fadd_rn(len[k], len[(k + 2) & 7]);
+      if (s != s) s = INFINITY;                       // diff[isnan] = inf, transform.py:259
+      if (k == 0 || s < best) { best = s; bk = k; }   // argmin keeps the first minimum
+    }
+    float ax = 0, ay = 0, az = 0, bx = 0, by = 0, bz = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      if (k == bk) { ax = qx[k]; ay = qy[k]; az = qz[k]; bx = qx[(k + 2) & 7]; by = qy[(k + 2) & 7]; bz = qz[(k + 2) & 7]; }
+    }
+    // torch.cross then normalise (transform.py:262-267)
+    const float nx = __fadd_rn(__fmul_rn(ay, bz), -__fmul_rn(az, by));
+    const float ny = __fadd_rn(__fmul_rn(az, bx), -__fmul_rn(ax, bz));
+    const float nz = __fadd_rn(__fmul_rn(ax, by), -__fmul_rn(ay, bx));
+    const float nn = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(nx, nx), __fmul_rn(ny, ny)), __fmul_rn(nz, nz)));
+    float* o = normals + ((int64_t)i * W + j) * 3;
+    o[0] = nx / nn; o[1] = ny / nn; o[2] = nz / nn;
   }
-  // torch.cross then normalise (transform.py:262-267)
-  const float nx = __fadd_rn(__fmul_rn(ay, bz), -__fmul_rn(az, by));
-  const float ny = __fadd_rn(__fmul_rn(az, bx), -__fmul_rn(ax, bz));
-  const float nz = __fadd_rn(__fmul_rn(ax, by), -__fmul_rn(ay, bx));
-  const float nn = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(nx, nx), __fmul_rn(ny, ny)), __fmul_rn(nz, nz)));
-  float* o = normals + ((int64_t)i * W + j) * 3;
-  o[0] = nx / nn; o[1] = ny / nn; o[2] = nz / nn;
 }
 
 // one thread per ray: stable insertion sort of (z, sdf) by z, first negative sdf, reference quirks kept:
@@ -94,7 +113,7 @@ __global__ void render_depth_kernel(const int32_t* __restrict__ n_valid, int64_t
 
 int launch_normals(const float* depth, int H, int W, float fx, float fy, float cx, float cy, float* normals,
                    hipStream_t st) {
-  hipLaunchKernelGGL(normals_kernel, dim3((W + 31) / 32, (H + 7) / 8), dim3(256), 0, st, depth, H, W, fx, fy, cx, cy,
+  hipLaunchKernelGGL(normals_kernel, dim3((W + 31) / 32, (H + NRM_BH - 1) / NRM_BH), dim3(256), 0, st, depth, H, W, fx, fy, cx, cy,
                      normals);
   return isdf_launch_status();
 }
