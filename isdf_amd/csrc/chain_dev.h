@@ -14,9 +14,6 @@ namespace isdf {
 #ifndef ISDF_EXP_CHEAP_EPI
 #define ISDF_EXP_CHEAP_EPI 0
 #endif
-#ifndef ISDF_BSTORE_REUNIFORM
-#define ISDF_BSTORE_REUNIFORM 0
-#endif
 #ifndef ISDF_PE_MAP
 #define ISDF_PE_MAP 1      // thread mapping of the PE-shaped stages (0: one point per lane, the round-1/2 mapping)
 #endif
@@ -73,11 +70,6 @@ template <bool NT = true>
 __device__ __forceinline__ void bstore16_nt(uint4 x, i32x4 srd, int voff, int soff, int c) {
   u32x4 v; v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w;
   soff += (c >> 2) * 4096;
-#if ISDF_BSTORE_REUNIFORM   // the descriptor may have been moved to VGPRs under SGPR pressure: bring it back for the "s" operands
-  srd[0] = __builtin_amdgcn_readfirstlane(srd[0]); srd[1] = __builtin_amdgcn_readfirstlane(srd[1]);
-  srd[2] = __builtin_amdgcn_readfirstlane(srd[2]); srd[3] = __builtin_amdgcn_readfirstlane(srd[3]);
-  soff = __builtin_amdgcn_readfirstlane(soff);
-#endif
   if (NT) {
     switch (c & 3) {
       case 0: ISDF_BSTORE16_NT(0); break;

@@ -23,17 +23,10 @@
 //   * the spilled tensors an epilogue re-reads are requested a GEMM and a barrier ahead (32 VGPRs);
 //   * a stage's epilogue and GEMM work on different halves of the tile: one barrier per GEMM instead of two, and one
 //     accumulator for both halves (the epilogue drains it before the GEMM refills it).
-#ifndef ISDF_PAIR_SWAP
-#define ISDF_PAIR_SWAP 0
-#endif
-#define ISDF_BSTORE_REUNIFORM ISDF_PAIR_SWAP
 #include "chain_dev.h"
 
 namespace isdf {
 
-#ifndef ISDF_PAIR_SWAP
-#define ISDF_PAIR_SWAP 0       // 1: waves 4-7 run a stage's epilogue BEFORE its GEMM (MFMA of one wave beside VALU of its SIMD partner)
-#endif
 #ifndef ISDF_DEBUG_HOOKS
 #define ISDF_DEBUG_HOOKS 0
 #endif
