@@ -65,6 +65,9 @@ namespace isdf {
 #else
 #define CH_STORE(NT, X, SOFF, C) bstore16_nt<(NT)>((X), srdS, lane16, (SOFF), (C))
 #endif
+#ifndef ISDF_REV1_EARLY
+#define ISDF_REV1_EARLY 0
+#endif
 #ifndef GEMM_LDS_DEPTH
 #define GEMM_LDS_DEPTH 1   // k-steps of activation-operand LDS reads in flight ahead of the MFMAs
 #endif
@@ -122,9 +125,12 @@ __device__ __forceinline__ void preload_w(WChunk<FBN, CKF>& wq, rsrc_t rw, WRef 
       wq.v[s][fb] = bload16<0>(rw, lane16 + (s & 3) * 1024, r.soff + fb * r.rb + (s >> 2) * 4096);
 }
 
-template <bool F16, int KSTEPS, int FBN, int PBN, int ROWB, int CKF, typename Hook, typename Hook2>
+struct NoHook { __device__ void operator()() const {} };
+// midHook: requests issued BEHIND the last weight request of the GEMM and in front of its last chunk of MFMAs (they then
+// have that chunk and the barrier to land); only for requests small enough to stay inside the VGPR budget.
+template <bool F16, int KSTEPS, int FBN, int PBN, int ROWB, int CKF, typename Hook, typename Hook2, typename Hook3 = NoHook>
 __device__ __forceinline__ void gemm(f32x16 (&acc)[FBN][PBN], WChunk<FBN, CKF>& wq, rsrc_t rw, WRef wr, const char* xl,
-                                     int colByteBase, int lane, Hook&& earlyHook, Hook2&& lateHook) {
+                                     int colByteBase, int lane, Hook&& earlyHook, Hook2&& lateHook, Hook3&& midHook = NoHook()) {
   constexpr int CK = CKF / FBN;                  // k-steps per chunk: CK*FBN uint4 = 32 VGPRs
   static_assert(KSTEPS % CK == 0, "K must be a multiple of the chunk");
   static_assert((ROWB & 255) == 0, "row base must leave the swizzle bits (4-7) clear");
@@ -206,6 +212,8 @@ __device__ __forceinline__ void gemm(f32x16 (&acc)[FBN][PBN], WChunk<FBN, CKF>& 
   __builtin_amdgcn_sched_barrier(0);
   chunk(NCH - 1, std::false_type{});
 #else
+  midHook();
+  __builtin_amdgcn_sched_barrier(0);
   chunk(NCH - 1, std::false_type{});
   earlyHook();
 #endif
@@ -585,8 +593,13 @@ __global__ __launch_bounds__(chain_nw(HD) * 64, (HD <= 256 && EP == HD && chain_
     Pre preA;
     zero_acc(acc);
     refresh();
+#if ISDF_REV1_EARLY   // the first reverse sweep re-reads ONE tensor: requested in front of the last chunk of MFMAs
+    gemm<F16, HD / 16, FB, PB, ROWB, T::CKF>(acc, wq, rsW, wptr(setBwdA, L.bwdMat[li], HD), X, 0, lane,
+                                     [] {}, [] {}, [&] { prefetch(p.sp.A[li], preA); });
+#else
     gemm<F16, HD / 16, FB, PB, ROWB, T::CKF>(acc, wq, rsW, wptr(setBwdA, L.bwdMat[li], HD), X, 0, lane,
                                      [&] { prefetch(p.sp.A[li], preA); }, [] {});
+#endif
     TS();
     lds_barrier();
     TS();
