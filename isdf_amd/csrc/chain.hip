@@ -65,6 +65,20 @@ namespace isdf {
 #else
 #define CH_STORE(NT, X, SOFF, C) bstore16_nt<(NT)>((X), srdS, lane16, (SOFF), (C))
 #endif
+#ifndef ISDF_S1_U8
+#define ISDF_S1_U8 0           // 1: the backward sweeps re-read sigma'(z) as unorm8 (written by the forward epilogue) instead of
+#endif                         //    re-deriving it from the bf16 activation: half the bytes and registers, no exp.  Measured:
+                               //    chain -2.5 %, single-step dW accuracy unchanged, but saturated units get EXACT zeros and the
+                               //    three-step AdamW trajectories leave the oracle's twice as fast (1.1e-2 vs 5.7e-3 on exp_avg): off
+// sigma' of layer l for the backward epilogues: the unorm8 tile the forward epilogue wrote (S1[l]), or derived from the
+// bf16 activation tile A[l+1] (ISDF_S1_U8 = 0)
+#if ISDF_S1_U8
+#define S1_PREFETCH(LAYER, AOFF, PRE) prefetch8(p.sp.S1[LAYER], PRE)
+#define S1_LOAD(PRE, FB_, PB_, QP_, OUT) load_s1(PRE, FB_, PB_, QP_, OUT)
+#else
+#define S1_PREFETCH(LAYER, AOFF, PRE) prefetch(AOFF, PRE)
+#define S1_LOAD(PRE, FB_, PB_, QP_, OUT) do { load_tile8(PRE, FB_, PB_, QP_, OUT); for (int e_ = 0; e_ < 8; ++e_) OUT[e_] = s1_from_a(OUT[e_]); } while (0)
+#endif
 #ifndef ISDF_REV1_EARLY
 #define ISDF_REV1_EARLY 0
 #endif
@@ -468,6 +482,41 @@ __global__ __launch_bounds__(chain_nw(HD) * 64, (HD <= 256 && EP == HD && chain_
     const uint2 a = pack4<false>(v[0], v[1], v[2], v[3]), b = pack4<false>(v[4], v[5], v[6], v[7]);
     CH_STORE(true, make_uint4(a.x, a.y, b.x, b.y), sbase(tensorOff), cidx(fb, pb, qp));
   };
+  // sigma' tiles ("frag8": the same piece order as frag16 with 8 BYTES per lane: piece c of a wave at c*512 + lane*8).
+  // sigma' in (0, 1] as round(255 s): its error (<= 1/510) is the size of the error of 1 - exp(-beta a) from a bf16 `a`.
+  struct Pre8 { uint2 v[FB][2][PB]; };
+  auto sbase8 = [&](int64_t tensorOff) { return (int)(tensorOff * 2) + w * (FB * PB * 2) * 512; };
+  auto prefetch8 = [&](int64_t tensorOff, Pre8& pr) {
+    const int sb = sbase8(tensorOff);
+#pragma unroll
+    for (int fb = 0; fb < FB; ++fb)
+#pragma unroll
+      for (int qp = 0; qp < 2; ++qp)
+#pragma unroll
+        for (int pb = 0; pb < PB; ++pb) {
+          const auto v2 = __builtin_amdgcn_raw_buffer_load_b64(rsS, lane * 8 + cidx(fb, pb, qp) * 512, sb, kAuxNT);
+          pr.v[fb][qp][pb] = make_uint2(v2[0], v2[1]);
+        }
+  };
+  auto load_s1 = [&](const Pre8& pr, int fb, int pb, int qp, float (&o)[8]) {
+    const uint2 u = pr.v[fb][qp][pb];
+    constexpr float k = 1.f / 255.f;
+    // (float)((x >> 8k) & 255) is matched to v_cvt_f32_ubyte<k>
+    o[0] = (float)(u.x & 255u) * k; o[1] = (float)((u.x >> 8) & 255u) * k;
+    o[2] = (float)((u.x >> 16) & 255u) * k; o[3] = (float)(u.x >> 24) * k;
+    o[4] = (float)(u.y & 255u) * k; o[5] = (float)((u.y >> 8) & 255u) * k;
+    o[6] = (float)((u.y >> 16) & 255u) * k; o[7] = (float)(u.y >> 24) * k;
+  };
+  auto store_s1 = [&](int64_t tensorOff, int fb, int pb, int qp, const float (&s)[8]) {
+    uint32_t q[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) q[e] = (uint32_t)(s[e] * 255.f + 0.5f);   // s in [0, 1]: v_cvt_u32_f32 truncates, +0.5 rounds
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+    u32x2 v;
+    v[0] = q[0] | (q[1] << 8) | (q[2] << 16) | (q[3] << 24);
+    v[1] = q[4] | (q[5] << 8) | (q[6] << 16) | (q[7] << 24);
+    __builtin_amdgcn_raw_buffer_store_b64(v, rsS, lane * 8 + cidx(fb, pb, qp) * 512, sbase8(tensorOff), kAuxNT);
+  };
   auto store_tile8_p = [&](int64_t tensorOff, int fb, int pb, int qp, const float (&v)[8]) {
     const uint2 a = pack4<false>(v[0], v[1], v[2], v[3]), b = pack4<false>(v[4], v[5], v[6], v[7]);
     CH_STORE(ISDF_NT_P != 0, make_uint4(a.x, a.y, b.x, b.y), sbase(tensorOff), cidx(fb, pb, qp));
@@ -528,9 +577,22 @@ __global__ __launch_bounds__(chain_nw(HD) * 64, (HD <= 256 && EP == HD && chain_
         if (pb == 0) ld_params8(L.offB[li] + ubase(fb, qp), bv);
 #endif
         float a[8];
+#if ISDF_S1_U8
+        if (MODE >= 1) {
+          float s1[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) a[e] = softplus_s1(acc[fb][pb][8 * qp + e] + (ISDF_BIAS_INIT ? 0.f : bv[e]), s1[e]);
+          store_s1(p.sp.S1[li], fb, pb, qp, s1);
+          if (MODE == 2) store_tile8(p.sp.A[li + 1], fb, pb, qp, a);   // dW operand; the input-gradient mode needs sigma' only
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) a[e] = softplus_f(acc[fb][pb][8 * qp + e] + (ISDF_BIAS_INIT ? 0.f : bv[e]));
+        }
+#else
 #pragma unroll
         for (int e = 0; e < 8; ++e) a[e] = softplus_f(acc[fb][pb][8 * qp + e] + (ISDF_BIAS_INIT ? 0.f : bv[e]));
         if (MODE >= 1) store_tile8(p.sp.A[li + 1], fb, pb, qp, a);
+#endif
         put_x(F16, fb, pb, qp, a, 0);
       }, [](int, int) {});
     } else {
@@ -590,15 +652,19 @@ __global__ __launch_bounds__(chain_nw(HD) * 64, (HD <= 256 && EP == HD && chain_
   // ------------------------------------------------------------------ first reverse sweep
   PRIO(1);
   for (int li = L.L - 1; li >= 1; --li) {
+#if ISDF_S1_U8
+    Pre8 preA;   // sigma'(z_{li-1})
+#else
     Pre preA;
+#endif
     zero_acc(acc);
     refresh();
 #if ISDF_REV1_EARLY   // the first reverse sweep re-reads ONE tensor: requested in front of the last chunk of MFMAs
     gemm<F16, HD / 16, FB, PB, ROWB, T::CKF>(acc, wq, rsW, wptr(setBwdA, L.bwdMat[li], HD), X, 0, lane,
-                                     [] {}, [] {}, [&] { prefetch(p.sp.A[li], preA); });
+                                     [] {}, [] {}, [&] { S1_PREFETCH(li - 1, p.sp.A[li], preA); });
 #else
     gemm<F16, HD / 16, FB, PB, ROWB, T::CKF>(acc, wq, rsW, wptr(setBwdA, L.bwdMat[li], HD), X, 0, lane,
-                                     [&] { prefetch(p.sp.A[li], preA); }, [] {});
+                                     [&] { S1_PREFETCH(li - 1, p.sp.A[li], preA); }, [] {});
 #endif
     TS();
     lds_barrier();
@@ -607,9 +673,9 @@ __global__ __launch_bounds__(chain_nw(HD) * 64, (HD <= 256 && EP == HD && chain_
     const bool toR2 = (li - 1 == L.cat);
     for_blocks([&](int fb, int pb, int qp, int row) {
       float a[8], pv[8];
-      load_tile8(preA, fb, pb, qp, a);
+      S1_LOAD(preA, fb, pb, qp, a);   // a[] = sigma'
 #pragma unroll
-      for (int e = 0; e < 8; ++e) pv[e] = acc[fb][pb][8 * qp + e] * s1_from_a(a[e]);
+      for (int e = 0; e < 8; ++e) pv[e] = acc[fb][pb][8 * qp + e] * a[e];
       put_x(F16, fb, pb, qp, pv, 0);
       if (toR2) put_x(F16, fb, pb, qp, pv, HD);
       if (MODE == 2) store_tile8_p(p.sp.P[li - 1], fb, pb, qp, pv);
@@ -903,20 +969,25 @@ __global__ __launch_bounds__(chain_nw(HD) * 64, (HD <= 256 && EP == HD && chain_
       gemm<false, HD / 16, FB, PB, ROWB, T::CKF>(acc, wq, rsW, fwdW(setFwdB, li), X, 0, lane, pf0, pf);
   };
   for (int li = 0; li < L.L - 1; ++li) {
-    Pre preA, preP;
-    adj_gemm(li, [&] { prefetch(p.sp.A[li + 1], preA); }, [&] { prefetch(p.sp.P[li], preP); });
+#if ISDF_S1_U8
+    Pre8 preA;   // sigma'(z_li)
+#else
+    Pre preA;
+#endif
+    Pre preP;
+    adj_gemm(li, [&] { S1_PREFETCH(li, p.sp.A[li + 1], preA); }, [&] { prefetch(p.sp.P[li], preP); });
     TS();
     lds_barrier();
     TS();
     refresh();
     for_blocks([&](int fb, int pb, int qp, int row) {
       float a[8], pv[8], qb[8], inj[8];
-      load_tile8(preA, fb, pb, qp, a);
+      S1_LOAD(preA, fb, pb, qp, a);   // a[] = sigma'
       load_tile8(preP, fb, pb, qp, pv);
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const float u = acc[fb][pb][8 * qp + e];
-        const float s1 = s1_from_a(a[e]);
+        const float s1 = a[e];
         qb[e] = u * s1;
         inj[e] = kBeta * u * pv[e] * (1.f - s1);   // u * q * sigma''(z),  q*sigma' = p
       }
@@ -978,8 +1049,13 @@ __global__ __launch_bounds__(chain_nw(HD) * 64, (HD <= 256 && EP == HD && chain_
   // ------------------------------------------------------------------ ordinary reverse sweep with injection
   PRIO(3);
   for (int li = L.L - 2; li >= 0; --li) {
-    Pre preA, preI;
-    auto pf0 = [&] { prefetch(p.sp.A[li + 1], preA); };
+#if ISDF_S1_U8
+    Pre8 preA;   // sigma'(z_li)
+#else
+    Pre preA;
+#endif
+    Pre preI;
+    auto pf0 = [&] { S1_PREFETCH(li, p.sp.A[li + 1], preA); };
     auto pf = [&] { prefetch(p.sp.INJ[li], preI); };
     zero_acc(acc);
     refresh();
@@ -993,11 +1069,11 @@ __global__ __launch_bounds__(chain_nw(HD) * 64, (HD <= 256 && EP == HD && chain_
     for (int e = 0; e < 8; ++e) bsum[e] = 0.f;
     for_blocks2([&](int fb, int pb, int qp, int row) {
       float a[8], inj[8], zb[8];
-      load_tile8(preA, fb, pb, qp, a);
+      S1_LOAD(preA, fb, pb, qp, a);   // a[] = sigma'
       load_tile8(preI, fb, pb, qp, inj);
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        zb[e] = acc[fb][pb][8 * qp + e] * s1_from_a(a[e]) + inj[e];
+        zb[e] = acc[fb][pb][8 * qp + e] * a[e] + inj[e];
         bsum[e] += zb[e];
       }
       store_tile8_dw(p.sp.ZB[li], fb, pb, qp, zb);

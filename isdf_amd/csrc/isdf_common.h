@@ -77,6 +77,7 @@ struct SpillLayout {
   int64_t GB[MAXL];      // GB[0] = Ebar (EP/HD tensors), GB[li] = adjoint entering layer li (li >= 1)
   int64_t INJ[MAXL];     // injected second-order term of layer li
   int64_t ZB[MAXL];      // d loss / d z_li
+  int64_t S1[MAXL];      // sigma'(z_li) as unorm8, [64 pts x HD] BYTES per tile (half a tensor), "frag8" order (chain.hip)
   int64_t totalElems;
 };
 
@@ -182,6 +183,7 @@ inline void make_workspace(const NetLayout& l, int64_t maxPts, int64_t maxRays, 
   int64_t o = 0;
   const int embT = l.EP / l.HD;               // HD-wide tensors per embedding-shaped operand
   for (int i = 0; i <= l.L; ++i) { s.A[i] = o; o += s.tensorElems * (i == 0 ? embT : 1); }
+  for (int i = 0; i < l.L; ++i) { s.S1[i] = o; o += s.tensorElems / 2; }
   if (train) {
     for (int i = 0; i < l.L; ++i) { s.P[i] = o; o += s.tensorElems; }
     for (int i = 0; i < l.L; ++i) { s.GB[i] = o; o += s.tensorElems * (i == 0 ? embT : 1); }

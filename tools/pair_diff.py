@@ -17,7 +17,7 @@ idx = torch.arange(5, dtype=torch.int32, device="cuda")
 s = eng.sample(d, T, n, idx, idx, sc, seed=1, offset=0)
 noise = 0.01 * torch.randn(s["max_rays"], sc.S, device="cuda")
 R = int(s["n_valid"].item()); P = R * sc.S
-L = 6; names = ["A%d" % i for i in range(L + 1)] + ["P%d" % i for i in range(L)] + ["GB%d" % i for i in range(L)] + \
+L = 6; names = ["A%d" % i for i in range(L + 1)] + ["S1_%d+%d" % (2 * i, 2 * i + 1) for i in range(L // 2)] + ["P%d" % i for i in range(L)] + ["GB%d" % i for i in range(L)] + \
     ["INJ%d" % i for i in range(L)] + ["ZB%d" % i for i in range(L)]
 nT = (P + 63) // 64
 def run(single):
