@@ -1,5 +1,6 @@
 #!/bin/bash
 # Instruction-mix and wave-state counters of the chain / dW kernels (run on the GPU box through gpurun).
+# ISDF_CHAIN_PAIR=1 tools/pmc_breakdown.sh collects them for the pair-tile kernel instead of the one-tile kernel.
 # Separate rocprofv3 --pmc passes (with --kernel-trace only); summaries go to gpurun_out/pmc2/.
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
@@ -16,7 +17,7 @@ for f in sorted(glob.glob(R + "/gpurun_out/pmc2/*/**/*_counter_collection.csv", 
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        k = "chain_kernel" if "chain_kernel" in k else ("dw_kernel" if "dw_kernel" in k else None)
+        k = "chain_pair_kernel" if "chain_pair_kernel" in k else ("chain_kernel" if "chain_kernel" in k else ("dw_kernel" if "dw_kernel" in k else None))
         if k: acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k in acc:
         for c, v in acc[k].items(): rows.append((k, c, sum(v) / len(v)))
