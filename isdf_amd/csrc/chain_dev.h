@@ -62,8 +62,18 @@ __device__ __forceinline__ i32x4 make_srd(const void* base, uint32_t bytes) {
   d[2] = (int)bytes; d[3] = 0x00020000;
   return d;
 }
+#ifndef ISDF_SPILL_STORE_POLICY_ID
+#define ISDF_SPILL_STORE_POLICY_ID 0   // cache policy of the streaming spill stores: 0 nt, 1 sc1 (write-through, line dropped from L2), 2 sc1 nt
+#endif
+#if ISDF_SPILL_STORE_POLICY_ID == 1
+#define ISDF_SPILL_STORE_POLICY "sc1"
+#elif ISDF_SPILL_STORE_POLICY_ID == 2
+#define ISDF_SPILL_STORE_POLICY "sc1 nt"
+#else
+#define ISDF_SPILL_STORE_POLICY "nt"
+#endif
 #define ISDF_BSTORE16_NT(IMM) \
-  asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen offset:" #IMM " nt\n\ts_nop 1" ::"v"(v), "v"(voff), "s"(srd), "s"(soff) : "memory")
+  asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen offset:" #IMM " " ISDF_SPILL_STORE_POLICY "\n\ts_nop 1" ::"v"(v), "v"(voff), "s"(srd), "s"(soff) : "memory")
 #define ISDF_BSTORE16_DF(IMM) \
   asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen offset:" #IMM "\n\ts_nop 1" ::"v"(v), "v"(voff), "s"(srd), "s"(soff) : "memory")
 template <bool NT = true>
