@@ -245,7 +245,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--rays-per-frame", type=int, default=200)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--fwd-operand", default="fp16", choices=["fp16", "bf16"])
+    ap.add_argument("--fwd-operand", default="fp16x2", choices=["fp16x2", "fp16", "bf16"])
     ap.add_argument("--ramp-seconds", type=float, default=0.4,
                     help="untimed clock-ramp phase before the W warm-up steps (a fresh box runs the first ~100 ms at idle "
                          "clocks: 25 cold steps measured 13 %% slower than steady state in round 1); reported in the JSON line")

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define ISDF_ABI_VERSION 3
+#define ISDF_ABI_VERSION 4
 
 enum {
   ISDF_OK = 0,
@@ -53,8 +53,15 @@ typedef struct isdf_net_cfg {
   float scale_input;     /* embedding.scale_input                              */
   float scale_output;    /* model.scale_output (fc_map.py:109)                 */
   float bounds_T[12];    /* rows of inv_bounds_transform[:3,:4] (row-major)    */
-  int32_t fwd_operand;   /* 0: bf16, 1: fp16 MFMA operands in the forward and
-                            first-backward GEMMs (second-order passes: bf16)   */
+  int32_t fwd_operand;   /* MFMA operands of the forward and first-backward
+                            GEMMs (second-order passes are always bf16):
+                            0 bf16; 1 fp16; 2 "fp16x2" = fp16 with a compensated
+                            forward -- layers >= cat_layer also multiply the
+                            fp16 residual of their weights, the layers past it
+                            the fp16 residual of their input too -- which is
+                            what meets the reference's fp32 sdf to 1e-3
+                            (fc_map.py:94-111).  isdf_shadow_bytes
+                            grows by one forward set for mode 2.               */
   int32_t reserved;
 } isdf_net_cfg;
 
@@ -197,9 +204,6 @@ typedef struct isdf_step_out {
 /* layout of loss_sums inside reduce_buf (after the n_params gradient floats) */
 enum { ISDF_LS_SDF = 0, ISDF_LS_GRAD = 1, ISDF_LS_EIK = 2, ISDF_LS_TOTAL = 3, ISDF_LS_COUNT = 4 };
 
-/* Environment (read at every call, development switch, no effect on results beyond fp32 re-association):
- *   ISDF_CHAIN_PAIR=1  train mode of 256-wide nets with a 256-wide padded embedding runs the pair-tile chain kernel
- *                      (csrc/chain_pair.hip) instead of the one-tile kernel (csrc/chain.hip); DESIGN.md 7a.           */
 int isdf_train_step(const isdf_net_cfg* net, const isdf_loss_cfg* loss, const float* params,
                     const void* shadow, const isdf_step_args* a, const isdf_step_out* o,
                     void* workspace, int64_t workspace_bytes, void* stream);

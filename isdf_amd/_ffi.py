@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # ISDF_HIP_LIB: development override (A/B variants and the instrumented build of tools/build_variants.py)
 LIB_PATH = os.environ.get("ISDF_HIP_LIB") or os.path.join(HERE, "libisdf_hip.so")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 # every symbol include/isdf_hip.h declares (checked by tests/test_abi.py)
 SYMBOLS = [

@@ -11,15 +11,13 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libisdf_hip.so")
-SOURCES = ["chain.hip", "chain_pair.hip", "dw.hip", "sampler.hip", "optim.hip", "ingest.hip", "capi.hip"]
-HEADERS = ["isdf_common.h", "chain_params.h", "chain_dev.h", os.path.join("..", "..", "include", "isdf_hip.h")]
+SOURCES = ["chain.hip", "dw.hip", "sampler.hip", "optim.hip", "ingest.hip", "capi.hip"]
+HEADERS = ["isdf_common.h", "chain_params.h", "chain_dev.h", "chain_debug.h", os.path.join("..", "..", "include", "isdf_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-command-line-argument",
          "-fno-gpu-rdc"] + os.environ.get("ISDF_EXTRA_HIPCC_FLAGS", "").split()
 
 
-# per-source extra flags: the pair-tile kernel sits at the 256-VGPR budget; the GCN register-pressure trackers halve
-# its spill count (25 -> 0..6 spilled VGPRs)
-PER_FILE = {"chain_pair.hip": ["-mllvm", "-amdgpu-use-amdgpu-trackers=1", "-Wno-pass-failed"]}
+PER_FILE = {}   # per-source extra flags (none in the shipped build)
 
 
 def _hipcc():

@@ -4,7 +4,6 @@
 #include <cstdio>
 #include "isdf_common.h"
 #include "chain_params.h"
-#include <cstdlib>
 
 using namespace isdf;
 
@@ -171,9 +170,7 @@ static int train_step_impl(const isdf_net_cfg* net, const isdf_loss_cfg* loss, c
   p.sdf = o->sdf; p.sdf_grad = o->sdf_grad; p.tot_loss_mat = o->tot_loss_mat;
   p.tot_ws = totLoss; p.wg_loss = wgLoss; p.vec_part = vecPart; p.vecStride = w.vecStride;
   p.spill = (uint16_t*)(ws + w.offSpill); p.sp = w.sp;
-  if (const char* e = getenv("ISDF_DEBUG_ALIAS_SPILL")) p.dbg_alias = atoi(e);   // timing experiments only
-  if (const char* e = getenv("ISDF_DEBUG_STAGGER")) p.dbg_stagger = atoi(e);
-  if (getenv("ISDF_DEBUG_TIMELINE")) p.dbg_times = (unsigned long long*)(ws + w.totalBytes - 4096);
+  chain_debug_from_env(p.dbg, ws + w.totalBytes - 4096);   // no-op in the shipped build (chain_debug.h)
   hipEvent_t* ev = (hipEvent_t*)o->prof_events;
   if (ev && hipEventRecord(ev[0], st) != hipSuccess) return ISDF_EHIP;
   rc = launch_chain(p, 2, w.nTiles, st);

@@ -21,76 +21,21 @@
 // In the C layout a lane owns one point and 4 consecutive features per
 // register quad, so epilogues write 8-byte packed pieces back to the LDS tile.
 #include "chain_dev.h"
-#include <stdlib.h>
 
 namespace isdf {
 
-#ifndef GEMM_HOOK_BEFORE_LAST_CHUNK
-#define GEMM_HOOK_BEFORE_LAST_CHUNK 0   // 1: request one spill tensor before the last chunk (measured +15 us, 16 spilled VGPRs)
-#endif
-#ifndef GEMM_HOOKS_FIRST
-#define GEMM_HOOKS_FIRST 0
-#endif
-#ifndef GEMM_ROLLING_REFILL
-#define GEMM_ROLLING_REFILL 0
-#endif
-#ifndef ISDF_DEBUG_HOOKS
-#define ISDF_DEBUG_HOOKS 0     // 1: development build (tools/build_variants.py dbg=-DISDF_DEBUG_HOOKS=1): phase time stamps,
-#endif                         //    spill aliasing and start staggering switches; the shipped kernel carries none of it
-// what-if experiments (timing only, results wrong; never set in a shipped build)
-#ifndef ISDF_EXP_HALF_LDS
-#define ISDF_EXP_HALF_LDS 0
-#endif
-#ifndef ISDF_EXP_NO_WLOAD
-#define ISDF_EXP_NO_WLOAD 0
-#endif
-#ifndef ISDF_PRIO_MODE
-#define ISDF_PRIO_MODE 1
-#endif
-#ifndef ISDF_NT_DW_TENSORS
-#define ISDF_NT_DW_TENSORS 0   // 0: the tensors only the dW kernel re-reads (GB, ZB) are stored with the default cache policy
-#endif
-#ifndef ISDF_BIAS_INIT
-#define ISDF_BIAS_INIT 0       // 1: forward accumulators start from the bias (measured: no gain, 180.0 vs 180.3 us)
-#endif
-#ifndef ISDF_NT_P
-#define ISDF_NT_P 1            // 0: P (d sdf / d z) stored with the default cache policy
-#endif
-#ifndef ISDF_VISIBLE_STORES
-#define ISDF_VISIBLE_STORES 0  // 1: spill stores through the builtin with soffset = 0 (compiler-counted; see chain_pair.hip) instead of
-#endif                         //    the hand-issued SGPR-soffset form
-#if ISDF_VISIBLE_STORES
-#define CH_STORE(NT, X, SOFF, C) do { const uint4 x_ = (X); u32x4 v_; v_[0] = x_.x; v_[1] = x_.y; v_[2] = x_.z; v_[3] = x_.w; \
-    __builtin_amdgcn_raw_buffer_store_b128(v_, rsS, lane16 + (SOFF) + (C) * 1024, 0, (NT) ? kAuxNT : 0); } while (0)
-#else
-#define CH_STORE(NT, X, SOFF, C) bstore16_nt<(NT)>((X), srdS, lane16, (SOFF), (C))
-#endif
-#ifndef ISDF_S1_U8
-#define ISDF_S1_U8 0           // 1: the backward sweeps re-read sigma'(z) as unorm8 (written by the forward epilogue) instead of
-#endif                         //    re-deriving it from the bf16 activation: half the bytes and registers, no exp.  Measured:
-                               //    chain -2.5 %, single-step dW accuracy unchanged, but saturated units get EXACT zeros and the
-                               //    three-step AdamW trajectories leave the oracle's twice as fast (1.1e-2 vs 5.7e-3 on exp_avg): off
-// sigma' of layer l for the backward epilogues: the unorm8 tile the forward epilogue wrote (S1[l]), or derived from the
-// bf16 activation tile A[l+1] (ISDF_S1_U8 = 0)
-#if ISDF_S1_U8
-#define S1_PREFETCH(LAYER, AOFF, PRE) prefetch8(p.sp.S1[LAYER], PRE)
-#define S1_LOAD(PRE, FB_, PB_, QP_, OUT) load_s1(PRE, FB_, PB_, QP_, OUT)
-#else
-#define S1_PREFETCH(LAYER, AOFF, PRE) prefetch(AOFF, PRE)
-#define S1_LOAD(PRE, FB_, PB_, QP_, OUT) do { load_tile8(PRE, FB_, PB_, QP_, OUT); for (int e_ = 0; e_ < 8; ++e_) OUT[e_] = s1_from_a(OUT[e_]); } while (0)
-#endif
-#ifndef ISDF_REV1_EARLY
-#define ISDF_REV1_EARLY 0
-#endif
-#ifndef GEMM_LDS_DEPTH
-#define GEMM_LDS_DEPTH 1   // k-steps of activation-operand LDS reads in flight ahead of the MFMAs
-#endif
+// MFMA operand type of the forward / first-reverse GEMMs: 0 bf16, 1 fp16, 2 fp16 with the compensated forward
+// ("fp16x2", NetLayout::fwd_x2): layers >= cat also multiply the fp16 RESIDUAL of their weights, and the layers past
+// the cat layer the fp16 residual of their input activation (kept in region 2 of the tile, idle there), i.e.
+// W x ~= Wh xh + Wl xh + Wh xl -- what brings sdf within 1e-3 of the fp32 reference at BASELINE size.
+constexpr bool oper_f16(int oper) { return oper >= 1; }
+constexpr bool oper_x2(int oper) { return oper == 2; }
 
 template <int HD, int EP>
 struct Tile {
   static constexpr int BM = TILE_PTS;
-  static constexpr int NW = chain_nw(HD);
-  static constexpr int CKF = chain_chunk_frags(NW);   // weight fragments per chunk
+  static constexpr int NW = CHAIN_NW;
+  static constexpr int CKF = CHAIN_CHUNK_FRAGS;       // weight fragments per chunk
   static constexpr int FB = HD / (NW * 32);   // 32-row feature blocks per wave
   static constexpr int PB = BM / 32;          // 32-point blocks
   static constexpr int R2 = (EP > HD ? EP : HD);
@@ -113,38 +58,28 @@ struct Tile {
 // C[FB*32 feats][PB*32 pts] += Wpacked[feat][k] * X[pt][k]  over KSTEPS*16 k.
 // Measured: a workgroup's time is a serial latency chain, and a staged
 // weight loop pays one dependent L2/MALL round trip per stage (8 per K=256 unit).  So the
-// wave requests its WHOLE weight slice for a chunk of CK k-steps up front (64 VGPRs:
-// one round trip per chunk; K=256 is one chunk for 256-wide nets), one scheduling
-// barrier keeps the load block ahead of the MFMAs, and the k-steps are fully unrolled.
-// `lateHook` (the epilogue's spill prefetch) is issued right after the last MFMA: issuing it
-// mid-GEMM overlapped more latency but pushed the train kernel 130 VGPRs over its budget.
+// wave requests its WHOLE weight slice for a chunk of CK k-steps up front (32 VGPRs:
+// one round trip per chunk), one scheduling barrier keeps the load block ahead of the MFMAs,
+// and the k-steps are fully unrolled.  `postHook` (the epilogue's spill-tile requests) is issued right
+// after the last MFMA, when the weight registers are dead: vmcnt retires in order, so a request in front
+// of a weight load would put its HBM round trip into the MFMA stream, and requesting earlier costs
+// registers the 128-VGPR budget does not have (measured variants: profiles/r02_ab_chain_variants.txt).
 template <int FBN, int CKF> struct WChunk { uint4 v[CKF / FBN][FBN]; };   // one chunk of packed weight fragments (32 VGPRs)
 struct WRef { int soff; int rb; };   // byte offset of a wave's slice of a packed matrix in the shadow buffer + row-block stride (bytes)
 
-// request chunk 0 of a matrix (the whole 8-k-step slice up front: one L2 round trip per chunk).
-// Measured: issuing this at the END of the previous epilogue, ahead of the barrier, is 13 us SLOWER for the whole
-// kernel (and costs 32 spilled VGPRs); so is re-requesting each fragment register right after its MFMAs
-// (GEMM_ROLLING_REFILL, +4 us) and reading the activation operand two k-steps ahead (GEMM_LDS_DEPTH 2, +3 us).
 template <int FBN, int CKF>
-__device__ __forceinline__ void preload_w(WChunk<FBN, CKF>& wq, rsrc_t rw, WRef r, int lane16) {
+__device__ __forceinline__ void load_w(WChunk<FBN, CKF>& wq, rsrc_t rw, WRef r, int lane16, int chunk) {
   constexpr int CK = CKF / FBN;
-#if ISDF_EXP_NO_WLOAD      // what-if (results wrong): weight fragments are never fetched
-  asm volatile("" : "+v"(wq.v[0][0].x));
-  return;
-#endif
 #pragma unroll
   for (int s = 0; s < CK; ++s)
 #pragma unroll
     for (int fb = 0; fb < FBN; ++fb)
-      wq.v[s][fb] = bload16<0>(rw, lane16 + (s & 3) * 1024, r.soff + fb * r.rb + (s >> 2) * 4096);
+      wq.v[s][fb] = bload16<0>(rw, lane16 + (s & 3) * 1024, r.soff + fb * r.rb + chunk * CK * 1024 + (s >> 2) * 4096);
 }
 
-struct NoHook { __device__ void operator()() const {} };
-// midHook: requests issued BEHIND the last weight request of the GEMM and in front of its last chunk of MFMAs (they then
-// have that chunk and the barrier to land); only for requests small enough to stay inside the VGPR budget.
-template <bool F16, int KSTEPS, int FBN, int PBN, int ROWB, int CKF, typename Hook, typename Hook2, typename Hook3 = NoHook>
+template <bool F16, int KSTEPS, int FBN, int PBN, int ROWB, int CKF, typename Hook>
 __device__ __forceinline__ void gemm(f32x16 (&acc)[FBN][PBN], WChunk<FBN, CKF>& wq, rsrc_t rw, WRef wr, const char* xl,
-                                     int colByteBase, int lane, Hook&& earlyHook, Hook2&& lateHook, Hook3&& midHook = NoHook()) {
+                                     int colByteBase, int lane, Hook&& postHook) {
   constexpr int CK = CKF / FBN;                  // k-steps per chunk: CK*FBN uint4 = 32 VGPRs
   static_assert(KSTEPS % CK == 0, "K must be a multiple of the chunk");
   static_assert((ROWB & 255) == 0, "row base must leave the swizzle bits (4-7) clear");
@@ -156,15 +91,9 @@ __device__ __forceinline__ void gemm(f32x16 (&acc)[FBN][PBN], WChunk<FBN, CKF>& 
   // (point block, region, ks>>3) being immediate offsets.
   const int xlane = j * ROWB + ((hi * 16) ^ ((j & 15) << 4));   // byte offset from the tile base (kept an offset so the LDS address space survives)
   const int lane16 = lane * 16;
-  preload_w(wq, rw, wr, lane16);
-#if GEMM_HOOKS_FIRST
-  earlyHook();
-  lateHook();
-  __builtin_amdgcn_sched_barrier(0);
-#endif
-  // One chunk: the activation operand is read GEMM_LDS_DEPTH k-steps ahead of the MFMAs that consume it, and
-  // (REFILL) each weight fragment register is re-requested for the next chunk as soon as its MFMAs have issued,
-  // so CK fragment loads stay in flight across the chunk boundary with no extra registers.
+  load_w(wq, rw, wr, lane16, 0);
+  // One chunk: the activation operand is read one k-step ahead of the MFMAs that consume it; the weight registers are
+  // re-requested for the next chunk after the chunk's last MFMA.
   auto chunk = [&](int ch, auto refill) {
     const int k0 = ch * CK;
     int xch = (xlane ^ ((k0 & 7) * 32)) + (k0 >> 3) * 256 + colByteBase;
@@ -173,67 +102,32 @@ __device__ __forceinline__ void gemm(f32x16 (&acc)[FBN][PBN], WChunk<FBN, CKF>& 
     asm volatile("" : "+v"(xch));
     auto readb = [&](int s, v8 (&b)[PBN]) {
 #pragma unroll
-      for (int pb = 0; pb < PBN; ++pb) {
-#if ISDF_EXP_HALF_LDS    // what-if (results wrong): one operand read feeds both point blocks
-        if (pb > 0) { b[pb] = b[0]; continue; }
-#endif
+      for (int pb = 0; pb < PBN; ++pb)
         b[pb] = __builtin_bit_cast(v8, *(const uint4*)(xl + ((xch ^ (s * 32)) + pb * 32 * ROWB)));
-      }
     };
-    constexpr int D = GEMM_LDS_DEPTH < CK ? GEMM_LDS_DEPTH : CK - 1;
-    v8 b[D + 1][PBN];
-#pragma unroll
-    for (int s = 0; s < D; ++s) readb(s, b[s]);
+    v8 b[2][PBN];
+    readb(0, b[0]);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int s = 0; s < CK; ++s) {
-      if (s + D < CK) readb(s + D, b[(s + D) % (D + 1)]);
+      if (s + 1 < CK) readb(s + 1, b[(s + 1) & 1]);
 #pragma unroll
       for (int fb = 0; fb < FBN; ++fb)
 #pragma unroll
         for (int pb = 0; pb < PBN; ++pb)
-          acc[fb][pb] = Op<F16>::mfma(__builtin_bit_cast(v8, wq.v[s][fb]), b[s % (D + 1)][pb], acc[fb][pb]);
-#if GEMM_ROLLING_REFILL
-      if (decltype(refill)::value) {
-#pragma unroll
-        for (int fb = 0; fb < FBN; ++fb)
-          wq.v[s][fb] = bload16<0>(rw, lane16 + (s & 3) * 1024, wr.soff + fb * wr.rb + (ch + 1) * CK * 1024 + (s >> 2) * 4096);
-      }
-#endif
+          acc[fb][pb] = Op<F16>::mfma(__builtin_bit_cast(v8, wq.v[s][fb]), b[s & 1][pb], acc[fb][pb]);
       __builtin_amdgcn_sched_barrier(0);
     }
-#if !GEMM_ROLLING_REFILL && !ISDF_EXP_NO_WLOAD
     if (decltype(refill)::value) {
-#pragma unroll
-      for (int s = 0; s < CK; ++s)
-#pragma unroll
-        for (int fb = 0; fb < FBN; ++fb)
-          wq.v[s][fb] = bload16<0>(rw, lane16 + (s & 3) * 1024, wr.soff + fb * wr.rb + (ch + 1) * CK * 1024 + (s >> 2) * 4096);
+      load_w(wq, rw, wr, lane16, ch + 1);
       __builtin_amdgcn_sched_barrier(0);
     }
-#endif
   };
 #pragma unroll 1
   for (int ch = 0; ch < NCH - 1; ++ch) chunk(ch, std::true_type{});
-  // The epilogue's spill-tile prefetch is split: ONE tensor (16 VGPRs) is requested before the last chunk --
-  // behind the last weight request, because vmcnt retires in order and a prefetch in front of a weight load
-  // would put its HBM round trip into the MFMA stream -- so the last chunk's MFMAs cover its latency; the
-  // rest goes out after the last MFMA, when the weight registers are dead (both early = 111 spilled VGPRs).
-#if GEMM_HOOKS_FIRST   // what-if at a 256-VGPR budget (one workgroup per CU): the epilogue's tiles are requested behind chunk 0's weights
-  chunk(NCH - 1, std::false_type{});
-#elif GEMM_HOOK_BEFORE_LAST_CHUNK
-  earlyHook();
   __builtin_amdgcn_sched_barrier(0);
   chunk(NCH - 1, std::false_type{});
-#else
-  midHook();
-  __builtin_amdgcn_sched_barrier(0);
-  chunk(NCH - 1, std::false_type{});
-  earlyHook();
-#endif
-#if !GEMM_HOOKS_FIRST
-  lateHook();
-#endif
+  postHook();
 }
 
 template <int FBN, int PBN> __device__ __forceinline__ void zero_acc(f32x16 (&acc)[FBN][PBN]) {
@@ -251,9 +145,10 @@ __device__ __forceinline__ int frag16_off(int w, int fb, int pb, int qp, int lan
   return ((((w * FBN + fb) * PBN + pb) * 2 + qp) * 64 + lane) * 8;
 }
 
-template <int HD, int EP, bool F16, int MODE>
-__global__ __launch_bounds__(chain_nw(HD) * 64, (HD <= 256 && EP == HD && chain_nw(HD) == 8 && TILE_PTS == 64 ? 4 : 2)) void chain_kernel(const ChainParams p) {
+template <int HD, int EP, int OPER, int MODE>
+__global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 && EP == HD ? 4 : 2)) void chain_kernel(const ChainParams p) {
   typedef Tile<HD, EP> T;
+  constexpr bool F16 = oper_f16(OPER), X2 = oper_x2(OPER);
   static_assert(EP == HD || EP == 2 * HD, "padded embedding width is one or two hidden widths");
   constexpr bool WIDE_E = T::WIDE_E;
   constexpr int BM = T::BM, FB = T::FB, PB = T::PB, ROWB = T::ROWB;
@@ -286,58 +181,23 @@ __global__ __launch_bounds__(chain_nw(HD) * 64, (HD <= 256 && EP == HD && chain_
   if (n0 >= P) return;
   const int nf = L.n_freqs;
   const float so = L.scale_output;
-#if ISDF_DEBUG_HOOKS
-  if (p.dbg_stagger && (blockIdx.x & 1)) {   // experiment: de-phase odd tiles (L2-bound vs HBM-bound sweeps)
-    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-    while (__builtin_amdgcn_s_memtime() - t0 < (unsigned long long)p.dbg_stagger * 1000ull) __builtin_amdgcn_s_sleep(64);
-  }
-  int tsn = 0;
-  auto TS = [&]() {   // debug timeline: wave 0 of workgroup 100 stamps phase boundaries
-    if (p.dbg_times && blockIdx.x == 100 && tid == 0) p.dbg_times[tsn] = __builtin_amdgcn_s_memtime();
-    ++tsn;
-  };
-#else
-  auto TS = [] {};
-#endif
+  ChainStamps TS(p.dbg);   // phase time stamps of the -DISDF_DEBUG_HOOKS=1 build; empty inlines in the shipped kernel
   TS();
-  // Issue priority between the two workgroups of a CU (A/B switch ISDF_PRIO_MODE): with equal priority
-  // the OLDER workgroup's waves win VALU/MFMA arbitration all the way, finish ~33 us early and leave the younger one
-  // to run the rest alone at the poor single-workgroup rate.  `gen` = which round of 256 workgroups this one was
-  // dispatched in (the second workgroup of a CU when the grid is <= 512).
+  // Issue priority between the two workgroups of a CU: with equal priority the OLDER workgroup's waves win
+  // VALU/MFMA arbitration all the way, finish ~33 us early and leave the younger one to run the rest alone at the poor
+  // single-workgroup rate.  The second workgroup of a CU (dispatch round `gen` odd; the grid is <= 512 at the reference
+  // batch) therefore raises its priority for the two middle sweeps and the pair finishes together.
   const bool genOdd = (blockIdx.x >> 8) & 1;
   auto PRIO = [&](int phase) {   // phase 0 fwd, 1 first reverse, 2 adjoint, 3 reverse
-#if ISDF_PRIO_MODE == 1
     if (genOdd) { if (phase == 1 || phase == 2) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
-#elif ISDF_PRIO_MODE == 2
-    if (genOdd) __builtin_amdgcn_s_setprio(1);
-#elif ISDF_PRIO_MODE == 3
-    if (genOdd) { if (phase >= 2) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
-#elif ISDF_PRIO_MODE == 4
-    if (genOdd) { if (phase == 0 || phase == 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
-#elif ISDF_PRIO_MODE == 5
-    if (genOdd) { if (phase >= 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
-#elif ISDF_PRIO_MODE == 6
-    if (genOdd) { if (phase <= 2) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
-#elif ISDF_PRIO_MODE == 7
-    if (genOdd) { if (phase == 1 || phase == 3) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
-#endif
-    (void)phase;
   };
   PRIO(0);
-#if ISDF_DEBUG_HOOKS
-  // debug: wall-clock (s_memrealtime, 100 MHz) start/end of every 4th workgroup -> slots 128..511
-  if (p.dbg_times && tid == 0 && (blockIdx.x & 3) == 0 && blockIdx.x < 4 * 190)
-    p.dbg_times[128 + blockIdx.x / 2] = __builtin_amdgcn_s_memrealtime();
-#endif
+  TS.wall(0);
 
   // element offsets of the four shadow weight sets inside the shadow buffer
-  const int64_t setFwdA = L.setFwdA, setFwdB = L.setFwdB, setBwdA = L.setBwdA, setBwdB = L.setBwdB;
+  const int64_t setFwdA = L.setFwdA, setFwdB = L.setFwdB, setBwdA = L.setBwdA, setBwdB = L.setBwdB, setFwdLo = L.setFwdLo;
   // this tile's block of the spill buffer ([tile][tensor][BM*HD] bf16)
-#if ISDF_DEBUG_HOOKS
-  uint16_t* spillTile = p.spill + (int64_t)(p.dbg_alias ? (blockIdx.x % p.dbg_alias) : blockIdx.x) * p.sp.tileStride;
-#else
-  uint16_t* spillTile = p.spill + (int64_t)blockIdx.x * p.sp.tileStride;
-#endif
+  uint16_t* spillTile = p.spill + TS.spill_tile() * p.sp.tileStride;
   const rsrc_t rsW = make_rsrc(p.shadow, 0x7fffffffu);
   const rsrc_t rsS = make_rsrc(spillTile, (uint32_t)(p.sp.tileStride * 2));   // loads (compiler-tracked)
   const i32x4 srdS = make_srd(spillTile, (uint32_t)(p.sp.tileStride * 2));     // stores (bstore16_nt)
@@ -347,7 +207,7 @@ __global__ __launch_bounds__(chain_nw(HD) * 64, (HD <= 256 && EP == HD && chain_
   constexpr auto cidx = [](int fb, int pb, int qp) { return (fb * PB + pb) * 2 + qp; };   // piece-of-64-lanes index within the wave
   float* vecTile = MODE == 2 ? p.vec_part + (int64_t)blockIdx.x * p.vecStride : nullptr;
   const rsrc_t rsV = make_rsrc(vecTile, MODE == 2 ? (uint32_t)p.vecStride * 4u : 0u);
-  (void)setFwdB; (void)setBwdB; (void)rsS; (void)rsV; (void)srdS;
+  (void)setFwdB; (void)setBwdB; (void)setFwdLo; (void)rsS; (void)rsV; (void)srdS;
   // feature index of (fb, qp) blocks: f0 = ubase(fb, qp) + 4*hi
   auto ubase = [&](int fb, int qp) { return w * (FB * 32) + fb * 32 + 16 * qp; };
   // 8 fp32 parameters params[off + f0 + {0..3, 8..11}]
@@ -368,11 +228,8 @@ __global__ __launch_bounds__(chain_nw(HD) * 64, (HD <= 256 && EP == HD && chain_
   // embedding in the forward operand type; region 1 a bf16 copy staged for the
   // spill (dW operand A_0).
   {
-#if ISDF_PE_MAP   // a wave = (BM / NW points) x (direction slices): rows 1 KB apart land on 8 banks, so 64 points per wave was 8-way conflicted
+    // a wave = (BM / NW points) x (direction slices): rows are 1 KB apart, i.e. 8 banks -- 64 points per wave was 8-way conflicted
     const int pt = (tid % (BM / T::NW)) + (BM / T::NW) * (tid / 64), prt = (tid % 64) / (BM / T::NW);
-#else
-    const int pt = tid & (BM - 1), prt = tid / BM;
-#endif
     constexpr int NPART = (T::NW * 64) / BM;
     const int64_t n = n0 + pt;
     float x0 = 0.f, x1 = 0.f, x2 = 0.f;
@@ -421,7 +278,7 @@ __global__ __launch_bounds__(chain_nw(HD) * 64, (HD <= 256 && EP == HD && chain_
             lo = pack4<false>((float)a[0], (float)a[1], (float)a[2], (float)a[3]);
             hi2 = pack4<false>((float)b[0], (float)b[1], (float)b[2], (float)b[3]);
           }
-          CH_STORE(true, make_uint4(lo.x, lo.y, hi2.x, hi2.y), sbase(tensorOff), cidx(fb, pb, qp));
+          bstore16_nt<true>(make_uint4(lo.x, lo.y, hi2.x, hi2.y), srdS, lane16, sbase(tensorOff), cidx(fb, pb, qp));
         }
   };
   refresh();
@@ -480,51 +337,19 @@ __global__ __launch_bounds__(chain_nw(HD) * 64, (HD <= 256 && EP == HD && chain_
   };
   auto store_tile8 = [&](int64_t tensorOff, int fb, int pb, int qp, const float (&v)[8]) {
     const uint2 a = pack4<false>(v[0], v[1], v[2], v[3]), b = pack4<false>(v[4], v[5], v[6], v[7]);
-    CH_STORE(true, make_uint4(a.x, a.y, b.x, b.y), sbase(tensorOff), cidx(fb, pb, qp));
+    bstore16_nt<true>(make_uint4(a.x, a.y, b.x, b.y), srdS, lane16, sbase(tensorOff), cidx(fb, pb, qp));
   };
-  // sigma' tiles ("frag8": the same piece order as frag16 with 8 BYTES per lane: piece c of a wave at c*512 + lane*8).
-  // sigma' in (0, 1] as round(255 s): its error (<= 1/510) is the size of the error of 1 - exp(-beta a) from a bf16 `a`.
-  struct Pre8 { uint2 v[FB][2][PB]; };
-  auto sbase8 = [&](int64_t tensorOff) { return (int)(tensorOff * 2) + w * (FB * PB * 2) * 512; };
-  auto prefetch8 = [&](int64_t tensorOff, Pre8& pr) {
-    const int sb = sbase8(tensorOff);
-#pragma unroll
-    for (int fb = 0; fb < FB; ++fb)
-#pragma unroll
-      for (int qp = 0; qp < 2; ++qp)
-#pragma unroll
-        for (int pb = 0; pb < PB; ++pb) {
-          const auto v2 = __builtin_amdgcn_raw_buffer_load_b64(rsS, lane * 8 + cidx(fb, pb, qp) * 512, sb, kAuxNT);
-          pr.v[fb][qp][pb] = make_uint2(v2[0], v2[1]);
-        }
-  };
-  auto load_s1 = [&](const Pre8& pr, int fb, int pb, int qp, float (&o)[8]) {
-    const uint2 u = pr.v[fb][qp][pb];
-    constexpr float k = 1.f / 255.f;
-    // (float)((x >> 8k) & 255) is matched to v_cvt_f32_ubyte<k>
-    o[0] = (float)(u.x & 255u) * k; o[1] = (float)((u.x >> 8) & 255u) * k;
-    o[2] = (float)((u.x >> 16) & 255u) * k; o[3] = (float)(u.x >> 24) * k;
-    o[4] = (float)(u.y & 255u) * k; o[5] = (float)((u.y >> 8) & 255u) * k;
-    o[6] = (float)((u.y >> 16) & 255u) * k; o[7] = (float)(u.y >> 24) * k;
-  };
-  auto store_s1 = [&](int64_t tensorOff, int fb, int pb, int qp, const float (&s)[8]) {
-    uint32_t q[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) q[e] = (uint32_t)(s[e] * 255.f + 0.5f);   // s in [0, 1]: v_cvt_u32_f32 truncates, +0.5 rounds
-    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-    u32x2 v;
-    v[0] = q[0] | (q[1] << 8) | (q[2] << 16) | (q[3] << 24);
-    v[1] = q[4] | (q[5] << 8) | (q[6] << 16) | (q[7] << 24);
-    __builtin_amdgcn_raw_buffer_store_b64(v, rsS, lane * 8 + cidx(fb, pb, qp) * 512, sbase8(tensorOff), kAuxNT);
-  };
-  auto store_tile8_p = [&](int64_t tensorOff, int fb, int pb, int qp, const float (&v)[8]) {
-    const uint2 a = pack4<false>(v[0], v[1], v[2], v[3]), b = pack4<false>(v[4], v[5], v[6], v[7]);
-    CH_STORE(ISDF_NT_P != 0, make_uint4(a.x, a.y, b.x, b.y), sbase(tensorOff), cidx(fb, pb, qp));
-  };
-  // tensors that only the dW kernel re-reads (GB, ZB): cache policy is an A/B switch
+  // tensors that only the dW kernel re-reads (GB, ZB) are stored with the default cache policy (chain -2.3 %, dW unchanged);
+  // everything the chain kernel itself re-reads (A, P, INJ) stays non-temporal
   auto store_tile8_dw = [&](int64_t tensorOff, int fb, int pb, int qp, const float (&v)[8]) {
     const uint2 a = pack4<false>(v[0], v[1], v[2], v[3]), b = pack4<false>(v[4], v[5], v[6], v[7]);
-    CH_STORE(ISDF_NT_DW_TENSORS != 0, make_uint4(a.x, a.y, b.x, b.y), sbase(tensorOff), cidx(fb, pb, qp));
+    bstore16_nt<false>(make_uint4(a.x, a.y, b.x, b.y), srdS, lane16, sbase(tensorOff), cidx(fb, pb, qp));
+  };
+  // sigma'(z) of a layer for the backward epilogues, re-derived from the bf16 activation tile (no sigma' tensor is stored)
+  auto load_s1 = [&](const Pre& pr, int fb, int pb, int qp, float (&o)[8]) {
+    load_tile8(pr, fb, pb, qp, o);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = s1_from_a(o[e]);
   };
   auto put_x = [&](bool f16, int fb, int pb, int qp, const float (&v)[8], int colElemBase) {
     uint2 a, b;
@@ -539,85 +364,69 @@ __global__ __launch_bounds__(chain_nw(HD) * 64, (HD <= 256 && EP == HD && chain_
 #pragma unroll
   for (int pb = 0; pb < PB; ++pb) rawp[pb] = 0.f;
 
+  // region 1 <- fp16(v), region 2 <- fp16(v - fp16(v)): the operand pair of a compensated layer (OPER 2)
+  auto put_x_hilo = [&](int fb, int pb, int qp, const float (&v)[8]) {
+    float r[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) r[e] = v[e] - (float)(_Float16)v[e];
+    put_x(true, fb, pb, qp, v, 0);
+    put_x(true, fb, pb, qp, r, HD);
+  };
   for (int li = 0; li < L.L; ++li) {
     refresh();
-#if ISDF_BIAS_INIT
-    {   // z = b + W x: the bias rides in the accumulator, its load latency hides behind the weight preload
-      float bv[8];
-#pragma unroll
-      for (int fb = 0; fb < FB; ++fb)
-#pragma unroll
-        for (int qp = 0; qp < 2; ++qp) {
-          ld_params8(L.offB[li] + ubase(fb, qp), bv);
-#pragma unroll
-          for (int pb = 0; pb < PB; ++pb)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) acc[fb][pb][8 * qp + e] = bv[e];
-        }
-    }
-#else
     zero_acc(acc);
-#endif
+    // compensated layers (OPER 2): the cat layer adds W_lo [a | emb]; the layers past it W_lo a and W a_lo (a_lo sits in
+    // region 2, which the forward pass no longer needs once the cat layer has consumed the embedding)
+    const bool comp = X2 && li >= L.cat;
     if (li == 0)
-      gemm<F16, EP / 16, FB, PB, ROWB, T::CKF>(acc, wq, rsW, fwdW(setFwdA, li), X, HD * 2, lane, [] {}, [] {});
-    else if (li == L.cat)
-      gemm<F16, (HD + EP) / 16, FB, PB, ROWB, T::CKF>(acc, wq, rsW, fwdW(setFwdA, li), X, 0, lane, [] {}, [] {});
-    else
-      gemm<F16, HD / 16, FB, PB, ROWB, T::CKF>(acc, wq, rsW, fwdW(setFwdA, li), X, 0, lane, [] {}, [] {});
+      gemm<F16, EP / 16, FB, PB, ROWB, T::CKF>(acc, wq, rsW, fwdW(setFwdA, li), X, HD * 2, lane, [] {});
+    else if (li == L.cat) {
+      gemm<F16, (HD + EP) / 16, FB, PB, ROWB, T::CKF>(acc, wq, rsW, fwdW(setFwdA, li), X, 0, lane, [] {});
+      if (comp) gemm<F16, (HD + EP) / 16, FB, PB, ROWB, T::CKF>(acc, wq, rsW, fwdW(setFwdLo, li), X, 0, lane, [] {});
+    } else {
+      gemm<F16, HD / 16, FB, PB, ROWB, T::CKF>(acc, wq, rsW, fwdW(setFwdA, li), X, 0, lane, [] {});
+      if (comp) {
+        gemm<F16, HD / 16, FB, PB, ROWB, T::CKF>(acc, wq, rsW, fwdW(setFwdLo, li), X, 0, lane, [] {});
+        gemm<F16, HD / 16, FB, PB, ROWB, T::CKF>(acc, wq, rsW, fwdW(setFwdA, li), X, HD * 2, lane, [] {});
+      }
+    }
     TS();
-    lds_barrier();  // all waves finished reading region 1
+    lds_barrier();  // all waves finished reading the tile
     TS();
     refresh();
     const bool last = li == L.L - 1;
     if (!last) {
       float bv[8];
-      (void)bv;
-      for_blocks2([&](int fb, int pb, int qp, int row) {
-#if !ISDF_BIAS_INIT
+      for_blocks([&](int fb, int pb, int qp, int row) {
         if (pb == 0) ld_params8(L.offB[li] + ubase(fb, qp), bv);
-#endif
         float a[8];
-#if ISDF_S1_U8
-        if (MODE >= 1) {
-          float s1[8];
 #pragma unroll
-          for (int e = 0; e < 8; ++e) a[e] = softplus_s1(acc[fb][pb][8 * qp + e] + (ISDF_BIAS_INIT ? 0.f : bv[e]), s1[e]);
-          store_s1(p.sp.S1[li], fb, pb, qp, s1);
-          if (MODE == 2) store_tile8(p.sp.A[li + 1], fb, pb, qp, a);   // dW operand; the input-gradient mode needs sigma' only
-        } else {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) a[e] = softplus_f(acc[fb][pb][8 * qp + e] + (ISDF_BIAS_INIT ? 0.f : bv[e]));
-        }
-#else
-#pragma unroll
-        for (int e = 0; e < 8; ++e) a[e] = softplus_f(acc[fb][pb][8 * qp + e] + (ISDF_BIAS_INIT ? 0.f : bv[e]));
+        for (int e = 0; e < 8; ++e) a[e] = softplus_f(acc[fb][pb][8 * qp + e] + bv[e]);
         if (MODE >= 1) store_tile8(p.sp.A[li + 1], fb, pb, qp, a);
-#endif
-        put_x(F16, fb, pb, qp, a, 0);
-      }, [](int, int) {});
+        if (comp) put_x_hilo(fb, pb, qp, a);
+        else put_x(F16, fb, pb, qp, a, 0);
+      });
     } else {
       float bv[8], wv[8];
-      for_blocks2([&](int fb, int pb, int qp, int row) {
+      for_blocks([&](int fb, int pb, int qp, int row) {
         if (pb == 0) {
-#if !ISDF_BIAS_INIT
           ld_params8(L.offB[li] + ubase(fb, qp), bv);
-#endif
           ld_params8(L.offWout + ubase(fb, qp), wv);
         }
         float a[8], pl[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           float s1;
-          a[e] = softplus_s1(acc[fb][pb][8 * qp + e] + (ISDF_BIAS_INIT ? 0.f : bv[e]), s1);
+          a[e] = softplus_s1(acc[fb][pb][8 * qp + e] + bv[e], s1);
           rawp[pb] += wv[e] * a[e];
           pl[e] = so * wv[e] * s1;   // p_L = q_L * sigma'(z_L), q_L = so * w_out
         }
         if (MODE >= 1) {
           store_tile8(p.sp.A[li + 1], fb, pb, qp, a);
           put_x(F16, fb, pb, qp, pl, 0);
-          if (MODE == 2) store_tile8_p(p.sp.P[li], fb, pb, qp, pl);
+          if (MODE == 2) store_tile8(p.sp.P[li], fb, pb, qp, pl);
         }
-      }, [](int, int) {});
+      });
     }
     if (last) {
 #pragma unroll
@@ -652,20 +461,11 @@ __global__ __launch_bounds__(chain_nw(HD) * 64, (HD <= 256 && EP == HD && chain_
   // ------------------------------------------------------------------ first reverse sweep
   PRIO(1);
   for (int li = L.L - 1; li >= 1; --li) {
-#if ISDF_S1_U8
-    Pre8 preA;   // sigma'(z_{li-1})
-#else
-    Pre preA;
-#endif
+    Pre preA;   // a_{li-1}: sigma'(z_{li-1}) is re-derived from it
     zero_acc(acc);
     refresh();
-#if ISDF_REV1_EARLY   // the first reverse sweep re-reads ONE tensor: requested in front of the last chunk of MFMAs
     gemm<F16, HD / 16, FB, PB, ROWB, T::CKF>(acc, wq, rsW, wptr(setBwdA, L.bwdMat[li], HD), X, 0, lane,
-                                     [] {}, [] {}, [&] { S1_PREFETCH(li - 1, p.sp.A[li], preA); });
-#else
-    gemm<F16, HD / 16, FB, PB, ROWB, T::CKF>(acc, wq, rsW, wptr(setBwdA, L.bwdMat[li], HD), X, 0, lane,
-                                     [&] { S1_PREFETCH(li - 1, p.sp.A[li], preA); }, [] {});
-#endif
+                                             [&] { prefetch(p.sp.A[li], preA); });
     TS();
     lds_barrier();
     TS();
@@ -673,12 +473,12 @@ __global__ __launch_bounds__(chain_nw(HD) * 64, (HD <= 256 && EP == HD && chain_
     const bool toR2 = (li - 1 == L.cat);
     for_blocks([&](int fb, int pb, int qp, int row) {
       float a[8], pv[8];
-      S1_LOAD(preA, fb, pb, qp, a);   // a[] = sigma'
+      load_s1(preA, fb, pb, qp, a);   // a[] = sigma'
 #pragma unroll
       for (int e = 0; e < 8; ++e) pv[e] = acc[fb][pb][8 * qp + e] * a[e];
       put_x(F16, fb, pb, qp, pv, 0);
       if (toR2) put_x(F16, fb, pb, qp, pv, HD);
-      if (MODE == 2) store_tile8_p(p.sp.P[li - 1], fb, pb, qp, pv);
+      if (MODE == 2) store_tile8(p.sp.P[li - 1], fb, pb, qp, pv);
     });
     TS();
     lds_barrier();
@@ -706,7 +506,7 @@ __global__ __launch_bounds__(chain_nw(HD) * 64, (HD <= 256 && EP == HD && chain_
   };
   refresh();
   if constexpr (!WIDE_E) {
-  gemm<F16, (2 * HD) / 16, FB, PB, ROWB, T::CKF>(acc, wq, rsW, wptr(setBwdA, L.bwdG, 2 * HD), X, 0, lane, [] {}, loss_inputs);
+  gemm<F16, (2 * HD) / 16, FB, PB, ROWB, T::CKF>(acc, wq, rsW, wptr(setBwdA, L.bwdG, 2 * HD), X, 0, lane, loss_inputs);
   // g_x' = J_pe^T Eg.  Eg goes through the (now idle) X tile as fp32 [BM][HD] so the contraction can run in
   // the PE stage's (point, direction-slice) mapping: 2*nf sin/cos per direction per thread and wave-uniform
   // direction constants, instead of one cos + index arithmetic per accumulator element (which took
@@ -727,11 +527,8 @@ __global__ __launch_bounds__(chain_nw(HD) * 64, (HD <= 256 && EP == HD && chain_
     }
   lds_barrier();
   {
-#if ISDF_PE_MAP   // a wave = (BM / NW points) x (direction slices): rows 1 KB apart land on 8 banks, so 64 points per wave was 8-way conflicted
+    // a wave = (BM / NW points) x (direction slices): rows are 1 KB apart, i.e. 8 banks -- 64 points per wave was 8-way conflicted
     const int pt = (tid % (BM / T::NW)) + (BM / T::NW) * (tid / 64), prt = (tid % 64) / (BM / T::NW);
-#else
-    const int pt = tid & (BM - 1), prt = tid / BM;
-#endif
     constexpr int NPART = T::NPART;
     const float y0 = xs[pt * 4], y1 = xs[pt * 4 + 1], y2 = xs[pt * 4 + 2];
     const char* row = X + pt * ROWB;
@@ -769,8 +566,8 @@ __global__ __launch_bounds__(chain_nw(HD) * 64, (HD <= 256 && EP == HD && chain_
       if (rh > 0) { zero_acc(acc); refresh(); }
       WRef wg = wptr(setBwdA, L.bwdG, 2 * HD);
       wg.soff += rh * (HD / 32) * ((2 * HD) / 16) * 1024;
-      if (rh == 0) gemm<F16, (2 * HD) / 16, FB, PB, ROWB, T::CKF>(acc, wq, rsW, wg, X, 0, lane, [] {}, loss_inputs);
-      else gemm<F16, (2 * HD) / 16, FB, PB, ROWB, T::CKF>(acc, wq, rsW, wg, X, 0, lane, [] {}, [] {});
+      if (rh == 0) gemm<F16, (2 * HD) / 16, FB, PB, ROWB, T::CKF>(acc, wq, rsW, wg, X, 0, lane, loss_inputs);
+      else gemm<F16, (2 * HD) / 16, FB, PB, ROWB, T::CKF>(acc, wq, rsW, wg, X, 0, lane, [] {});
       refresh();
 #pragma unroll
       for (int pb = 0; pb < PB; ++pb) {
@@ -922,11 +719,8 @@ __global__ __launch_bounds__(chain_nw(HD) * 64, (HD <= 256 && EP == HD && chain_
   // ------------------------------------------------------------------ Ebar = J_pe gbar  -> region 2 (bf16)
   if (tid < HD / 4) ((float4*)part)[tid] = ((const float4*)(p.params + L.offWout))[tid];   // w_out for the top epilogue
   {
-#if ISDF_PE_MAP   // a wave = (BM / NW points) x (direction slices): rows 1 KB apart land on 8 banks, so 64 points per wave was 8-way conflicted
+    // a wave = (BM / NW points) x (direction slices): rows are 1 KB apart, i.e. 8 banks -- 64 points per wave was 8-way conflicted
     const int pt = (tid % (BM / T::NW)) + (BM / T::NW) * (tid / 64), prt = (tid % 64) / (BM / T::NW);
-#else
-    const int pt = tid & (BM - 1), prt = tid / BM;
-#endif
     constexpr int NPART = (T::NW * 64) / BM;
     const float y0 = xs[pt * 4], y1 = xs[pt * 4 + 1], y2 = xs[pt * 4 + 2];
     const float b0 = gbs[pt * 4], b1 = gbs[pt * 4 + 1], b2 = gbs[pt * 4 + 2];
@@ -958,31 +752,26 @@ __global__ __launch_bounds__(chain_nw(HD) * 64, (HD <= 256 && EP == HD && chain_
   // injection just computed and sbar*w_out), so INJ[L-1] never leaves registers and the reverse sweep
   // starts at layer L-2 with its operand already in the X tile.
   PRIO(2);
-  auto adj_gemm = [&](int li, auto&& pf0, auto&& pf) {
+  auto adj_gemm = [&](int li, auto&& pf) {
     zero_acc(acc);
     refresh();
     if (li == 0)
-      gemm<false, EP / 16, FB, PB, ROWB, T::CKF>(acc, wq, rsW, fwdW(setFwdB, li), X, HD * 2, lane, pf0, pf);
+      gemm<false, EP / 16, FB, PB, ROWB, T::CKF>(acc, wq, rsW, fwdW(setFwdB, li), X, HD * 2, lane, pf);
     else if (li == L.cat)
-      gemm<false, (HD + EP) / 16, FB, PB, ROWB, T::CKF>(acc, wq, rsW, fwdW(setFwdB, li), X, 0, lane, pf0, pf);
+      gemm<false, (HD + EP) / 16, FB, PB, ROWB, T::CKF>(acc, wq, rsW, fwdW(setFwdB, li), X, 0, lane, pf);
     else
-      gemm<false, HD / 16, FB, PB, ROWB, T::CKF>(acc, wq, rsW, fwdW(setFwdB, li), X, 0, lane, pf0, pf);
+      gemm<false, HD / 16, FB, PB, ROWB, T::CKF>(acc, wq, rsW, fwdW(setFwdB, li), X, 0, lane, pf);
   };
   for (int li = 0; li < L.L - 1; ++li) {
-#if ISDF_S1_U8
-    Pre8 preA;   // sigma'(z_li)
-#else
-    Pre preA;
-#endif
-    Pre preP;
-    adj_gemm(li, [&] { S1_PREFETCH(li, p.sp.A[li + 1], preA); }, [&] { prefetch(p.sp.P[li], preP); });
+    Pre preA, preP;
+    adj_gemm(li, [&] { prefetch(p.sp.A[li + 1], preA); prefetch(p.sp.P[li], preP); });
     TS();
     lds_barrier();
     TS();
     refresh();
     for_blocks([&](int fb, int pb, int qp, int row) {
       float a[8], pv[8], qb[8], inj[8];
-      S1_LOAD(preA, fb, pb, qp, a);   // a[] = sigma'
+      load_s1(preA, fb, pb, qp, a);   // a[] = sigma'
       load_tile8(preP, fb, pb, qp, pv);
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
@@ -1002,7 +791,7 @@ __global__ __launch_bounds__(chain_nw(HD) * 64, (HD <= 256 && EP == HD && chain_
   {   // top layer (peeled: its three partial-sum streams must not raise the register pressure of the loop above)
     const int li = L.L - 1;
     Pre preA, preP;
-    adj_gemm(li, [&] { prefetch(p.sp.A[li + 1], preA); }, [&] { prefetch(p.sp.P[li], preP); });
+    adj_gemm(li, [&] { prefetch(p.sp.A[li + 1], preA); prefetch(p.sp.P[li], preP); });
     TS();
     lds_barrier();
     TS();
@@ -1049,17 +838,11 @@ __global__ __launch_bounds__(chain_nw(HD) * 64, (HD <= 256 && EP == HD && chain_
   // ------------------------------------------------------------------ ordinary reverse sweep with injection
   PRIO(3);
   for (int li = L.L - 2; li >= 0; --li) {
-#if ISDF_S1_U8
-    Pre8 preA;   // sigma'(z_li)
-#else
-    Pre preA;
-#endif
-    Pre preI;
-    auto pf0 = [&] { S1_PREFETCH(li, p.sp.A[li + 1], preA); };
-    auto pf = [&] { prefetch(p.sp.INJ[li], preI); };
+    Pre preA, preI;
     zero_acc(acc);
     refresh();
-    gemm<false, HD / 16, FB, PB, ROWB, T::CKF>(acc, wq, rsW, wptr(setBwdB, L.bwdMat[li + 1], HD), X, 0, lane, pf0, pf);
+    gemm<false, HD / 16, FB, PB, ROWB, T::CKF>(acc, wq, rsW, wptr(setBwdB, L.bwdMat[li + 1], HD), X, 0, lane,
+                                               [&] { prefetch(p.sp.A[li + 1], preA); prefetch(p.sp.INJ[li], preI); });
     TS();
     lds_barrier();
     TS();
@@ -1069,7 +852,7 @@ __global__ __launch_bounds__(chain_nw(HD) * 64, (HD <= 256 && EP == HD && chain_
     for (int e = 0; e < 8; ++e) bsum[e] = 0.f;
     for_blocks2([&](int fb, int pb, int qp, int row) {
       float a[8], inj[8], zb[8];
-      S1_LOAD(preA, fb, pb, qp, a);   // a[] = sigma'
+      load_s1(preA, fb, pb, qp, a);   // a[] = sigma'
       load_tile8(preI, fb, pb, qp, inj);
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
@@ -1089,42 +872,35 @@ __global__ __launch_bounds__(chain_nw(HD) * 64, (HD <= 256 && EP == HD && chain_
     lds_barrier();
     TS();
   }
-#if ISDF_DEBUG_HOOKS
-  if (p.dbg_times && tid == 0 && (blockIdx.x & 3) == 0 && blockIdx.x < 4 * 190)
-    p.dbg_times[129 + blockIdx.x / 2] = __builtin_amdgcn_s_memrealtime();
-#endif
+  TS.wall(1);
 }
 
 // ---------------------------------------------------------------------------
-template <int HD, int EP, bool F16, int MODE>
+template <int HD, int EP, int OPER, int MODE>
 static int launch_one(const ChainParams& p, int64_t nTiles, hipStream_t st) {
   typedef Tile<HD, EP> T;
-  auto k = chain_kernel<HD, EP, F16, MODE>;
+  auto k = chain_kernel<HD, EP, OPER, MODE>;
   if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES) != hipSuccess) return ISDF_EHIP;
   hipLaunchKernelGGL(k, dim3((unsigned)nTiles), dim3(T::NW * 64), T::LDS_BYTES, st, p);
   return isdf_launch_status();
 }
 
-template <int MODE>
-static int launch_mode(const ChainParams& p, int64_t nTiles, hipStream_t st) {
-  if (p.lay.HD == 256 && p.lay.EP == 256)
-    return p.lay.fwd_f16 ? launch_one<256, 256, true, MODE>(p, nTiles, st) : launch_one<256, 256, false, MODE>(p, nTiles, st);
-  if (p.lay.HD == 256)   // realsense*.json: hidden 256, E = 381 / 465
-    return p.lay.fwd_f16 ? launch_one<256, 512, true, MODE>(p, nTiles, st) : launch_one<256, 512, false, MODE>(p, nTiles, st);
-  return p.lay.fwd_f16 ? launch_one<512, 512, true, MODE>(p, nTiles, st) : launch_one<512, 512, false, MODE>(p, nTiles, st);
+template <int HD, int EP, int MODE>
+static int launch_oper(const ChainParams& p, int64_t nTiles, hipStream_t st) {
+  if (p.lay.fwd_x2) return launch_one<HD, EP, 2, MODE>(p, nTiles, st);
+  return p.lay.fwd_f16 ? launch_one<HD, EP, 1, MODE>(p, nTiles, st) : launch_one<HD, EP, 0, MODE>(p, nTiles, st);
 }
 
-bool pair_supported(const NetLayout& l);
-int launch_chain_pair(const ChainParams& p, int64_t nTiles, hipStream_t st);
+template <int MODE>
+static int launch_mode(const ChainParams& p, int64_t nTiles, hipStream_t st) {
+  if (p.lay.HD == 256 && p.lay.EP == 256) return launch_oper<256, 256, MODE>(p, nTiles, st);   // replicaCAD / scanNet
+  if (p.lay.HD == 256) return launch_oper<256, 512, MODE>(p, nTiles, st);   // realsense*.json: hidden 256, E = 381 / 465
+  return launch_oper<512, 512, MODE>(p, nTiles, st);                         // BASELINE configs[4]
+}
 
 int launch_chain(const ChainParams& p, int mode, int64_t nTiles, hipStream_t st) {
   if (!layout_supported(p.lay)) return ISDF_EUNSUPPORTED;
   if (nTiles <= 0) return ISDF_OK;
-  // ISDF_CHAIN_PAIR=1: train mode of the 256-wide nets with a 256-wide padded embedding goes through the pair-tile
-  // kernel (chain_pair.hip: one workgroup per CU owning two tiles, shared weight fetches, requests a stage ahead).
-  // Measured 208 vs 193 us on the BASELINE batch, so it is opt-in; same results (tests/test_gpu_parity.py).
-  const char* e = getenv("ISDF_CHAIN_PAIR");
-  if (mode == 2 && TILE_PTS == 64 && e && e[0] == '1' && pair_supported(p.lay)) return launch_chain_pair(p, nTiles, st);
   switch (mode) {
     case 0: return launch_mode<0>(p, nTiles, st);
     case 1: return launch_mode<1>(p, nTiles, st);

@@ -1,0 +1,59 @@
+// Development instruments of the chain kernel, compiled in ONLY with -DISDF_DEBUG_HOOKS=1
+// (tools/build_variants.py dbg=-DISDF_DEBUG_HOOKS=1, loaded by tools/timeline.py through ISDF_HIP_LIB).
+// The shipped library carries none of it: ChainDebug is empty and every hook below is an empty inline.
+#pragma once
+#include <stdint.h>
+#include <stdlib.h>
+#include <hip/hip_runtime.h>
+
+namespace isdf {
+
+#ifndef ISDF_DEBUG_HOOKS
+#define ISDF_DEBUG_HOOKS 0
+#endif
+
+#if ISDF_DEBUG_HOOKS
+struct ChainDebug {
+  int32_t alias;              // ISDF_DEBUG_ALIAS_SPILL=n: tiles share n spill regions (timing only, results garbage)
+  int32_t stagger;            // ISDF_DEBUG_STAGGER=k: odd tiles start k kilo-cycles late
+  unsigned long long* times;  // ISDF_DEBUG_TIMELINE: [0..127] s_memtime stamps of workgroup 100, [128..] wall clocks
+};
+inline void chain_debug_from_env(ChainDebug& d, void* stamp_area) {
+  if (const char* e = getenv("ISDF_DEBUG_ALIAS_SPILL")) d.alias = atoi(e);
+  if (const char* e = getenv("ISDF_DEBUG_STAGGER")) d.stagger = atoi(e);
+  if (getenv("ISDF_DEBUG_TIMELINE")) d.times = (unsigned long long*)stamp_area;
+}
+#if defined(__HIPCC__)
+struct ChainStamps {
+  const ChainDebug& d; int n = 0;
+  __device__ explicit ChainStamps(const ChainDebug& dd) : d(dd) {
+    if (d.stagger && (blockIdx.x & 1)) {   // de-phase odd tiles
+      const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+      while (__builtin_amdgcn_s_memtime() - t0 < (unsigned long long)d.stagger * 1000ull) __builtin_amdgcn_s_sleep(64);
+    }
+  }
+  __device__ void operator()() {   // phase boundary: wave 0 of workgroup 100
+    if (d.times && blockIdx.x == 100 && threadIdx.x == 0) d.times[n] = __builtin_amdgcn_s_memtime();
+    ++n;
+  }
+  __device__ void wall(int slot) const {   // wall clock (s_memrealtime, 100 MHz) of every 4th workgroup
+    if (d.times && threadIdx.x == 0 && (blockIdx.x & 3) == 0 && blockIdx.x < 4 * 190)
+      d.times[128 + slot + blockIdx.x / 2] = __builtin_amdgcn_s_memrealtime();
+  }
+  __device__ int64_t spill_tile() const { return d.alias ? (int64_t)(blockIdx.x % d.alias) : (int64_t)blockIdx.x; }
+};
+#endif
+#else
+struct ChainDebug {};
+inline void chain_debug_from_env(ChainDebug&, void*) {}
+#if defined(__HIPCC__)
+struct ChainStamps {
+  __device__ explicit ChainStamps(const ChainDebug&) {}
+  __device__ void operator()() const {}
+  __device__ void wall(int) const {}
+  __device__ int64_t spill_tile() const { return (int64_t)blockIdx.x; }
+};
+#endif
+#endif
+
+}  // namespace isdf

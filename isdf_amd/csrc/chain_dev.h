@@ -1,22 +1,12 @@
-// Device helpers shared by the tile kernels (chain.hip: one 64-point tile per workgroup, two workgroups per CU;
-// chain_pair.hip: two tiles per workgroup, one workgroup per CU): LDS-only barrier, buffer-descriptor loads and the
-// hand-issued spill store, swizzle, DPP half-wave reductions, Softplus(beta = 100) on the base-2 units.
+// Device helpers of the tile kernel (chain.hip: one 64-point tile per workgroup, two workgroups per CU): LDS-only
+// barrier, buffer-descriptor loads and the hand-issued spill store, swizzle, DPP half-wave reductions,
+// Softplus(beta = 100) on the base-2 units.
 #pragma once
 #include "isdf_common.h"
 #include "chain_params.h"
 
 namespace isdf {
 
-// what-if experiments (timing only, results wrong; never set in a shipped build)
-#ifndef ISDF_EXP_NO_BARRIER
-#define ISDF_EXP_NO_BARRIER 0
-#endif
-#ifndef ISDF_EXP_CHEAP_EPI
-#define ISDF_EXP_CHEAP_EPI 0
-#endif
-#ifndef ISDF_PE_MAP
-#define ISDF_PE_MAP 1      // thread mapping of the PE-shaped stages (0: one point per lane, the round-1/2 mapping)
-#endif
 constexpr float kHalfPi = 1.5707963267948966f;
 constexpr float kBeta = 100.f;
 
@@ -26,9 +16,7 @@ constexpr float kBeta = 100.f;
 // __syncthreads() would drain them (s_waitcnt vmcnt(0)) at every layer.
 __device__ __forceinline__ void lds_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#if !ISDF_EXP_NO_BARRIER   // what-if (results wrong): waves of a workgroup run unsynchronised
   __builtin_amdgcn_s_barrier();
-#endif
   asm volatile("" ::: "memory");
 }
 
@@ -62,18 +50,9 @@ __device__ __forceinline__ i32x4 make_srd(const void* base, uint32_t bytes) {
   d[2] = (int)bytes; d[3] = 0x00020000;
   return d;
 }
-#ifndef ISDF_SPILL_STORE_POLICY_ID
-#define ISDF_SPILL_STORE_POLICY_ID 0   // cache policy of the streaming spill stores: 0 nt, 1 sc1 (write-through, line dropped from L2), 2 sc1 nt
-#endif
-#if ISDF_SPILL_STORE_POLICY_ID == 1
-#define ISDF_SPILL_STORE_POLICY "sc1"
-#elif ISDF_SPILL_STORE_POLICY_ID == 2
-#define ISDF_SPILL_STORE_POLICY "sc1 nt"
-#else
-#define ISDF_SPILL_STORE_POLICY "nt"
-#endif
+// (write-through `sc1` instead of `nt` measured the same: profiles/r02_ab_chain_variants.txt)
 #define ISDF_BSTORE16_NT(IMM) \
-  asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen offset:" #IMM " " ISDF_SPILL_STORE_POLICY "\n\ts_nop 1" ::"v"(v), "v"(voff), "s"(srd), "s"(soff) : "memory")
+  asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen offset:" #IMM " nt\n\ts_nop 1" ::"v"(v), "v"(voff), "s"(srd), "s"(soff) : "memory")
 #define ISDF_BSTORE16_DF(IMM) \
   asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen offset:" #IMM "\n\ts_nop 1" ::"v"(v), "v"(voff), "s"(srd), "s"(soff) : "memory")
 template <bool NT = true>
@@ -129,9 +108,6 @@ __device__ __forceinline__ void half_wave_store(float v, float* dst, int lane) {
 constexpr float kC1 = kBeta * 1.4426950408889634f;   // beta * log2(e)
 constexpr float kC2 = 0.6931471805599453f / kBeta;   // ln2 / beta
 __device__ __forceinline__ float softplus_f(float z) {
-#if ISDF_EXP_CHEAP_EPI     // what-if (results wrong): no transcendental math in the epilogues
-  return fmaxf(z, 0.f);
-#endif
   const float t = __builtin_amdgcn_exp2f(fminf(kC1 * z, 30.f));
   return fmaxf(z, kC2 * __builtin_amdgcn_logf(1.f + t));
 }
@@ -143,9 +119,6 @@ __device__ __forceinline__ float softplus_s1(float z, float& s1) {   // also sig
 }
 // sigma'(z) recovered from the stored activation: 1 - exp(-beta a)
 __device__ __forceinline__ float s1_from_a(float a) {
-#if ISDF_EXP_CHEAP_EPI
-  return a;
-#endif
   return 1.f - __builtin_amdgcn_exp2f(-kC1 * a);
 }
 

@@ -1,6 +1,7 @@
 // Kernel-argument structs shared by the launchers (capi.hip) and the kernels.
 #pragma once
 #include "isdf_common.h"
+#include "chain_debug.h"
 
 namespace isdf {
 
@@ -25,10 +26,7 @@ struct ChainParams {
   float* vec_part;            // [nTiles][vecStride] bias / out-layer gradient partials (no atomics)
   int32_t vecStride;
   uint16_t* spill; SpillLayout sp;
-  // development builds only (-DISDF_DEBUG_HOOKS=1; the shipped kernel ignores them)
-  int32_t dbg_alias;          // ISDF_DEBUG_ALIAS_SPILL: alias tiles' spills (timing experiments)
-  int32_t dbg_stagger;        // ISDF_DEBUG_STAGGER: odd tiles start this many kilo-cycles late
-  unsigned long long* dbg_times;  // ISDF_DEBUG_TIMELINE: [256] s_memtime stamps of one workgroup
+  ChainDebug dbg;             // empty in the shipped build (chain_debug.h)
 };
 
 struct DwParams {

@@ -18,12 +18,9 @@
 
 namespace isdf {
 
-#ifndef ISDF_DW_NT_STORES
-#define ISDF_DW_NT_STORES 1   // the K-split slabs are written once and read once (by the step tail): non-temporal (dW 75.9 -> 74.9 us)
-#endif
-#ifndef ISDF_DW_NT_LOADS
-#define ISDF_DW_NT_LOADS 1   // operand tiles are read exactly once: non-temporal, so the 353 MB stream does not evict the packed weight
-#endif                      // copies from L2 (measured: dW unchanged, the NEXT step's chain kernel 185.6 -> 182.8 us, step +1.8 %)
+// Read-once / write-once streams are non-temporal: the operand tiles (353 MB) must not evict the packed weight copies the
+// NEXT step's chain kernel streams from L2 (measured: that kernel 185.6 -> 182.8 us), and the K-split slabs are written
+// once and read once by the step tail (dW 75.9 -> 74.9 us).
 
 template <int HD> struct DwTile {
   static constexpr int BM = DW_PTS;
@@ -96,15 +93,10 @@ __global__ __launch_bounds__(512, 2) void dw_kernel(const DwParams p) {
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
       int pt, f0;
-#if ISDF_DW_NT_LOADS   // every operand byte is read exactly once: non-temporal
       typedef unsigned int u32x4n __attribute__((ext_vector_type(4)));
       const u32x4n va = __builtin_nontemporal_load((const u32x4n*)(ta + frag16_piece(c * 512 + tid, half, slA, pt, f0)));
       const u32x4n vb = __builtin_nontemporal_load((const u32x4n*)(tb + frag16_piece(c * 512 + tid, half, slB, pt, f0)));
       ra[c] = make_uint4(va[0], va[1], va[2], va[3]); rb[c] = make_uint4(vb[0], vb[1], vb[2], vb[3]);
-#else
-      ra[c] = ta[frag16_piece(c * 512 + tid, half, slA, pt, f0)];
-      rb[c] = tb[frag16_piece(c * 512 + tid, half, slB, pt, f0)];
-#endif
     }
   };
   auto commit = [&](const uint4 (&ra)[CH], const uint4 (&rb)[CH], int buf) {
@@ -185,18 +177,7 @@ __global__ __launch_bounds__(512, 2) void dw_kernel(const DwParams p) {
       for (int r = 0; r < 16; ++r) {
         const int o = wo * 64 + ob * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
         const int i = wi * 128 + ib * 32 + (lane & 31);
-#if ISDF_SLAB_BF16
-        // neighbouring lanes hold neighbouring columns: pair them (quad_perm [1,0,3,2]) so even lanes store 4 bytes
-        const float v = acc[ob][ib][r];
-        const float nb = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));
-        if (!(lane & 1)) *(uint32_t*)(slab + o * DW_BLK + i) = pack4<false>(v, nb, 0.f, 0.f).x;
-#else
-#if ISDF_DW_NT_STORES
         __builtin_nontemporal_store(acc[ob][ib][r], slab + o * DW_BLK + i);
-#else
-        slab[o * DW_BLK + i] = acc[ob][ib][r];
-#endif
-#endif
       }
 }
 

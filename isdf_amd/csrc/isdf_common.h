@@ -9,33 +9,12 @@ namespace isdf {
 
 constexpr int MAXL = 16;       // max hidden layers (2B+2)
 constexpr int N_DIRS = 21;     // icosahedron directions, embedding.py:40-62
-#ifndef ISDF_TILE_PTS
-#define ISDF_TILE_PTS 64
-#endif
-constexpr int TILE_PTS = ISDF_TILE_PTS;   // points per chain-kernel workgroup (64: two workgroups per CU)
-constexpr int DW_PTS = 64;     // points per dW-kernel stage (half a chain tile)
-#ifndef ISDF_CHAIN_NW
-#define ISDF_CHAIN_NW 8
-#endif
-constexpr int CHAIN_NW = ISDF_CHAIN_NW;    // waves per chain-kernel workgroup (each owns HD/CHAIN_NW features)
-// the 512-wide instantiation always runs 8 waves (one workgroup per CU)
-constexpr int chain_nw(int hd) { return hd == 256 ? CHAIN_NW : 8; }
-// weight fragments a wave requests at once: 8 (32 VGPRs) at the 128-VGPR budget of 8-wave workgroups, 16 at 4 waves
-#ifndef ISDF_CHUNK_FRAGS
-#define ISDF_CHUNK_FRAGS 8
-#endif
-constexpr int chain_chunk_frags(int nw) { return nw == 8 ? ISDF_CHUNK_FRAGS : 16; }
+constexpr int TILE_PTS = 64;   // points per chain-kernel workgroup (two workgroups per CU)
+constexpr int DW_PTS = 64;     // points per dW-kernel stage
+constexpr int CHAIN_NW = 8;    // waves per chain-kernel workgroup (each owns HD/CHAIN_NW features)
+constexpr int CHAIN_CHUNK_FRAGS = 8;   // weight fragments a wave requests at once (32 VGPRs at the 128-VGPR budget)
 constexpr int DW_SPLITK = 36;  // K-splits per dW unit (7 units x 36 = 252 workgroups)
-#ifndef ISDF_SLAB_BF16
-#define ISDF_SLAB_BF16 0       // 1: the K-split partial slabs are stored as bf16 (half the slab traffic of dW + step tail)
-#endif
-typedef
-#if ISDF_SLAB_BF16
-    uint16_t
-#else
-    float
-#endif
-    slab_t;
+typedef float slab_t;          // K-split partial slabs (bf16 slabs measured: parity unchanged, -2 us only)
 
 // Vector types for the 16-bit MFMA operands.
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
@@ -50,6 +29,8 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 struct NetLayout {
   int HD, EP, E, B, L, cat, n_freqs;
   int fwd_f16;                 // 1: fp16 operands in forward/first-backward GEMMs
+  int fwd_x2;                  // 1: compensated forward ("fp16x2"): layers >= cat add W_lo * x (and, past the cat layer,
+                               //    W * x_lo) so that sdf meets the reference to 1e-3
   int has_transform;
   float scale_input, scale_output;
   float T[12];
@@ -63,6 +44,7 @@ struct NetLayout {
   int64_t fwdSetElems, bwdSetElems;
   // the four sets inside the shadow buffer (element offsets)
   int64_t setFwdA, setFwdB, setBwdA, setBwdB;  // A: fwd_operand type, B: bf16
+  int64_t setFwdLo;            // fp16 residuals W - fp16(W) of the forward matrices of layers >= cat (fwd_x2 only)
   int64_t shadowElems;
 };
 
@@ -77,7 +59,6 @@ struct SpillLayout {
   int64_t GB[MAXL];      // GB[0] = Ebar (EP/HD tensors), GB[li] = adjoint entering layer li (li >= 1)
   int64_t INJ[MAXL];     // injected second-order term of layer li
   int64_t ZB[MAXL];      // d loss / d z_li
-  int64_t S1[MAXL];      // sigma'(z_li) as unorm8, [64 pts x HD] BYTES per tile (half a tensor), "frag8" order (chain.hip)
   int64_t totalElems;
 };
 
@@ -120,7 +101,9 @@ inline int make_layout(const isdf_net_cfg* c, NetLayout* l) {
   // shares region 2 of the activation tile with hidden-width operands)
   l->EP = round_up(l->E, 256) > l->HD ? round_up(l->E, 256) : l->HD;
   l->L = 2 * c->blocks + 2; l->cat = c->blocks + 1;
+  if (c->fwd_operand < 0 || c->fwd_operand > 2) return ISDF_EINVAL;
   l->fwd_f16 = c->fwd_operand ? 1 : 0;
+  l->fwd_x2 = c->fwd_operand == 2 ? 1 : 0;
   l->has_transform = c->has_transform;
   l->scale_input = c->scale_input; l->scale_output = c->scale_output;
   for (int i = 0; i < 12; ++i) l->T[i] = c->has_transform ? c->bounds_T[i] : (i % 5 == 0 ? 1.f : 0.f);
@@ -143,7 +126,8 @@ inline int make_layout(const isdf_net_cfg* c, NetLayout* l) {
   l->bwdG = b; b += (int64_t)l->EP * 2 * l->HD;
   l->fwdSetElems = f; l->bwdSetElems = b;
   l->setFwdA = 0; l->setFwdB = f; l->setBwdA = 2 * f; l->setBwdB = 2 * f + b;
-  l->shadowElems = 2 * f + 2 * b;
+  l->setFwdLo = 2 * f + 2 * b;
+  l->shadowElems = 2 * f + 2 * b + (l->fwd_x2 ? f : 0);
   return ISDF_OK;
 }
 
@@ -177,13 +161,11 @@ __host__ __device__ inline DwUnit dw_unit(const NetLayout& l, int u) {
 
 inline void make_workspace(const NetLayout& l, int64_t maxPts, int64_t maxRays, bool train, WorkspaceLayout* w) {
   w->nTiles = (maxPts + TILE_PTS - 1) / TILE_PTS;
-  w->nTiles += w->nTiles & 1;   // even: the pair-tile kernel (chain_pair.hip) owns two tiles per workgroup
   SpillLayout& s = w->sp;
   s.tensorElems = TILE_PTS * (int64_t)l.HD;   // offsets below are WITHIN a tile's block
   int64_t o = 0;
   const int embT = l.EP / l.HD;               // HD-wide tensors per embedding-shaped operand
   for (int i = 0; i <= l.L; ++i) { s.A[i] = o; o += s.tensorElems * (i == 0 ? embT : 1); }
-  for (int i = 0; i < l.L; ++i) { s.S1[i] = o; o += s.tensorElems / 2; }
   if (train) {
     for (int i = 0; i < l.L; ++i) { s.P[i] = o; o += s.tensorElems; }
     for (int i = 0; i < l.L; ++i) { s.GB[i] = o; o += s.tensorElems * (i == 0 ? embT : 1); }
@@ -201,7 +183,7 @@ inline void make_workspace(const NetLayout& l, int64_t maxPts, int64_t maxRays, 
   w->vecStride = round_up(l.L * l.HD + 2 * l.HD + 8, 64);   // [db_0..db_{L-1} | dwout(adjoint) | dwout(reverse) | dbout]
   w->offVecPart = b; b += train ? w->nTiles * (int64_t)w->vecStride * 4 : 0; b = (b + 255) / 256 * 256;
   w->offTotLoss = b; b += train ? maxPts * 4 : 0; b = (b + 255) / 256 * 256;
-  w->totalBytes = b + 256 + 4096;   // last 4 KB: debug timeline stamps
+  w->totalBytes = b + 256 + 4096;   // last 4 KB: timeline stamps of the -DISDF_DEBUG_HOOKS=1 development build
 }
 
 // ---- device helpers ---------------------------------------------------------
@@ -237,6 +219,8 @@ template <bool F16> __device__ __forceinline__ uint2 pack4(float a, float b, flo
   v[2] = (typename Op<F16>::e)Op<F16>::clampf(c); v[3] = (typename Op<F16>::e)Op<F16>::clampf(d);
   return __builtin_bit_cast(uint2, v);
 }
+// v - fp16(v): the second operand of the compensated ("fp16x2") forward GEMMs
+__device__ __forceinline__ float f16_residual(float v) { return v - (float)(_Float16)v; }
 __device__ __forceinline__ void unpack4_bf16(uint2 u, float (&o)[4]) {
   o[0] = __uint_as_float(u.x << 16); o[1] = __uint_as_float(u.x & 0xffff0000u);
   o[2] = __uint_as_float(u.y << 16); o[3] = __uint_as_float(u.y & 0xffff0000u);

@@ -16,21 +16,13 @@ __device__ __forceinline__ float adamw_update(float* __restrict__ p, float* __re
 #pragma clang fp contract(off)
   const float gi = gsum * gs;
   float pi = p[i] * (1.f - c.lr * c.wd);
-#if ISDF_ADAM_NT
-  const float m0 = __builtin_nontemporal_load(m + i), v0 = __builtin_nontemporal_load(v + i);
-#else
-  const float m0 = m[i], v0 = v[i];
-#endif
+  const float m0 = m[i], v0 = v[i];   // (non-temporal moments measured: no change)
   const float mi = c.b1 * m0 + (1.f - c.b1) * gi;
   const float vi = c.b2 * v0 + (1.f - c.b2) * gi * gi;
   const float denom = sqrtf(vi) / c.bc2_sqrt + c.eps;
   pi -= (c.lr / c.bc1) * (mi / denom);
   p[i] = pi;
-#if ISDF_ADAM_NT
-  __builtin_nontemporal_store(mi, m + i); __builtin_nontemporal_store(vi, v + i);
-#else
   m[i] = mi; v[i] = vi;
-#endif
   return pi;
 }
 __global__ void adamw_kernel(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
@@ -102,6 +94,13 @@ __global__ void pack_kernel(NetLayout L, const float* __restrict__ P, uint16_t* 
   const uint4 hB = make_uint4(abf.x, abf.y, bbf.x, bbf.y);
   *(uint4*)(shadow + (isFwd ? L.setFwdA : L.setBwdA) + e0) = hA;
   *(uint4*)(shadow + (isFwd ? L.setFwdB : L.setBwdB) + e0) = hB;
+  if (L.fwd_x2 && isFwd && e0 >= L.fwdMat[L.cat]) {   // fp16 residuals of the compensated layers' weights
+    float r[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) r[t] = f16_residual(v[t]);
+    const uint2 al = pack4<true>(r[0], r[1], r[2], r[3]), bl = pack4<true>(r[4], r[5], r[6], r[7]);
+    *(uint4*)(shadow + L.setFwdLo + e0) = make_uint4(al.x, al.y, bl.x, bl.y);
+  }
 }
 
 // ---- loss sums + 8x8 block-loss bins ------------------------------------------
@@ -229,10 +228,12 @@ struct TailParams {
   int nW, nV;                        // blocks of the weight and the vector sections
 };
 
-__device__ __forceinline__ void shadow_put(const NetLayout& L, uint16_t* sh, bool fwdSet, int64_t elem, float val) {
+__device__ __forceinline__ void shadow_put(const NetLayout& L, uint16_t* sh, bool fwdSet, int64_t elem, float val,
+                                           bool withResidual = false) {
   const uint32_t h = pack4<true>(val, 0.f, 0.f, 0.f).x & 0xffffu, b = pack4<false>(val, 0.f, 0.f, 0.f).x & 0xffffu;
   sh[(fwdSet ? L.setFwdA : L.setBwdA) + elem] = (uint16_t)(L.fwd_f16 ? h : b);
   sh[(fwdSet ? L.setFwdB : L.setBwdB) + elem] = (uint16_t)b;
+  if (withResidual) sh[L.setFwdLo + elem] = (uint16_t)(pack4<true>(f16_residual(val), 0.f, 0.f, 0.f).x & 0xffffu);
 }
 // element offset of (row, k) inside a packed [rows/32][Kp/16][64][8] matrix (see pack_kernel)
 __device__ __forceinline__ int64_t packed_elem(int row, int k, int Kp) {
@@ -241,15 +242,8 @@ __device__ __forceinline__ int64_t packed_elem(int row, int k, int Kp) {
 
 // PHASE 0: everything (single GPU).  PHASE 1: reduction + finalisation only (isdf_train_step: the gradient
 // sums go to the all-reduce).  PHASE 2: AdamW + operand repack from an already reduced gradient (isdf_adamw).
-#ifndef ISDF_TAIL_NT_LOADS
-#define ISDF_TAIL_NT_LOADS 1   // the 66 MB of K-split slabs are read exactly once: non-temporal, so they do not evict the packed weight copies
-#endif                        // this kernel writes for the next step (measured: next chain kernel -3 %, dW -5 %, step +3.5 %)
-#ifndef ISDF_ADAM_NT
-#define ISDF_ADAM_NT 0         // 1: AdamW moments (touched once per step by this kernel only) loaded / stored non-temporally
-#endif
-#ifndef ISDF_TAIL_UNROLL
-#define ISDF_TAIL_UNROLL 36
-#endif
+// The 66 MB of K-split slabs are read exactly once: non-temporal, so they do not evict the packed weight copies this kernel
+// writes for the next step (measured: next chain kernel -3 %, dW -5 %, step +3.5 %).
 template <int PHASE>
 __global__ __launch_bounds__(1024) void step_tail_kernel(const TailParams p) {
   __shared__ FinalizeLds lds;
@@ -282,25 +276,15 @@ __global__ __launch_bounds__(1024) void step_tail_kernel(const TailParams p) {
       const slab_t* src = (const slab_t*)p.dwPart + (int64_t)unit * DW_SPLITK * perUnit + rem;
       // all K-split slabs of this element in flight at once: with 4 at a time the kernel was nine dependent HBM round
       // trips long (23-26 us for 88 MB)
-#pragma unroll ISDF_TAIL_UNROLL
-      for (int k = 0; k < DW_SPLITK; ++k) {
-#if ISDF_SLAB_BF16
-        s += __uint_as_float((uint32_t)src[(int64_t)k * perUnit] << 16);
-#else
-#if ISDF_TAIL_NT_LOADS
-        s += __builtin_nontemporal_load(src + (int64_t)k * perUnit);   // slabs are read exactly once
-#else
-        s += src[(int64_t)k * perUnit];
-#endif
-#endif
-      }
+#pragma unroll
+      for (int k = 0; k < DW_SPLITK; ++k) s += __builtin_nontemporal_load(src + (int64_t)k * perUnit);
       p.grad[pi] = s;
       if (PHASE == 1) return;
     }
     const float w = adamw_update(p.params, p.m, p.v, pi, s, gs, p.c);
     // packed operand copies (pack_kernel's sources, inverted): forward orientation ...
     const int KpF = li == 0 ? L.EP : (li == L.cat ? HD + L.EP : HD);
-    shadow_put(L, p.shadow, true, L.fwdMat[li] + packed_elem(o, col, KpF), w);
+    shadow_put(L, p.shadow, true, L.fwdMat[li] + packed_elem(o, col, KpF), w, L.fwd_x2 && li >= L.cat);
     // ... W^T restricted to the first HD inputs (layers >= 1) ...
     if (li >= 1 && col < HD) shadow_put(L, p.shadow, false, L.bwdMat[li] + packed_elem(col, o, HD), w);
     // ... and the embedding-gradient matrix [W_in^T | W_cat[:, HD:]^T]

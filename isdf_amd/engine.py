@@ -17,6 +17,7 @@ import torch
 from . import _ffi
 
 N_DIRS = 21
+FWD_OPERANDS = ("bf16", "fp16", "fp16x2")   # isdf_net_cfg.fwd_operand = index
 
 
 @dataclass
@@ -28,7 +29,10 @@ class NetConfig:
     scale_input: float = 0.05937489
     scale_output: float = 0.14
     transform: Optional[np.ndarray] = None   # 4x4 inv_bounds_transform or None
-    fwd_operand: str = "fp16"    # MFMA operand type of forward/first-backward GEMMs
+    # MFMA operand type of the forward / first-backward GEMMs (include/isdf_hip.h `fwd_operand`):
+    #   "fp16x2" (default) fp16 with the compensated forward of layers >= cat -- sdf within 1e-3 of the reference
+    #   "fp16"   plain fp16 operands (fast mode: sdf 0.9e-3 .. 1.5e-3 at BASELINE size);  "bf16" plain bf16 (1.1e-2)
+    fwd_operand: str = "fp16x2"
 
     @property
     def emb(self):
@@ -57,9 +61,9 @@ class NetConfig:
         T = np.eye(4, dtype=np.float32) if self.transform is None else np.asarray(self.transform, np.float32)
         for i in range(12):
             c.bounds_T[i] = float(T[i // 4, i % 4])
-        if self.fwd_operand not in ("fp16", "bf16"):
-            raise ValueError("fwd_operand must be 'fp16' or 'bf16'")
-        c.fwd_operand = 1 if self.fwd_operand == "fp16" else 0
+        if self.fwd_operand not in FWD_OPERANDS:
+            raise ValueError("fwd_operand must be one of %s" % (FWD_OPERANDS,))
+        c.fwd_operand = FWD_OPERANDS.index(self.fwd_operand)
         return c
 
 

@@ -483,7 +483,7 @@ UNSUPPORTED_HINT = ("isdf_amd hot path: %s (the reference's own Python path is t
                     "this build ships no second implementation)")
 
 
-def graft(trainer, rng="philox", seed=1, dist_group=None, fix_normal_window=False, fwd_operand="fp16",
+def graft(trainer, rng="philox", seed=1, dist_group=None, fix_normal_window=False, fwd_operand="fp16x2",
           fuse_optimiser=True, virtual_step_ms=None, engine_factory=None):
     """Re-bind the hot path of `trainer` (an `isdf.modules.trainer.Trainer` or a `StandinTrainer`) to the HIP
     kernels, IN PLACE, and return it.

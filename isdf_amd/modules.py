@@ -35,7 +35,7 @@ def _fc_block(in_f, out_f):
 
 class SDFMapHIP(nn.Module):
     def __init__(self, positional_encoding, hidden_size=256, hidden_layers_block=1, scale_output=1.0,
-                 device="cuda", fwd_operand="fp16", engine_factory=None):
+                 device="cuda", fwd_operand="fp16x2", engine_factory=None):
         super().__init__()
         object.__setattr__(self, "_engine_factory", engine_factory)
         self.scale_output = scale_output

@@ -101,7 +101,7 @@ class FrameData:
 
 class StandinTrainer:
     def __init__(self, device, config_file, chkpt_load_file=None, incremental=True, grid_dim=200, *,
-                 inv_bounds_transform=None, fwd_operand="fp16", engine_factory=None):
+                 inv_bounds_transform=None, fwd_operand="fp16x2", engine_factory=None):
         """Positional signature of the reference constructor (trainer.py:35-42).  config_file: path to / dict
         with the reference's JSON schema.  The reference derives `inv_bounds_transform` from the GT mesh
         (trainer.py:76-87, 102-123); with no mesh IO here it is an argument (None = live modes)."""

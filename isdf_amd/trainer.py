@@ -20,7 +20,7 @@ from .standin import FrameData, StandinTrainer                   # noqa: F401
 
 class HipTrainer(HotPath, StandinTrainer):
     def __init__(self, device, config, incremental=True, inv_bounds_transform=None, rng="philox",
-                 seed=1, dist_group=None, fix_normal_window=False, fwd_operand="fp16", virtual_step_ms=None,
+                 seed=1, dist_group=None, fix_normal_window=False, fwd_operand="fp16x2", virtual_step_ms=None,
                  engine_factory=None):
         """config: path to / dict with the reference's JSON schema (replicaCAD.json).
         rng: "philox" (in-kernel, no host sync) or "torch" (draw with torch in the

@@ -20,13 +20,22 @@ def bf16(x):
 
 
 def forward(params, cfg, x, operand="fp16"):
-    q = f16 if operand == "fp16" else bf16
+    """operand "fp16x2": the compensated forward (isdf_amd/csrc/chain.hip, OPER 2) -- layers >= cat add W_lo x, the
+    layers past the cat layer also W x_lo (W_lo = fp16(W - fp16(W)), x_lo = fp16(x - fp16(x)))."""
+    x2 = operand == "fp16x2"
+    q = bf16 if operand == "bf16" else f16
     x = np.asarray(x, np.float32).reshape(-1, 3)
     e = q(orc.positional_encoding(x, cfg.transform, cfg.scale_input, cfg.n_freqs))
     a = e
     for li, n in enumerate(cfg.names):
         inp = np.concatenate([a, e], -1) if li == cfg.cat else a
-        z = inp @ q(params[n + ".weight"]).T + params[n + ".bias"]
+        W = params[n + ".weight"]
+        z = inp @ q(W).T
+        if x2 and li >= cfg.cat:
+            z = z + inp @ f16(W - f16(W)).T
+            if li > cfg.cat:
+                z = z + f16(af - a) @ f16(W).T
+        z = z + params[n + ".bias"]
         af = orc.softplus(z)
         a = q(af)
     raw = af @ params["out_alpha.weight"][0] + params["out_alpha.bias"][0]

@@ -43,7 +43,12 @@ def test_size_queries_default_net(lib):
     sh = lib.isdf_shadow_bytes(C.byref(c))
     fwd = 256 * 256 + 4 * 256 * 256 + 256 * 512
     bwd = 5 * 256 * 256 + 256 * 512
-    assert sh == 2 * (2 * fwd + 2 * bwd)
+    assert sh == 2 * (3 * fwd + 2 * bwd)      # default "fp16x2": + one forward set of fp16 weight residuals
+    for op, sets in (("fp16", 2), ("bf16", 2)):
+        assert lib.isdf_shadow_bytes(C.byref(NetConfig(fwd_operand=op).to_c())) == 2 * (sets * fwd + 2 * bwd)
+    bad = NetConfig().to_c()
+    bad.fwd_operand = 3
+    assert lib.isdf_shadow_bytes(C.byref(bad)) == -1
     assert lib.isdf_workspace_bytes(C.byref(c), 27000, 1) > lib.isdf_workspace_bytes(C.byref(c), 27000, 0) > 0
 
 

@@ -4,8 +4,9 @@ reference-generated golden fixtures.  Needs a real MI355X: `pytest -m gpu`.
 Tolerances (BASELINE.json north_star / SURVEY 8c):
   * sample indices, validity, compaction order: BIT-EXACT
   * z_vals / pc: <= 1e-6 / 4e-6 abs (fp32 re-association only)
-  * sdf outputs and every loss term: <= 1e-3 relative
-  * sdf_grad: <= 5e-3 relative (fp16 operands; measured ~2e-3)
+  * sdf outputs and every loss term: <= 1e-3 relative (default operand mode "fp16x2": compensated forward)
+  * sdf_grad: <= 2e-3 relative at BASELINE size (measured ~1.3e-3: forward error of layers 0-2 and the fp16 first reverse
+    sweep; SURVEY 8c asks 1e-3); small batches are judged on the scale of a unit gradient
   * weight gradients: cosine >= 0.999 and <= 1e-2 rel-L2 per tensor
   * AdamW update given identical gradients: <= 1e-6
 """
@@ -20,11 +21,11 @@ pytestmark = pytest.mark.gpu
 
 TOL_SDF = 1e-3
 TOL_LOSS = 1e-3
-TOL_SDF_GRAD = 5e-3
+TOL_SDF_GRAD = 2e-3
 TOL_DW = 1e-2
 
 
-def _engine(g, fwd_operand="fp16"):
+def _engine(g, fwd_operand="fp16x2"):
     from isdf_amd.engine import Engine, NetConfig
     H, B, nf, si, so = g["net"]
     has_T = int(g["has_transform"][0]) if "has_transform" in g else 1
@@ -97,7 +98,7 @@ def test_sampler_bit_exact_vs_reference_fixture():
     np.testing.assert_allclose(s["pc"][:R].cpu().numpy(), g["pc"], rtol=0, atol=4e-6)
 
 
-@pytest.mark.parametrize("fwd_operand,tol", [("fp16", TOL_SDF), ("bf16", 8e-3)])
+@pytest.mark.parametrize("fwd_operand,tol", [("fp16x2", TOL_SDF), ("fp16", TOL_SDF), ("bf16", 8e-3)])
 def test_forward_sdf(fwd_operand, tol):
     g = gu.load("eval_full_ray")
     eng = _engine(g, fwd_operand)
@@ -135,7 +136,7 @@ def test_input_gradient_vs_reference_fixture():
     assert gu.rel_err(sdf.cpu().numpy(), g["sdf_nonoise"].reshape(-1)) < TOL_SDF
 
 
-def _run_step(g, bounds_method=None, loss_type=None, fwd_operand="fp16", oracle=True, identity_transform=False,
+def _run_step(g, bounds_method=None, loss_type=None, fwd_operand="fp16x2", oracle=True, identity_transform=False,
               with_normals=None, **loss_over):
     """HIP sampler (injected draws) + training step on a fixture, and the oracle on the same inputs.
     loss_over: LossConfig fields to override on both sides (orien_loss=True, eik_weight=0.0, ...)."""
@@ -679,46 +680,47 @@ def test_base_size_sampler_bit_exact_vs_reference(case):
     np.testing.assert_allclose(s["pc"][:R].cpu().numpy(), g["pc"], rtol=0, atol=4e-6)
 
 
-# fp16-operand floor of the forward pass at BASELINE size, measured with the numpy model of the kernel's numerics
-# (tests/precision_model.py; dominated by the rounding of the WEIGHTS of the last three hidden layers, which is a
-# per-network bias rather than per-point noise): rel-L2 vs the reference 1.48e-3 (680x1200 fixture, seed 41),
-# 9.4e-4 (480x640, seed 42), 8.7e-4 (eval_full_ray).  The north-star's 1e-3 is therefore met on two of the three
-# reference fixtures and missed by 1.5x on the third; plain bf16 operands (what the north star names) sit at 1.1e-2.
-TOL_SDF_BASE = 2e-3
+# sdf at BASELINE size vs the REFERENCE (north star: 1e-3).  Default operand mode "fp16x2" (compensated forward of layers
+# >= cat, isdf_amd/csrc/chain.hip OPER 2): numpy model of its numerics 5.4e-4 / 4.9e-4 / 4.8e-4 on the three reference
+# fixtures.  The plain-fp16 fast mode sits on its operand floor (model: 1.48e-3 / 9.4e-4 / 8.7e-4, dominated by the
+# rounding of the weights and inputs of the last three hidden layers): it is checked against the MODEL and not held to
+# the north star; FAST_MODE_SDF_FLOOR only bounds it from above so a regression would show.
+FAST_MODE_SDF_FLOOR = 2e-3
 
 
-@pytest.mark.parametrize("case", BASE_CASES)
-def test_base_size_forward_and_input_gradient_vs_reference(case):
+@pytest.mark.parametrize("fwd_operand", ["fp16x2", "fp16"])
+@pytest.mark.parametrize("case", BASE_CASES + ["eval_full_ray"])
+def test_base_size_forward_and_input_gradient_vs_reference(case, fwd_operand):
     from tests import precision_model as pm
     g = gu.load(case)
-    eng = _engine(g)
+    eng = _engine(g, fwd_operand)
     x = g["pc"].reshape(-1, 3)
-    assert x.shape[0] > 25000
+    assert x.shape[0] > 25000 or case == "eval_full_ray"
     sdf, grad = eng.sdf_eval(_dev(x), want_grad=True)
     sdf, grad = sdf.cpu().numpy(), grad.cpu().numpy()
     ref = g["sdf_nonoise"].reshape(-1)
     err = gu.rel_err(sdf, ref)
+    gerr = gu.rel_err(grad, g["sdf_grad"].reshape(-1, 3))
     # (1) the kernel computes what its design says: against the numpy model of its numerics (same operand rounding)
-    model = pm.forward(gu.params_of(g), gu.net_of(g), x, "fp16")
+    model = pm.forward(gu.params_of(g), gu.net_of(g), x, fwd_operand)
     err_model = gu.rel_err(sdf, model)
     floor = gu.rel_err(model, ref)
-    print("%s: sdf rel-L2 vs reference %.3e, vs fp16-operand model %.3e, model vs reference %.3e" % (case, err, err_model, floor))
+    print("%s %s: sdf rel-L2 vs reference %.3e, vs operand model %.3e, model vs reference %.3e; d sdf/dx %.3e"
+          % (case, fwd_operand, err, err_model, floor, gerr))
     assert err_model < 6e-4, err_model   # accumulation order, v_sin/v_exp/v_log approximations, fp16 subnormal operands
-    # (2) against the REFERENCE: the operand-rounding floor documented above
-    assert err < TOL_SDF_BASE, err
+    # (2) against the REFERENCE
+    assert err < (TOL_SDF if fwd_operand == "fp16x2" else FAST_MODE_SDF_FLOOR), err
     assert _scaled_err(sdf, ref, 0.14) < TOL_SDF          # max error on the scale of the network output
-    assert gu.rel_err(grad, g["sdf_grad"].reshape(-1, 3)) < TOL_SDF_GRAD
+    assert gerr < (TOL_SDF_GRAD if fwd_operand == "fp16x2" else 2.5e-3), gerr
 
 
-@pytest.mark.parametrize("pair", [False, True], ids=["tile", "pair"])
+@pytest.mark.parametrize("fwd_operand", ["fp16x2", "fp16"])
 @pytest.mark.parametrize("case,src", [("eval_base_680x1200_ray", None), ("eval_base_480x640_ray", None),
                                       ("eval_base_680x1200_pc", "eval_base_680x1200_ray")])
-def test_base_size_train_step_vs_reference_and_oracle(case, src, pair, monkeypatch):
-    """(pair: the same through the opt-in pair-tile kernel, csrc/chain_pair.hip, ISDF_CHAIN_PAIR=1.)
-    The training step at BASELINE size -- where the 422-tile grid, the 36 K-splits of the dW kernel and the
+def test_base_size_train_step_vs_reference_and_oracle(case, src, fwd_operand):
+    """The training step at BASELINE size -- where the 422-tile grid, the 36 K-splits of the dW kernel and the
     680x1200 bin geometry are exercised -- against what the REAL reference produced (four loss means, per-frame
     block averages, norm / probe / head digests of all 14 gradients) and against the oracle tensor by tensor."""
-    monkeypatch.setenv("ISDF_CHAIN_PAIR", "1" if pair else "0")   # read by launch_chain at every launch
     g = gu.load(case)
     if src is not None:                                  # slim fixture: same seed and draws as its sibling
         full = gu.load(src)
@@ -726,7 +728,7 @@ def test_base_size_train_step_vs_reference_and_oracle(case, src, pair, monkeypat
             assert np.array_equal(g[k], full[k]), k
         for k in ("norm_sample",):
             g[k] = full[k]
-    eng, s, dbg, terms, grads, R = _run_step(g)
+    eng, s, dbg, terms, grads, R = _run_step(g, fwd_operand=fwd_operand)
     S = s["S"]
     N = R * S
     assert N > 25000
@@ -736,7 +738,7 @@ def test_base_size_train_step_vs_reference_and_oracle(case, src, pair, monkeypat
     la, fa = eng.frame_avg(5)
     np.testing.assert_allclose(fa.cpu().numpy(), g["frame_avg_loss"], rtol=5e-3, atol=1e-6)
     np.testing.assert_allclose(la.cpu().numpy(), g["loss_approx"], rtol=2e-2, atol=1e-5)
-    assert gu.rel_err(dbg["sdf_grad"][:R].cpu().numpy(), terms["sdf_grad"]) < TOL_SDF_GRAD
+    assert gu.rel_err(dbg["sdf_grad"][:R].cpu().numpy(), terms["sdf_grad"]) < (TOL_SDF_GRAD if fwd_operand == "fp16x2" else 2.5e-3)
     assert gu.rel_err(dbg["tot_loss_mat"][:R].cpu().numpy(), terms["tot_loss_mat"]) < 5e-3
     _check_grads_vs_reference_digest(eng, N, g)
     _check_grads_vs_oracle(eng, N, grads)
@@ -772,16 +774,14 @@ def _replay_hip_steps(g, eng, lc, sc, n_steps, fused):
     return out
 
 
-@pytest.mark.parametrize("pair", [False, True], ids=["tile", "pair"])
 @pytest.mark.parametrize("fused", [False, True])
-def test_hip_step_x3_default_net_vs_reference_fixture(fused, pair, monkeypatch):
+def test_hip_step_x3_default_net_vs_reference_fixture(fused):
     """`step_full_k7`: the unmodified reference `Trainer.step` x3 with the DEFAULT 6x256 net and K=7 > window
     (select_keyframes windows, quirk q4).  HIP path on the same windows and draws: per-step losses and
     frame_avg_losses vs the reference, the AdamW moments tensor by tensor vs the oracle trajectory (exp_avg is
     linear in the gradients: 1e-2; exp_avg_sq quadratic: 2e-2), and the reference's digests of the parameter
     update and both moments."""
     from tests.test_oracle_golden import replay_step_fixture, check_step_digests
-    monkeypatch.setenv("ISDF_CHAIN_PAIR", "1" if pair else "0")   # pair: the opt-in pair-tile kernel (chain_pair.hip)
     g = gu.load("step_full_k7")
     eng = _engine(g)
     lc, sc = _cfgs(g)
@@ -816,7 +816,9 @@ def test_hip_step_x3_default_net_vs_reference_fixture(fused, pair, monkeypatch):
         hip_v[k] = eng.exp_avg_sq[off:off + cnt].view(*shp).cpu().numpy()
         assert gu.rel_err(hip_m[k], state["exp_avg"][k]) < TOL_DW, (k, gu.rel_err(hip_m[k], state["exp_avg"][k]))
         assert gu.rel_err(hip_v[k], state["exp_avg_sq"][k]) < 2 * TOL_DW, (k, gu.rel_err(hip_v[k], state["exp_avg_sq"][k]))
-    # ... and the reference's own digests (the parameter UPDATE is ~lr*sign(g) this early: judged loosely)
+    # ... and the reference's own digests of both moments.  The digest of the parameter UPDATE is only a sanity bound
+    # (15 %): three steps in, the update is ~lr*sign(g) per element, i.e. decided by the SIGN of near-zero gradients; the
+    # moments above and here carry the trajectory check.
     check_step_digests(g, hip_p, init, hip_m, hip_v, 0.15, TOL_DW, 2 * TOL_DW)
 
 
@@ -870,9 +872,9 @@ def test_realsense_config_nets_match_oracle(blocks, n_freqs, E):
     x = g["pc"].reshape(-1, 3)
     sdf, grad = eng.sdf_eval(_dev(x), want_grad=True)
     ref, refg = orc.sdf_forward_grad(params, cfg, x)
-    err, err_model = gu.rel_err(sdf.cpu().numpy(), ref), gu.rel_err(sdf.cpu().numpy(), pm.forward(params, cfg, x, "fp16"))
-    print("realsense net (blocks %d, n_freqs %d): sdf rel-L2 vs oracle %.3e, vs fp16-operand model %.3e" % (blocks, n_freqs, err, err_model))
-    assert err_model < 6e-4 and err < TOL_SDF_BASE, (err, err_model)      # fp16-operand floor, see TOL_SDF_BASE
+    err, err_model = gu.rel_err(sdf.cpu().numpy(), ref), gu.rel_err(sdf.cpu().numpy(), pm.forward(params, cfg, x, "fp16x2"))
+    print("realsense net (blocks %d, n_freqs %d): sdf rel-L2 vs oracle %.3e, vs operand model %.3e" % (blocks, n_freqs, err, err_model))
+    assert err_model < 6e-4 and err < TOL_SDF, (err, err_model)
     assert gu.rel_err(grad.cpu().numpy(), refg) < TOL_SDF_GRAD, gu.rel_err(grad.cpu().numpy(), refg)
     lc, sc = _cfgs(g)
     s_ = _sample_hip(eng, g, sc)
@@ -1048,54 +1050,3 @@ def test_sampler_ray_count_sweep(F, n):
             near = torch.clamp(ds[ok][:, None] + N_off[:R], min=sc.min_depth)
             near = torch.minimum(near, (ds[ok] + sc.dist_behind_surf)[:, None])
             assert torch.equal(s["z_vals"][:R, 0], ds[ok]) and torch.allclose(s["z_vals"][:R, 1:sc.n_surf], near, rtol=0, atol=1e-6)
-
-
-# ---- the opt-in pair-tile chain kernel (csrc/chain_pair.hip, ISDF_CHAIN_PAIR=1): same formats, same results ----------
-def test_pair_kernel_equals_single_tile_kernel(monkeypatch):
-    """Even tiles (first half of a pair) are bit-identical to the one-tile kernel up to the loss stage; every gradient
-    tensor agrees to fp32 re-association + bf16 flips (1e-3), and the pair kernel is deterministic."""
-    g = gu.load("eval_base_680x1200_ray")
-    monkeypatch.setenv("ISDF_CHAIN_PAIR", "0")
-    eng, s, dbg, _, _, R = _run_step(g, oracle=False)
-    ref_grad, ref_sdf = eng.reduce_buf.clone(), dbg["sdf"].clone()
-    monkeypatch.setenv("ISDF_CHAIN_PAIR", "1")
-    outs = []
-    for _ in range(2):
-        eng2, s2, dbg2, _, _, R2 = _run_step(g, oracle=False)
-        outs.append((eng2.reduce_buf.clone(), dbg2["sdf"].clone()))
-    assert R2 == R
-    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])   # deterministic
-    S = g["z_vals"].shape[1]
-    sdf1, sdf2 = ref_sdf[:R].reshape(-1), outs[0][1][:R].reshape(-1)
-    even = (torch.arange(R * S, device=sdf1.device) // 64) % 2 == 0
-    assert torch.equal(sdf1[even], sdf2[even])                       # first halves: same k order, same bits
-    assert gu.rel_err(sdf2.cpu().numpy(), sdf1.cpu().numpy()) < 1e-6   # second halves too (same k order)
-    for k, (off, shp) in eng.slices.items():
-        n = int(np.prod(shp))
-        a, b = ref_grad[off:off + n].cpu().numpy(), outs[0][0][off:off + n].cpu().numpy()
-        assert gu.rel_err(b, a) < 1e-3, k
-
-
-def test_pair_kernel_ragged_sizes(monkeypatch):
-    """1 .. 26 rays per keyframe x 5 keyframes x 27 points (1 .. 55 tiles, odd and even counts, a lone first half, a
-    partial last tile): loss sums, point count and all gradients of the pair kernel against the one-tile kernel."""
-    import dataclasses
-    g = gu.load("eval_base_680x1200_ray")
-    eng = _engine(g)
-    lc, sc = _cfgs(g)
-    d, T, n = _dev(g["depth_batch"]), _dev(g["T_WC_batch"]), _dev(g["normal_batch"])
-    idx = torch.arange(d.shape[0], dtype=torch.int32, device="cuda")
-    for nr in (1, 2, 3, 5, 13, 26):
-        sc2 = dataclasses.replace(sc, n_rays=nr)
-        s = eng.sample(d, T, n, idx, idx, sc2, seed=3, offset=nr)
-        monkeypatch.setenv("ISDF_CHAIN_PAIR", "0")
-        eng.train_step(s, lc, sc2)
-        a = eng.reduce_buf.clone()
-        monkeypatch.setenv("ISDF_CHAIN_PAIR", "1")
-        eng.train_step(s, lc, sc2)
-        b = eng.reduce_buf.clone()
-        torch.cuda.synchronize()
-        np_ = eng.n_params
-        assert a[np_ + 4].item() > 0 and torch.equal(a[np_ + 4], b[np_ + 4])                  # same point count
-        assert gu.rel_err(b[np_:np_ + 4].cpu().numpy(), a[np_:np_ + 4].cpu().numpy()) < 1e-5, nr
-        assert gu.rel_err(b[:np_].cpu().numpy(), a[:np_].cpu().numpy()) < 2e-3, nr
