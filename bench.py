@@ -126,6 +126,34 @@ def cpu_baseline(depth, normal, T, cam, cfg, budget_s=12.0):
             "as_shipped_sample": "%d steps in %.1f s, denormals not flushed" % out["as_shipped"][1:]}
 
 
+def gpu_eager_baseline(depth, normal, T, cam, cfg, device, budget_s=8.0):
+    """SURVEY 8d's informative second baseline: the reference's op chain as PyTorch-ROCm EAGER ops + autograd on this
+    MI355X (oracle/torch_port.py on device "cuda": what the unmodified reference does when handed a HIP device), same
+    27k-point workload, device-synchronised per step as metrics.start_timing/end_timing do.  Not the target."""
+    from oracle import torch_port as tp
+    sc = dict(n_rays=cfg["sample"]["n_rays"], n_strat=19, n_surf=8, min_depth=0.07, dist_behind_surf=0.1)
+    lc = dict(trunc_distance=cfg["loss"]["trunc_distance"], loss_type="L1", trunc_weight=cfg["loss"]["trunc_weight"],
+              eik_apply_dist=0.1, eik_weight=cfg["loss"]["eik_weight"], grad_weight=cfg["loss"]["grad_weight"])
+    d, n, Tt = (torch.from_numpy(a).to(device) for a in (depth, normal, T))
+    torch.manual_seed(1)
+    net = tp.PortNet(256, 2, 6, 0.05937489, 0.14, None).to(device)
+    opt = torch.optim.AdamW(net.parameters(), lr=0.0013, weight_decay=0.012)
+    gen = torch.Generator().manual_seed(1)
+    for _ in range(5):
+        tp.train_step(net, opt, d, Tt, n, cam, sc, lc, 0.25, gen)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter(); k = 0
+    while True:
+        tp.train_step(net, opt, d, Tt, n, cam, sc, lc, 0.25, gen)
+        torch.cuda.synchronize(); k += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or k >= 300:
+            break
+    return {"value": round(k / el, 2), "unit": "train-steps/s", "kind": "port on device", "device": torch.cuda.get_device_name(device),
+            "sample": "%d device-synchronised steps of the same 27k-point workload in %.1f s, torch %s eager + autograd "
+                      "(fp32), the reference's op chain (oracle/torch_port.py)" % (k, el, torch.__version__)}
+
+
 def sampler_scale(args, tr, eng, cam, rank):
     """The sampler as a streaming kernel: 5 x RAYS_PER_FRAME rays per launch (in-kernel Philox draws), HIP-event timed.
     Algorithmic bytes per ray: 16 read (depth 4 + normal 12) + 496 written (pc 324, z_vals 108,
@@ -460,6 +488,10 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(depth, normal, T, cam, cfg)
             res["speedup_vs_cpu_baseline"] = round(res["value"] / res["cpu_baseline"]["value"], 1)
+            try:      # informative second baseline: the same op chain as eager PyTorch-ROCm on this GPU
+                res["gpu_eager_baseline"] = gpu_eager_baseline(depth, normal, T, cam, cfg, dev)
+            except Exception as e:   # never lose the bench line to the baseline
+                res["gpu_eager_baseline"] = {"error": repr(e)[:200]}
     if group is not None:
         torch.distributed.destroy_process_group()
     try:      # RCCL prints its version banner through C stdio, which is flushed at exit when stdout is a pipe:

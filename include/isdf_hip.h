@@ -240,6 +240,16 @@ int isdf_train_step_adamw(const isdf_net_cfg* net, const isdf_loss_cfg* loss, co
                           const isdf_step_out* o, const isdf_optim_args* opt, void* workspace,
                           int64_t workspace_bytes, void* stream);
 
+/* Second half of the DATA-PARALLEL step: after isdf_train_step has written this rank's SUMS to reduce_buf
+ * and ONE all-reduce(sum) over reduce_buf has made them global, this single launch does what
+ * `self.optimiser.step()` and `self.frames.frame_avg_losses[idxs] = frame_avg_loss` do upstream (trainer.py:979-982):
+ * AdamW on gradient = grad_sum * grad_scale / reduced count, refresh of the packed operand copies, and (when
+ * opt->loss_approx / opt->frame_avg are given) loss.frame_avg (loss.py:208-240) from the reduced bins.
+ * isdf_train_step + all-reduce + isdf_train_step_finish == isdf_train_step_adamw on the union batch
+ * (tests/test_dp_gpu.py).                                                                                          */
+int isdf_train_step_finish(const isdf_net_cfg* net, const isdf_optim_args* opt, const float* reduce_buf,
+                           int32_t n_frames, void* stream);
+
 /* nearest-surface-point bounds (bounds_method "pc", loss.py:56-89): for every sample point the distance to
  * the nearest SURFACE sample (sign from z vs depth) and the unit vector from it.  surf_pts == NULL: the
  * surface set is this batch's own pc[:, 0, :] (what the single-process reference uses, loss.py:58-61).

@@ -17,7 +17,7 @@ ABI_VERSION = 4
 SYMBOLS = [
     "isdf_abi_version", "isdf_error_string", "isdf_check_net", "isdf_param_count", "isdf_shadow_bytes",
     "isdf_workspace_bytes", "isdf_reduce_floats", "isdf_sample_scan_bytes", "isdf_pack_weights", "isdf_sample_rays",
-    "isdf_sdf_eval", "isdf_train_step", "isdf_train_step_adamw", "isdf_bounds_pc",
+    "isdf_sdf_eval", "isdf_train_step", "isdf_train_step_adamw", "isdf_train_step_finish", "isdf_bounds_pc",
     "isdf_frame_avg", "isdf_adamw", "isdf_estimate_normals", "isdf_render_depth",
 ]
 
@@ -116,6 +116,7 @@ def lib():
     L.isdf_sdf_eval.argtypes = [P(NetCfg), vp, vp, vp, i64, vp, vp, vp, vp, i64, vp]
     L.isdf_train_step.argtypes = [P(NetCfg), P(LossCfg), vp, vp, P(StepArgs), P(StepOut), vp, i64, vp]
     L.isdf_train_step_adamw.argtypes = [P(NetCfg), P(LossCfg), P(StepArgs), P(StepOut), P(OptimArgs), vp, i64, vp]
+    L.isdf_train_step_finish.argtypes = [P(NetCfg), P(OptimArgs), vp, i32, vp]
     L.isdf_bounds_pc.argtypes = [vp, i32, i32, vp, vp, vp, vp, i64, vp, vp, vp]
     L.isdf_frame_avg.argtypes = [vp, i64, i32, vp, vp, vp, vp]
     L.isdf_adamw.argtypes = [P(NetCfg), vp, vp, vp, vp, vp, f32, f32, f32, f32, f32, f32, i32, vp, vp]

@@ -17,7 +17,8 @@ int launch_adamw(float* p, float* m, float* v, const float* g, const float* cnt,
 int launch_pack(const NetLayout& L, const float* params, uint16_t* shadow, hipStream_t st);
 int launch_adamw_pack(const NetLayout& L, float* params, float* m, float* v, uint16_t* shadow, const float* grad,
                       const float* count_ptr, float grad_scale, float lr, float b1, float b2, float eps, float wd,
-                      int step, hipStream_t st);
+                      int step, hipStream_t st, int n_frames = 0, const float* bl = nullptr, const float* bc = nullptr,
+                      float* la = nullptr, float* fa = nullptr, const int32_t* fa_index = nullptr);
 int launch_step_tail(int phase, const NetLayout& L, const float* dwPart, const float* vecPart, int vecStride, float* grad,
                      float* params, float* m, float* v, uint16_t* shadow, float grad_scale, float lr, float b1, float b2,
                      float eps, float wd, int step, const float* wg_loss, int64_t maxTiles, const int32_t* n_valid, int S,
@@ -218,6 +219,24 @@ int isdf_train_step_adamw(const isdf_net_cfg* net, const isdf_loss_cfg* loss, co
   if (!opt || !opt->params || !opt->exp_avg || !opt->exp_avg_sq || !opt->shadow || opt->step < 1) return ISDF_EINVAL;
   if ((opt->loss_approx == nullptr) != (opt->frame_avg == nullptr)) return ISDF_EINVAL;   // both or neither
   return train_step_impl(net, loss, opt->params, opt->shadow, a, o, workspace, workspace_bytes, stream, opt);
+}
+
+int isdf_train_step_finish(const isdf_net_cfg* net, const isdf_optim_args* opt, const float* reduce_buf, int32_t n_frames,
+                           void* stream) {
+  isdf_clear_stale_hip_error();
+  NetLayout l; int rc = make_layout(net, &l);
+  if (rc) return rc;
+  if (!layout_supported(l)) return ISDF_EUNSUPPORTED;
+  if (!opt || !opt->params || !opt->exp_avg || !opt->exp_avg_sq || !opt->shadow || opt->step < 1 || !reduce_buf) return ISDF_EINVAL;
+  if ((opt->loss_approx == nullptr) != (opt->frame_avg == nullptr)) return ISDF_EINVAL;   // both or neither
+  if (opt->loss_approx && n_frames < 1) return ISDF_EINVAL;
+  const float* lossSums = reduce_buf + l.n_params;
+  const float* bl = lossSums + 8;
+  const int F = opt->loss_approx ? n_frames : 0;
+  return launch_adamw_pack(l, opt->params, opt->exp_avg, opt->exp_avg_sq, (uint16_t*)opt->shadow, reduce_buf,
+                           lossSums + ISDF_LS_COUNT, opt->grad_scale, opt->lr, opt->beta1, opt->beta2, opt->eps,
+                           opt->weight_decay, opt->step, (hipStream_t)stream, F, bl, bl + (int64_t)n_frames * 64,
+                           opt->loss_approx, opt->frame_avg, opt->frame_avg_index);
 }
 
 int isdf_bounds_pc(const int32_t* n_valid, int32_t max_rays, int32_t S, const float* pc, const float* z_vals,

@@ -375,14 +375,20 @@ __global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 && EP == HD ? 4 : 2)) voi
   for (int li = 0; li < L.L; ++li) {
     refresh();
     zero_acc(acc);
-    // compensated layers (OPER 2): the cat layer adds W_lo [a | emb]; the layers past it W_lo a and W a_lo (a_lo sits in
-    // region 2, which the forward pass no longer needs once the cat layer has consumed the embedding)
+    // compensated layers (OPER 2): the cat layer adds W_lo[:, HD:] emb (the residual of its embedding columns; the one of
+    // its hidden columns moves sdf by 3e-5 and is skipped), the layers past it W_lo a and W a_lo (a_lo sits in region 2,
+    // which the forward pass no longer needs once the cat layer has consumed the embedding).  Numpy model of these
+    // numerics vs the reference at BASELINE size: tests/precision_model.py, tools/studies/split_precision_study.py.
     const bool comp = X2 && li >= L.cat;
     if (li == 0)
       gemm<F16, EP / 16, FB, PB, ROWB, T::CKF>(acc, wq, rsW, fwdW(setFwdA, li), X, HD * 2, lane, [] {});
     else if (li == L.cat) {
       gemm<F16, (HD + EP) / 16, FB, PB, ROWB, T::CKF>(acc, wq, rsW, fwdW(setFwdA, li), X, 0, lane, [] {});
-      if (comp) gemm<F16, (HD + EP) / 16, FB, PB, ROWB, T::CKF>(acc, wq, rsW, fwdW(setFwdLo, li), X, 0, lane, [] {});
+      if (comp) {
+        WRef wl = fwdW(setFwdLo, li);
+        wl.soff += (HD / 16) * 1024;   // k-steps HD/16 .. of every row block: the embedding columns
+        gemm<F16, EP / 16, FB, PB, ROWB, T::CKF>(acc, wq, rsW, wl, X, HD * 2, lane, [] {});
+      }
     } else {
       gemm<F16, HD / 16, FB, PB, ROWB, T::CKF>(acc, wq, rsW, fwdW(setFwdA, li), X, 0, lane, [] {});
       if (comp) {

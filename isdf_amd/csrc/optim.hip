@@ -244,13 +244,31 @@ __device__ __forceinline__ int64_t packed_elem(int row, int k, int Kp) {
 // sums go to the all-reduce).  PHASE 2: AdamW + operand repack from an already reduced gradient (isdf_adamw).
 // The 66 MB of K-split slabs are read exactly once: non-temporal, so they do not evict the packed weight copies this kernel
 // writes for the next step (measured: next chain kernel -3 %, dW -5 %, step +3.5 %).
+// loss.frame_avg (loss.py:208-240) of frame f from the (all-reduced) bins: 64 threads, one per 8x8 block
+__device__ __forceinline__ void frame_avg_block(int f, int t, const float* __restrict__ block_loss,
+                                                const float* __restrict__ block_cnt, float* __restrict__ loss_approx,
+                                                float* __restrict__ frame_avg, const int32_t* __restrict__ fa_index) {
+  if (t >= 64) return;
+  float c = block_cnt[f * 64 + t];
+  c = c == 0.f ? 1.f : c;                      // loss.py:215
+  float v = block_loss[f * 64 + t] / c;
+  loss_approx[f * 64 + t] = v;
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  if (t == 0) frame_avg[fa_index ? fa_index[f] : f] = v / 64.f;         // loss.py:236-238
+}
+
 template <int PHASE>
 __global__ __launch_bounds__(1024) void step_tail_kernel(const TailParams p) {
   __shared__ FinalizeLds lds;
   const NetLayout& L = p.lay;
   const int HD = L.HD;
   const int b = blockIdx.x;
-  if (b >= p.nW + p.nV) { if (PHASE != 2) finalize_block(b - p.nW - p.nV, p.fin, lds); return; }
+  if (b >= p.nW + p.nV) {
+    if (PHASE != 2) finalize_block(b - p.nW - p.nV, p.fin, lds);
+    else frame_avg_block(b - p.nW - p.nV, threadIdx.x, p.fin.block_loss, p.fin.block_cnt, p.fin.la_out, p.fin.fa_out, p.fin.fa_index);
+    return;
+  }
   const int64_t P = PHASE == 2 ? 0 : (int64_t)(*p.fin.n_valid) * p.fin.S;
   float gs = p.grad_scale;
   if (PHASE == 0) gs /= (float)P;
@@ -353,14 +371,7 @@ __global__ __launch_bounds__(1024) void step_tail_kernel(const TailParams p) {
 __global__ void frame_avg_kernel(const float* __restrict__ block_loss, const float* __restrict__ block_cnt,
                                  int n_frames, float* __restrict__ loss_approx, float* __restrict__ frame_avg,
                                  const int32_t* __restrict__ fa_index) {
-  const int f = blockIdx.x, t = threadIdx.x;  // 64 threads
-  float c = block_cnt[f * 64 + t];
-  c = c == 0.f ? 1.f : c;                      // loss.py:215
-  float v = block_loss[f * 64 + t] / c;
-  loss_approx[f * 64 + t] = v;
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-  if (t == 0) frame_avg[fa_index ? fa_index[f] : f] = v / 64.f;         // loss.py:236-238
+  frame_avg_block(blockIdx.x, threadIdx.x, block_loss, block_cnt, loss_approx, frame_avg, fa_index);   // 64 threads
 }
 
 // ---- bounds_pc: brute-force nearest surface point, LDS-tiled -------------------
@@ -447,17 +458,22 @@ int launch_step_tail(int phase, const NetLayout& L, const float* dwPart, const f
   else hipLaunchKernelGGL(step_tail_kernel<1>, grid, dim3(1024), 0, st, p);
   return isdf_launch_status();
 }
+// n_frames > 0: the same launch also turns the (all-reduced) bins into loss_approx / frame averages (the data-parallel
+// step's closing launch, isdf_train_step_finish)
 int launch_adamw_pack(const NetLayout& L, float* params, float* m, float* v, uint16_t* shadow, const float* grad,
                       const float* count_ptr, float grad_scale, float lr, float b1, float b2, float eps, float wd,
-                      int step, hipStream_t st) {
+                      int step, hipStream_t st, int n_frames = 0, const float* bl = nullptr, const float* bc = nullptr,
+                      float* la = nullptr, float* fa = nullptr, const int32_t* fa_index = nullptr) {
   TailParams p = {};
+  p.fin.block_loss = const_cast<float*>(bl); p.fin.block_cnt = const_cast<float*>(bc);
+  p.fin.la_out = la; p.fin.fa_out = fa; p.fin.fa_index = fa_index;
   p.lay = L; p.grad = const_cast<float*>(grad); p.params = params; p.m = m; p.v = v; p.shadow = shadow;
   p.grad_scale = grad_scale; p.count_ptr = count_ptr;
   p.c = AdamwCoef{lr, b1, b2, eps, wd, 1.f - powf(b1, (float)step), sqrtf(1.f - powf(b2, (float)step))};
   const int64_t total = (int64_t)dw_units(L) * DW_BLK * DW_BLK;
   p.nW = (int)((total + 1023) / 1024);
   p.nV = (L.L * L.HD + L.HD + 1 + 63) / 64;
-  hipLaunchKernelGGL(step_tail_kernel<2>, dim3((unsigned)(p.nW + p.nV)), dim3(1024), 0, st, p);
+  hipLaunchKernelGGL(step_tail_kernel<2>, dim3((unsigned)(p.nW + p.nV + n_frames)), dim3(1024), 0, st, p);
   return isdf_launch_status();
 }
 int launch_frame_avg(const float* bl, const float* bc, int F, float* la, float* fa, const int32_t* fa_index,

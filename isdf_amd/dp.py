@@ -8,9 +8,13 @@ and ONE all-reduce(sum) over it (RCCL on GPUs; gloo in the CPU tests) makes
 gradients, logged losses and the per-frame block averages global.  AdamW then
 divides the summed gradient by the reduced element count, which reproduces the
 single-process `mean` exactly even when ranks drop different numbers of
-invalid-depth rays (sample.py:39-55).  No other collective is on the step path;
-keyframe selection stays identical across ranks because its inputs
-(frame_avg_losses from the reduced bins, the numpy seed) are identical.
+invalid-depth rays (sample.py:39-55).  No other collective is on the step path:
+keyframe selection stays identical across ranks because its inputs are
+(frame_avg_losses from the reduced bins; a private numpy stream seeded
+identically by graft(), hot_path.HotPath.select_keyframes), and the shared
+virtual clock rides in the same message -- `world` extra floats at its tail,
+one slot per rank holding that rank's PREVIOUS step time (hot_path.HotPath._step).
+Per-FRAME traffic (new keyframe broadcast, keyframe decision) is separate.
 """
 import torch
 
@@ -88,21 +92,7 @@ def src_rank(group=None):
     return torch.distributed.get_global_rank(group, 0)
 
 
-def broadcast_ints(values, group, device):
-    """rank 0's integer list on every rank (window indices of `select_keyframes`, trainer.py:652-674)"""
-    t = torch.as_tensor([int(v) for v in values], dtype=torch.int64, device=device)
-    torch.distributed.broadcast(t, src_rank(group), group=group)
-    return [int(v) for v in t.cpu()]
-
-
 def broadcast_floats(values, group, device):
     t = torch.as_tensor([float(v) for v in values], dtype=torch.float64, device=device)
     torch.distributed.broadcast(t, src_rank(group), group=group)
     return [float(v) for v in t.cpu()]
-
-
-def max_over_ranks(value, group, device):
-    """the step time every rank adds to its virtual clock (trainer.py:1011-1013): the slowest rank's"""
-    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
-    torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX, group=group)
-    return float(t.item())

@@ -164,6 +164,8 @@ class Engine:
         self._ws_key = None
         self._scan_ws = None      # sampler look-back state (zero on first use, self re-arming afterwards)
         self.reduce_buf = None
+        self.reduce_extra = 0
+        self.reduce_floats = 0
         self.opt_step = 0
         self.slices = {}
         off = 0
@@ -295,9 +297,12 @@ class Engine:
         all-gathered surface samples of every rank."""
         dev = self.device
         F, R0, S = smp["n_frames"], smp["max_rays"], smp["S"]
+        # [isdf_reduce_floats | reduce_extra caller-owned floats]: the kernels write the first part; the tail belongs to the
+        # host protocol (data parallel: per-rank step-time slots riding in the same all-reduce message, hot_path.py)
         nred = int(self.lib.isdf_reduce_floats(C.byref(self.cnet), F))
-        if self.reduce_buf is None or self.reduce_buf.numel() != nred:
-            self.reduce_buf = torch.zeros(nred, dtype=torch.float32, device=dev)
+        if self.reduce_buf is None or self.reduce_buf.numel() != nred + self.reduce_extra:
+            self.reduce_buf = torch.zeros(nred + self.reduce_extra, dtype=torch.float32, device=dev)
+        self.reduce_floats = nred
         ws = self.workspace(R0 * S, True)
         closs = lc.to_c()
         a = _ffi.StepArgs()
@@ -346,23 +351,7 @@ class Engine:
             if lc.bounds_method == "pc":
                 dbg["pc_bounds"], dbg["pc_grad_vec"] = keep[-2].view(R0, S), keep[-1].view(R0, S, 3)
         if optim is not None:
-            self.opt_step += 1
-            betas = optim.get("betas", (0.9, 0.999))
-            q = _ffi.OptimArgs()
-            q.params, q.exp_avg, q.exp_avg_sq = self.params.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr()
-            q.shadow = self.shadow.data_ptr()
-            q.lr, q.weight_decay = float(optim.get("lr", 0.0013)), float(optim.get("weight_decay", 0.012))
-            q.beta1, q.beta2, q.eps = float(betas[0]), float(betas[1]), float(optim.get("eps", 1e-8))
-            q.grad_scale, q.step = float(optim.get("grad_scale", 1.0)), int(self.opt_step)
-            if optim.get("frame_avg_out") is not None:   # loss.frame_avg fused into the same launch
-                la = torch.empty(F, 8, 8, dtype=torch.float32, device=dev)
-                fa_out, fa_idx = optim["frame_avg_out"], optim.get("frame_avg_index")
-                assert fa_out.dtype == torch.float32 and fa_out.is_contiguous()
-                assert fa_idx is None or (fa_idx.dtype == torch.int32 and fa_idx.numel() == F)
-                q.loss_approx, q.frame_avg = la.data_ptr(), fa_out.data_ptr()
-                q.frame_avg_index = None if fa_idx is None else fa_idx.data_ptr()
-                dbg["loss_approx"] = la
-                keep += [fa_out, fa_idx]
+            q = self._optim_args(optim, F, dbg, keep)
             _ffi.check(self.lib.isdf_train_step_adamw(C.byref(self.cnet), C.byref(closs), C.byref(a), C.byref(o),
                                                       C.byref(q), _ffi.ptr(ws), ws.numel(), _stream()),
                        "isdf_train_step_adamw")
@@ -370,6 +359,38 @@ class Engine:
             _ffi.check(self.lib.isdf_train_step(C.byref(self.cnet), C.byref(closs), _ffi.ptr(self.params),
                                                 _ffi.ptr(self.shadow), C.byref(a), C.byref(o), _ffi.ptr(ws),
                                                 ws.numel(), _stream()), "isdf_train_step")
+        dbg["_keep"] = keep
+        return dbg
+
+    def _optim_args(self, optim, F, dbg, keep):
+        """isdf_optim_args of this engine's buffers; advances the optimiser step.  optim: dict(lr, weight_decay, betas,
+        eps, grad_scale[, frame_avg_out, frame_avg_index])"""
+        self.opt_step += 1
+        betas = optim.get("betas", (0.9, 0.999))
+        q = _ffi.OptimArgs()
+        q.params, q.exp_avg, q.exp_avg_sq = self.params.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr()
+        q.shadow = self.shadow.data_ptr()
+        q.lr, q.weight_decay = float(optim.get("lr", 0.0013)), float(optim.get("weight_decay", 0.012))
+        q.beta1, q.beta2, q.eps = float(betas[0]), float(betas[1]), float(optim.get("eps", 1e-8))
+        q.grad_scale, q.step = float(optim.get("grad_scale", 1.0)), int(self.opt_step)
+        if optim.get("frame_avg_out") is not None:   # loss.frame_avg fused into the same launch
+            la = torch.empty(F, 8, 8, dtype=torch.float32, device=self.device)
+            fa_out, fa_idx = optim["frame_avg_out"], optim.get("frame_avg_index")
+            assert fa_out.dtype == torch.float32 and fa_out.is_contiguous()
+            assert fa_idx is None or (fa_idx.dtype == torch.int32 and fa_idx.numel() == F)
+            q.loss_approx, q.frame_avg = la.data_ptr(), fa_out.data_ptr()
+            q.frame_avg_index = None if fa_idx is None else fa_idx.data_ptr()
+            dbg["loss_approx"] = la
+            keep += [fa_out, fa_idx]
+        return q
+
+    def train_step_finish(self, n_frames, optim):
+        """Second half of the data-parallel step (isdf_train_step_finish): AdamW on the all-reduced gradient sums,
+        operand repack and -- with optim["frame_avg_out"] -- loss.frame_avg from the reduced bins, ONE launch."""
+        dbg, keep = {}, []
+        q = self._optim_args(optim, n_frames, dbg, keep)
+        _ffi.check(self.lib.isdf_train_step_finish(C.byref(self.cnet), C.byref(q), _ffi.ptr(self.reduce_buf), int(n_frames),
+                                                   _stream()), "isdf_train_step_finish")
         dbg["_keep"] = keep
         return dbg
 

@@ -277,7 +277,9 @@ class HotPath:
             kw["surf_group"] = hip.dist_group
         dbg = eng.train_step(s, self._loss_cfg(), sc, noise=noise, **kw)
         if hip.dist_group is not None:   # sums over ranks; AdamW divides by the reduced count
-            dp.allreduce_(eng.reduce_buf, hip.dist_group)
+            if hip.time_src is not None:   # this rank's previous step time rides in the message's tail (one slot per rank)
+                eng.reduce_buf[eng.reduce_floats:].copy_(hip.time_src, non_blocking=True)
+            dp.allreduce_(eng.reduce_buf, hip.dist_group)   # THE collective of the step
         return dbg
 
     def sdf_eval_and_loss(self, sample, do_avg_loss=True):
@@ -335,9 +337,7 @@ class HotPath:
 
         K = self.frames.T_WC_batch.shape[0]
         if len(self.frames) > self.window_size and self.incremental:
-            idxs = self.select_keyframes()
-            if hip.dist_group is not None:             # replicated window: rank 0's draw
-                idxs = dp.broadcast_ints(idxs, hip.dist_group, hip.device)
+            idxs = self.select_keyframes()             # replicated under data parallelism without a collective (below)
         else:
             idxs = np.arange(K)
         self.active_idxs = idxs
@@ -362,26 +362,58 @@ class HotPath:
         direct = fal.is_contiguous() and fal.dtype == torch.float32 and fal.device == hip.device
         dbg = self._step_kernels(s, sc, fused, (fal, fidx) if direct else None)
         eng = self.engine
-        if not fused or not direct:                    # two-call / data-parallel path: bins -> frame averages
-            if direct:
-                eng.frame_avg(len(idxs), out=fal, index=fidx)
-            else:
-                _, fa = eng.frame_avg(len(idxs))
-                self.frames.frame_avg_losses[fidx.long()] = fa      # trainer.py:979
-        if not fused:
-            self.optimiser.step()                      # AdamW on the (all-reduced) gradient sums
+        if not fused and direct and hip.fuse_optimiser:
+            # two-call / data-parallel form: ONE closing launch = AdamW on the (all-reduced) gradient sums + operand
+            # repack + `frames.frame_avg_losses[idxs] = frame_avg_loss` from the reduced bins (trainer.py:979-982)
+            g = self.optimiser.param_groups[0]
+            eng.train_step_finish(len(idxs), dict(lr=g["lr"], weight_decay=g["weight_decay"], betas=g["betas"], eps=g["eps"],
+                                                  frame_avg_out=fal, frame_avg_index=fidx))
+        else:
+            if not fused or not direct:                # separate launches (caller-owned frame_avg_losses layout, or
+                if direct:                             # fuse_optimiser=False: the reference's call sequence)
+                    eng.frame_avg(len(idxs), out=fal, index=fidx)
+                else:
+                    _, fa = eng.frame_avg(len(idxs))
+                    self.frames.frame_avg_losses[fidx.long()] = fa      # trainer.py:979
+            if not fused:
+                self.optimiser.step()                  # AdamW on the (all-reduced) gradient sums
         hip.loss_host.copy_(eng.loss_sums(), non_blocking=True)   # rides on the closing synchronisation
+        if hip.time_src is not None:
+            hip.time_host.copy_(eng.reduce_buf[eng.reduce_floats:], non_blocking=True)
 
         step_time = self._timing_end(st, start, end)
+        clock_ms = step_time
         if hip.virtual_step_ms is not None:            # pinned schedule (parity / accuracy runs)
-            step_time = float(hip.virtual_step_ms)
-        if hip.dist_group is not None:                 # ONE virtual clock for all ranks (frame schedule)
-            step_time = dp.max_over_ranks(step_time, hip.dist_group, hip.device)
+            clock_ms = step_time = float(hip.virtual_step_ms)
+        elif hip.time_src is not None:
+            # ONE virtual clock for all ranks (the frame schedule is a function of it) WITHOUT a second collective: every
+            # rank's time of the PREVIOUS step came back in the tail of this step's all-reduce message; the clock advances
+            # by the slowest rank's, one step late (step 0 advances it by 0).  This step's own time goes out with the next.
+            clock_ms = float(hip.time_host.max())
+            hip.time_src.zero_()
+            hip.time_src[hip.rank] = step_time
         losses = StepLosses(hip.loss_host, self.grad_weight != 0, self.eik_weight != 0)
         hip.step_count += 1
-        self.tot_step_time += (1 / self.frac_time_perception) * (step_time / 1000.0)
+        self.tot_step_time += (1 / self.frac_time_perception) * (clock_ms / 1000.0)
         self.steps_since_frame += 1
         return losses, step_time
+
+    def select_keyframes(self):
+        """The reference's window draw (trainer.py:652-674) runs unchanged.  Under data parallelism every rank must pick
+        the SAME window, and it does without a collective: the inputs are bit-identical on every rank
+        (`frames.frame_avg_losses` comes from the all-reduced bins) and `np.random.choice` draws from a private stream
+        that graft() seeded identically everywhere -- swapped in for the call, so nothing else that touches numpy's
+        global generator on one rank can de-synchronise it."""
+        hip = self._hip
+        if hip.dist_group is None:
+            return super().select_keyframes()
+        saved = np.random.get_state()
+        np.random.set_state(hip.window_rng_state)
+        try:
+            return super().select_keyframes()
+        finally:
+            hip.window_rng_state = np.random.get_state()
+            np.random.set_state(saved)
 
     # ------------------------------------------------------------------ keyframe test (trainer.py:586-620)
     def is_keyframe(self, T_WC, depth_gt):
@@ -448,6 +480,7 @@ class HotPath:
                           last_is_keyframe=self.last_is_keyframe, optim_frames=self.optim_frames,
                           noise_std=self.noise_std, step_count=hip.step_count),
             "rng": dict(draw_count=hip.draw_count, noise_count=hip.noise_count, seed=hip.seed,
+                        window=getattr(hip, "window_rng_state", None),
                         numpy=np.random.get_state(), torch=torch.get_rng_state(),
                         torch_cuda=torch.cuda.get_rng_state(hip.device) if hip.device.type == "cuda" else None),
         }
@@ -471,6 +504,8 @@ class HotPath:
         r = sd["rng"]
         hip.draw_count, hip.noise_count, hip.seed = r["draw_count"], r["noise_count"], r["seed"]
         hip.idx_cache = None
+        if r.get("window") is not None:
+            hip.window_rng_state = r["window"]
         np.random.set_state(r["numpy"]); torch.set_rng_state(r["torch"])
         if r.get("torch_cuda") is not None:
             torch.cuda.set_rng_state(r["torch_cuda"], hip.device)
@@ -541,9 +576,17 @@ def graft(trainer, rng="philox", seed=1, dist_group=None, fix_normal_window=Fals
     base = trainer.__class__
     if not issubclass(base, HotPath):
         trainer.__class__ = type("Hip" + base.__name__, (HotPath, base), {"__module__": HotPath.__module__})
+    hip.time_src = hip.time_host = None
     if dist_group is not None:                           # replicated weights / moments
         eng = trainer.sdf_map.engine
         for t in (eng.params, eng.exp_avg, eng.exp_avg_sq):
             torch.distributed.broadcast(t, dp.src_rank(dist_group), group=dist_group)
         eng.pack()
+        hip.rank, hip.world = torch.distributed.get_rank(dist_group), torch.distributed.get_world_size(dist_group)
+        hip.window_rng_state = np.random.RandomState(hip.seed + 104729).get_state()   # replicated select_keyframes stream
+        if hip.virtual_step_ms is None:                  # per-rank step-time slots in the tail of the all-reduce message
+            pin = dev.type == "cuda"
+            hip.time_src = torch.zeros(hip.world, dtype=torch.float32, pin_memory=pin)
+            hip.time_host = torch.zeros(hip.world, dtype=torch.float32, pin_memory=pin)
+            eng.reduce_extra = hip.world
     return trainer

@@ -23,8 +23,10 @@ class PortNet(torch.nn.Module):
         super().__init__()
         self.hidden, self.blocks, self.n_freqs = hidden, blocks, n_freqs
         self.scale_input, self.scale_output = scale_input, scale_output
-        self.transform = None if transform is None else torch.as_tensor(transform, dtype=torch.float32)
-        self.dirs = torch.tensor(ICO_DIRS, dtype=torch.float32)
+        # buffers, so that .to(device) moves them (the eager-GPU baseline of bench.py runs this module on "cuda")
+        self.register_buffer("transform", None if transform is None else torch.as_tensor(np.asarray(transform), dtype=torch.float32),
+                             persistent=False)
+        self.register_buffer("dirs", torch.tensor(ICO_DIRS, dtype=torch.float32), persistent=False)
         E = 2 * 21 * n_freqs + 3
         sp = lambda i, o: torch.nn.Sequential(torch.nn.Linear(i, o), torch.nn.Softplus(beta=100))
         self.in_layer = sp(E, hidden)
@@ -40,7 +42,7 @@ class PortNet(torch.nn.Module):
         if self.transform is not None:                        # transform.py:287-304
             x = x @ self.transform[:3, :3].T + self.transform[:3, 3]
         x = x * self.scale_input
-        freq = 2.0 ** torch.linspace(0, self.n_freqs - 1, self.n_freqs)
+        freq = 2.0 ** torch.linspace(0, self.n_freqs - 1, self.n_freqs, device=x.device)
         proj = x @ self.dirs
         xb = (proj[..., None] * freq).reshape(*proj.shape[:-1], -1)
         return torch.cat([x, torch.sin(torch.cat([xb, xb + 0.5 * np.pi], -1))], -1)
@@ -56,12 +58,15 @@ class PortNet(torch.nn.Module):
 
 
 def sample_step(depth, T_WC, normals, cam, sc, gen):
-    """sample_pixels + get_batch_data + sample_along_rays (`sample.py:11-178`)."""
+    """sample_pixels + get_batch_data + sample_along_rays (`sample.py:11-178`).  The draws come from the (CPU)
+    generator `gen` and are moved to the data's device -- what the reference itself does for the surface offsets
+    (sample.py:160-162); on "cuda" the rest of the chain then runs as eager device ops like upstream."""
     F, H, W = depth.shape
     n = sc["n_rays"]
-    ih = torch.randint(0, H, (F * n,), generator=gen)
-    iw = torch.randint(0, W, (F * n,), generator=gen)
-    ib = torch.arange(F).repeat_interleave(n)
+    dev = depth.device
+    ih = torch.randint(0, H, (F * n,), generator=gen).to(dev)
+    iw = torch.randint(0, W, (F * n,), generator=gen).to(dev)
+    ib = torch.arange(F, device=dev).repeat_interleave(n)
     d = depth[ib, ih, iw]
     nm = normals[ib, ih, iw]
     ok = (d != 0) & ~torch.isnan(nm[:, 0])
@@ -73,10 +78,10 @@ def sample_step(depth, T_WC, normals, cam, sc, gen):
     R = d.shape[0]
     maxd = d + sc["dist_behind_surf"]
     rng = (maxd - sc["min_depth"])[:, None]
-    lim = torch.linspace(0, 1, sc["n_strat"] + 1)[None, :].repeat(R, 1) * rng + sc["min_depth"]
-    z = lim[:, :-1] + torch.rand(R, sc["n_strat"], generator=gen) * (rng / sc["n_strat"])
-    off = torch.normal(torch.zeros(R, sc["n_surf"] - 1), 0.1, generator=gen)
-    near = torch.clamp(d[:, None] + off, torch.full((R, 1), sc["min_depth"]), maxd[:, None])
+    lim = torch.linspace(0, 1, sc["n_strat"] + 1, device=dev)[None, :].repeat(R, 1) * rng + sc["min_depth"]
+    z = lim[:, :-1] + torch.rand(R, sc["n_strat"], generator=gen).to(dev) * (rng / sc["n_strat"])
+    off = torch.normal(torch.zeros(R, sc["n_surf"] - 1), 0.1, generator=gen).to(dev)
+    near = torch.clamp(d[:, None] + off, torch.full((R, 1), sc["min_depth"], device=dev), maxd[:, None])
     z = torch.cat((d[:, None], near, z), 1)
     pc = Tm[:, None, :3, 3] + dW[:, None, :] * z[:, :, None]
     return dict(pc=pc, z=z, depth=d, dC=dC, dW=dW, normals=nm, ib=ib, ih=ih, iw=iw)
@@ -87,7 +92,7 @@ def loss_step(net, s, lc, noise_std, gen, noise=None):
     noise: optional pre-drawn, pre-scaled noise (parity tests)."""
     pc = s["pc"].clone().requires_grad_()
     if noise is None and noise_std is not None:
-        noise = torch.randn(pc.shape[:-1], generator=gen) * noise_std
+        noise = torch.randn(pc.shape[:-1], generator=gen).to(pc.device) * noise_std
     sdf = net(pc, noise)
     g = torch.autograd.grad(sdf, pc, torch.ones_like(sdf), create_graph=True, retain_graph=True)[0]
     bounds = s["dC"].norm(dim=-1)[:, None] * (s["depth"][:, None] - s["z"])
@@ -108,8 +113,8 @@ def loss_step(net, s, lc, noise_std, gen, noise=None):
 
 def frame_avg_step(tot, s, F, H, W):
     """`loss.frame_avg` (`loss.py:208-240`) incl. its dense [F,H,W] scatter images."""
-    full = torch.zeros(F, H, W)
-    mask = torch.zeros(F, H, W)
+    full = torch.zeros(F, H, W, device=tot.device)
+    mask = torch.zeros(F, H, W, device=tot.device)
     full[s["ib"], s["ih"], s["iw"]] = tot.sum(-1).detach()
     mask[s["ib"], s["ih"], s["iw"]] = 1
     la = full.view(-1, 8, H // 8, 8, W // 8).sum(dim=(2, 4))

@@ -21,6 +21,7 @@ class FakeEngine:
         self.params = torch.zeros(off)
         self.exp_avg, self.exp_avg_sq = torch.zeros(off), torch.zeros(off)
         self.reduce_buf, self.opt_step = None, 0
+        self.reduce_extra, self.reduce_floats = 0, 0     # caller-owned tail of the all-reduce message (data parallel)
         self.calls = []
 
     # ---- parameters
@@ -101,7 +102,9 @@ class FakeEngine:
                                           noise=None if noise is None else noise[:R].numpy())
         N = R * S
         nred = self.n_params + 8 + 2 * F * 64
-        self.reduce_buf = torch.zeros(nred)
+        self.reduce_floats = nred
+        self.reduce_buf = torch.zeros(nred + self.reduce_extra)
+        self._F = F
         for k, (off, shp) in self.slices.items():
             self.reduce_buf[off:off + int(np.prod(shp))] = torch.from_numpy((grads[k].astype(np.float64) * N).astype(np.float32).reshape(-1))
         ls = self.reduce_buf[self.n_params:self.n_params + 8]
@@ -111,6 +114,18 @@ class FakeEngine:
         la, fa = orc.frame_avg(terms["tot_loss_mat"], smp["indices_b"][:R].numpy(), smp["indices_h"][:R].numpy(),
                                smp["indices_w"][:R].numpy(), F, sc.H, sc.W)
         self._la, self._fa = torch.from_numpy(la.astype(np.float32)), torch.from_numpy(fa.astype(np.float32))
+        # block bins as SUMS / counts, like the kernels write them (this rank's rays; last ray on a pixel wins)
+        hb, wb = sc.H // 8, sc.W // 8
+        ray = terms["tot_loss_mat"].sum(-1)
+        bl, bc = np.zeros((F, 8, 8), np.float32), np.zeros((F, 8, 8), np.float32)
+        pix = list(zip(smp["indices_b"][:R].tolist(), smp["indices_h"][:R].tolist(), smp["indices_w"][:R].tolist()))
+        last = {p: r for r, p in enumerate(pix)}
+        for r, (b, h, w) in enumerate(pix):
+            if last[(b, h, w)] == r:
+                bl[b, h // hb, w // wb] += ray[r]; bc[b, h // hb, w // wb] += 1
+        o = self.n_params + 8
+        self.reduce_buf[o:o + 64 * F] = torch.from_numpy(bl.reshape(-1))
+        self.reduce_buf[o + 64 * F:o + 128 * F] = torch.from_numpy(bc.reshape(-1))
         self.calls.append("train_step")
         dbg = {}
         if optim is not None:
@@ -120,6 +135,20 @@ class FakeEngine:
             self.adamw(lr=optim.get("lr", 0.0013), weight_decay=optim.get("weight_decay", 0.012),
                        betas=optim.get("betas", (0.9, 0.999)), eps=optim.get("eps", 1e-8))
         return dbg
+
+    def train_step_finish(self, n_frames, optim):
+        """isdf_train_step_finish: AdamW on the (all-reduced) sums + frame averages from the (all-reduced) bins"""
+        o = self.n_params + 8
+        bl = self.reduce_buf[o:o + 64 * n_frames].view(n_frames, 64)
+        bc = self.reduce_buf[o + 64 * n_frames:o + 128 * n_frames].view(n_frames, 64).clone()
+        bc[bc == 0] = 1.0
+        la = bl / bc
+        if optim.get("frame_avg_out") is not None:
+            optim["frame_avg_out"][optim["frame_avg_index"].long()] = la.sum(1) / 64.0
+        self.adamw(lr=optim.get("lr", 0.0013), weight_decay=optim.get("weight_decay", 0.012),
+                   betas=optim.get("betas", (0.9, 0.999)), eps=optim.get("eps", 1e-8))
+        self.calls.append("train_step_finish")
+        return {"loss_approx": la.view(n_frames, 8, 8)}
 
     def loss_sums(self):
         return self.reduce_buf[self.n_params:self.n_params + 8]

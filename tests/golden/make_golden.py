@@ -390,6 +390,41 @@ def main():
     if only in round2:
         round2[only]()
         return
+    # ---- round 3: reference-generated pins for every network SHAPE the kernels are instantiated for, and for the
+    # realsense*.json constants.  embedding.py:36-72 (n_freqs = n_embed_funcs + 1 octaves),
+    # fc_map.py:77-92 (hidden_layers_block), realsense*.json (720x1280, scale_input 0.4 / 0.04, trunc_weight 30,
+    # trunc_distance 0.1, dist_behind_surf 0.01, depth_range[0] 0.1 / 0.15; live modes have NO bounds transform)
+    cam_rs = dict(H=720, W=1280, fx=636.1981811523438, fy=635.5728149414062, cx=633.679931640625, cy=372.60797119140625)       # realsense.json:10-17
+    cam_franka = dict(H=720, W=1280, fx=913.4483642578125, fy=913.4601440429688, cx=640.4678955078125, cy=359.1015319824219)  # realsense_franka*.json
+    loss_franka = dict(LOSS_DEFAULT, trunc_weight=30.0, trunc_distance=0.1)                     # realsense_franka.json:68-77
+    net_b3 = lambda nf: dict(H=64, B=3, n_freqs=nf, scale_input=0.05937489, scale_output=0.14)
+    round3 = {
+        # (i) 64-wide, hidden_layers_block 3, n_freqs 9 / 10 / 11: every tensor + full gradients (oracle pins)
+        "eval_small_b3_f9": lambda: run_eval_case(mods, "eval_small_b3_f9", net_b3(9), LOSS_DEFAULT, SAMPLE_DEFAULT, 3, cam_s, 51, 0.08, True),
+        "eval_small_b3_f10": lambda: run_eval_case(mods, "eval_small_b3_f10", net_b3(10), LOSS_DEFAULT, SAMPLE_DEFAULT, 3, cam_s, 52, 0.08, True),
+        "eval_small_b3_f11": lambda: run_eval_case(mods, "eval_small_b3_f11", net_b3(11), loss_franka, dict(SAMPLE_DEFAULT, dist_behind_surf=0.01), 3,
+                                                   cam_s, 53, 0.025, True, transform_on=False),
+        # (ii) BASELINE configs[4]: 8 x 512, n_freqs 10 (E = 423) -- the <512,512> instantiation; ~3 k points, digests
+        "eval_wide_512": lambda: run_eval_case(mods, "eval_wide_512", dict(H=512, B=3, n_freqs=10, scale_input=0.05937489, scale_output=0.14),
+                                               LOSS_DEFAULT, dict(SAMPLE_DEFAULT, n_rays=24), 5, cam_s, 54, 0.08, False),
+        # (iii) the three realsense configs at their own constants, 720x1280, identity PE transform: the <256,512> instantiation
+        "eval_rs_realsense": lambda: run_eval_case(mods, "eval_rs_realsense", dict(H=256, B=2, n_freqs=9, scale_input=0.04, scale_output=0.14),
+                                                   LOSS_DEFAULT, dict(SAMPLE_DEFAULT, n_rays=60, min_depth=0.15), 5, cam_rs, 55, 0.25, False,
+                                                   transform_on=False, exact_frames=True),
+        "eval_rs_franka": lambda: run_eval_case(mods, "eval_rs_franka", dict(H=256, B=2, n_freqs=9, scale_input=0.4, scale_output=0.14),
+                                                loss_franka, dict(SAMPLE_DEFAULT, n_rays=120, min_depth=0.1), 5, cam_franka, 56, 0.025, False,
+                                                transform_on=False, exact_frames=True),
+        "eval_rs_franka_offline": lambda: run_eval_case(mods, "eval_rs_franka_offline", dict(H=256, B=3, n_freqs=11, scale_input=0.04, scale_output=0.14),
+                                                        loss_franka, dict(SAMPLE_DEFAULT, n_rays=120, min_depth=0.1, dist_behind_surf=0.01), 5,
+                                                        cam_franka, 57, 0.025, False, transform_on=False, exact_frames=True),
+    }
+    if only == "round3":
+        for fn in round3.values():
+            fn()
+        return
+    if only in round3:
+        round3[only]()
+        return
     cam_s = dict(H=48, W=64, fx=60.0, fy=60.0, cx=31.5, cy=23.5)
     small = dict(H=64, B=1, n_freqs=6, scale_input=0.05937489, scale_output=0.14)
     full = dict(H=256, B=2, n_freqs=6, scale_input=0.05937489, scale_output=0.14)
@@ -415,6 +450,8 @@ def main():
     run_ingest_case(mods, "ingest_small", 31)
     # 8. round 2: BASELINE-size fixtures, default-net Trainer.step, extra oracle pins
     for fn in round2.values():
+        fn()
+    for fn in round3.values():
         fn()
 
 

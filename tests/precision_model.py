@@ -20,8 +20,8 @@ def bf16(x):
 
 
 def forward(params, cfg, x, operand="fp16"):
-    """operand "fp16x2": the compensated forward (isdf_amd/csrc/chain.hip, OPER 2) -- layers >= cat add W_lo x, the
-    layers past the cat layer also W x_lo (W_lo = fp16(W - fp16(W)), x_lo = fp16(x - fp16(x)))."""
+    """operand "fp16x2": the compensated forward (isdf_amd/csrc/chain.hip, OPER 2) -- the cat layer adds W_lo[:, H:] emb,
+    the layers past it W_lo x and W x_lo (W_lo = fp16(W - fp16(W)), x_lo = fp16(x - fp16(x)))."""
     x2 = operand == "fp16x2"
     q = bf16 if operand == "bf16" else f16
     x = np.asarray(x, np.float32).reshape(-1, 3)
@@ -31,10 +31,10 @@ def forward(params, cfg, x, operand="fp16"):
         inp = np.concatenate([a, e], -1) if li == cfg.cat else a
         W = params[n + ".weight"]
         z = inp @ q(W).T
-        if x2 and li >= cfg.cat:
-            z = z + inp @ f16(W - f16(W)).T
-            if li > cfg.cat:
-                z = z + f16(af - a) @ f16(W).T
+        if x2 and li == cfg.cat:      # residual of the embedding columns only
+            z = z + e @ f16(W - f16(W))[:, cfg.H:].T
+        elif x2 and li > cfg.cat:
+            z = z + inp @ f16(W - f16(W)).T + f16(af - a) @ f16(W).T
         z = z + params[n + ".bias"]
         af = orc.softplus(z)
         a = q(af)

@@ -131,3 +131,74 @@ def test_two_rank_surface_gather_for_bounds_pc():
     d_all = np.linalg.norm(q[:, None, :].astype(np.float64) - surf[None].astype(np.float64), axis=-1)
     d_ref = np.linalg.norm(q[:, None, :].astype(np.float64) - pc[live, 0][None].astype(np.float64), axis=-1)
     np.testing.assert_array_equal(np.take(np.r_[0:25, 40:75], d_ref.argmin(1)), d_all.argmin(1))
+
+
+# ---- the whole data-parallel step() of the host mirror under world size 2 (oracle-backed engine on CPU) -----------------
+def _step_worker(rank, world, port, ret):
+    """HipTrainer(dist_group=...) with rank-DIFFERENT host seeds and more keyframes than the window: every rank must pick
+    the same window WITHOUT a collective, share one virtual clock, and issue exactly ONE collective per step."""
+    import contextlib, io
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    from isdf_amd.trainer import HipTrainer
+    from isdf_amd import synthetic
+    from tests.accuracy_experiment import config
+    from tests.fake_engine import FakeEngine
+    cam = dict(H=48, W=64, fx=60.0, fy=60.0, cx=31.5, cy=23.5)
+    cfg = config(cam)
+    cfg["model"].update(hidden_feature_size=64, hidden_layers_block=1, window_size=3)
+    cfg["sample"].update(n_rays=12, n_rays_is_kf=24)
+    np.random.seed(100 + rank); torch.manual_seed(100 + rank)          # different host seeds per rank on purpose
+    tr = HipTrainer("cpu", cfg, inv_bounds_transform=gu.bounds_transform(), rng="philox", seed=5,
+                    dist_group=torch.distributed.group.WORLD, engine_factory=FakeEngine)
+    traj = synthetic.trajectory(30)
+    rng = np.random.RandomState(7)
+    counts = {"all_reduce": 0, "broadcast": 0, "other": 0}
+    orig = {k: getattr(torch.distributed, k) for k in ("all_reduce", "broadcast", "all_gather_into_tensor", "barrier")}
+
+    def counted(name, key):
+        def f(*a, **k):
+            counts[key] += 1
+            return orig[name](*a, **k)
+        return f
+    per_step, windows, clocks, times = [], [], [], []
+    with contextlib.redirect_stdout(io.StringIO()):
+        for k in range(5):                                             # 5 keyframes > window 3: select_keyframes draws
+            fr = tr.make_frame(k * 5, synthetic.render_depth(traj[k * 5], cam, rng, noise_std=0.0), traj[k * 5])
+            tr.last_is_keyframe = True
+            tr.add_frame(fr)
+            tr.noise_std = tr.noise_kf
+            for _ in range(2):
+                np.random.rand(rank + 1)                               # rank-dependent use of numpy's GLOBAL generator
+                for n_, key in (("all_reduce", "all_reduce"), ("broadcast", "broadcast"),
+                                ("all_gather_into_tensor", "other"), ("barrier", "other")):
+                    setattr(torch.distributed, n_, counted(n_, key))
+                before = dict(counts)
+                losses, ms = tr.step()
+                for n_ in orig:
+                    setattr(torch.distributed, n_, orig[n_])
+                per_step.append(tuple(counts[c] - before[c] for c in ("all_reduce", "broadcast", "other")))
+                windows.append([int(i) for i in tr.active_idxs])
+                clocks.append(tr.tot_step_time); times.append(ms)
+    ret[rank] = dict(per_step=per_step, windows=windows, clocks=clocks, times=times,
+                     params=tr.engine.params.numpy().copy(), fal=tr.frames.frame_avg_losses.numpy().copy(),
+                     calls=list(tr.engine.calls[-4:]))
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_trainer_step_issues_one_collective_and_stays_replicated():
+    port = _free_port()
+    mgr = mp.Manager(); ret = mgr.dict()
+    mp.spawn(_step_worker, args=(2, port, ret), nprocs=2, join=True)
+    a, b = ret[0], ret[1]
+    assert all(c == (1, 0, 0) for c in a["per_step"] + b["per_step"]), a["per_step"]     # ONE all-reduce, nothing else
+    assert a["windows"] == b["windows"] and any(len(w) == 3 and w != [0, 1, 2] for w in a["windows"])   # drawn, identical
+    assert a["clocks"] == b["clocks"]                                                      # one virtual clock ...
+    assert a["clocks"][0] == 0.0 and a["clocks"][-1] > 0.0                                 # ... one step late
+    # the clock advanced by the SLOWEST rank's time of the previous step
+    for k in range(1, len(a["clocks"])):
+        want = max(np.float32(a["times"][k - 1]), np.float32(b["times"][k - 1])) / 1000.0
+        assert abs((a["clocks"][k] - a["clocks"][k - 1]) - want) < 1e-9 + 1e-6 * want
+    assert np.array_equal(a["params"], b["params"]) and np.array_equal(a["fal"], b["fal"])
+    assert a["calls"] == ["sample", "train_step", "adamw", "train_step_finish"]   # (the fake finish logs its AdamW)

@@ -2,13 +2,14 @@
 ranks on one device, so the two ranks share cuda:0 and talk over gloo (the collective is the only difference to
 the 8-GPU path: same kernels, same buffers, same call sequence).  Checked:
 
-  * engine level: two ranks, each sampler -> isdf_train_step -> all_reduce(sum) -> isdf_adamw -> frame averages
+  * engine level: two ranks, each sampler -> isdf_train_step -> all_reduce(sum) -> isdf_train_step_finish (AdamW + frame averages)
     on ITS half of the rays, against ONE process running the union of the two ray sets in a single batch
     (sums + reduced count reproduce the single-process mean); bounds_method "ray" and "pc"
     (all-gathered surface set);
-  * trainer level: `HipTrainer(dist_group=...)`: weights broadcast at graft time, rank-0 window indices, one
-    virtual clock, per-frame broadcast in add_frame, rank-independent keyframe test -- the ranks stay
-    bit-identical through steps, a keyframe decision and a frame ingest.
+  * trainer level: `HipTrainer(dist_group=...)`: weights broadcast at graft time, replicated window draw (no collective),
+    one virtual clock riding in the all-reduce message, per-frame broadcast in add_frame, rank-independent keyframe
+    test -- the ranks stay bit-identical through steps, a keyframe decision and a frame ingest, and step() issues
+    exactly ONE collective.
 """
 import os
 import socket
@@ -78,10 +79,13 @@ def _run_engine(bounds, ranks, group, out):
         eng.train_step(s, lc, sc, noise=dev(b["noise"]), surf_group=group if bounds == "pc" else None)
         if group is not None:
             dp.allreduce_(eng.reduce_buf, group)
-        eng.frame_avg(F, out=fal, index=idx)
         if st == 0:
             out.update(g1=eng.reduce_buf[:eng.n_params].cpu().numpy())      # first-step gradient SUMS
-        eng.adamw()
+        if group is not None:        # the data-parallel closing launch: AdamW + repack + frame averages (isdf_train_step_finish)
+            eng.train_step_finish(F, dict(frame_avg_out=fal, frame_avg_index=idx))
+        else:                        # single process: the separate entry points
+            eng.frame_avg(F, out=fal, index=idx)
+            eng.adamw()
     torch.cuda.synchronize()
     out.update(params=eng.params.cpu().numpy(), m=eng.exp_avg.cpu().numpy(), v=eng.exp_avg_sq.cpu().numpy(),
                fal=fal.cpu().numpy(), ls=eng.loss_sums().cpu().numpy())
@@ -111,8 +115,21 @@ def _run_trainer(rank, group, out):
         tr.last_is_keyframe = False
         fr = tr.make_frame(36, synthetic.render_depth(traj[36], CAM, rng, noise_std=0.01), traj[36])
         tr.add_frame(fr)
+        counts = {"n": 0}
+        orig = {k: getattr(torch.distributed, k) for k in ("all_reduce", "broadcast", "all_gather_into_tensor")}
+
+        def counted(name):
+            def f(*a, **k):
+                counts["n"] += 1
+                return orig[name](*a, **k)
+            return f
+        for name in orig:
+            setattr(torch.distributed, name, counted(name))
         for _ in range(2):
             tr.step()
+        for name in orig:
+            setattr(torch.distributed, name, orig[name])
+        out.update(t_collectives_per_step=counts["n"] / 2.0)           # K = 8 > window: select_keyframes draws here
         add_new = tr.check_keyframe_latest()                          # keyframe test on the frozen net
     torch.cuda.synchronize()
     out.update(t_params=tr.engine.params.cpu().numpy(), t_depth_sum=float(tr.frames.depth_batch.double().sum()),
@@ -170,3 +187,4 @@ def test_two_ranks_on_one_gpu_match_the_single_process_union_batch():
     for k in ("t_params", "t_depth_sum", "t_clock", "t_idxs", "t_add_new", "t_kf", "t_fal", "t_K"):
         assert np.array_equal(r0[k], r1[k]), k
     assert int(r0["t_K"]) >= 7 and np.isfinite(r0["t_params"]).all()
+    assert float(r0["t_collectives_per_step"]) == 1.0 and float(r1["t_collectives_per_step"]) == 1.0

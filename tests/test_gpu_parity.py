@@ -1050,3 +1050,59 @@ def test_sampler_ray_count_sweep(F, n):
             near = torch.clamp(ds[ok][:, None] + N_off[:R], min=sc.min_depth)
             near = torch.minimum(near, (ds[ok] + sc.dist_behind_surf)[:, None])
             assert torch.equal(s["z_vals"][:R, 0], ds[ok]) and torch.allclose(s["z_vals"][:R, 1:sc.n_surf], near, rtol=0, atol=1e-6)
+
+
+# ---- round 3: every network shape the kernels are instantiated for, pinned to the REFERENCE -------------------------
+# (fixtures: tests/golden/make_golden.py round3 -- the unmodified reference on 8x512 / n_freqs 10 (BASELINE configs[4],
+# <512,512>) and on the three realsense*.json configurations at their own constants, 720x1280, no bounds transform
+# (<256,512>): n_freqs 9 and 11, hidden_layers_block 3, scale_input 0.4 / 0.04, trunc_weight 30, trunc_distance 0.1,
+# dist_behind_surf 0.01, depth_range[0] 0.1 / 0.15.  embedding.py:36-72, fc_map.py:77-92, realsense_franka_offline.json:63-71)
+SHAPE_CASES = ["eval_wide_512", "eval_rs_realsense", "eval_rs_franka", "eval_rs_franka_offline"]
+# summed weight gradients of the high-frequency nets: the loss is NOT smooth (L1 / eikonal signs, free-space branch,
+# loss.py:122-164, trainer.py:814-816) and with 9-11 PE octaves a random-init field oscillates so fast that the forward
+# rounding of a 16-bit-operand implementation flips some of those signs; measured bounds per fixture (rel to the norm)
+SHAPE_DW_TOL = {"eval_wide_512": 2e-2, "eval_rs_realsense": 2e-2, "eval_rs_franka": 3e-2, "eval_rs_franka_offline": 3e-2}
+
+
+@pytest.mark.parametrize("case", SHAPE_CASES)
+def test_other_network_shapes_vs_reference(case):
+    g = gu.load(case)
+    eng = _engine(g)
+    lc, sc = _cfgs(g)
+    # sampler at this geometry / depth range / dist_behind_surf: bit-exact index work, z / pc to fp32 re-association
+    s = _sample_hip(eng, g, sc)
+    torch.cuda.synchronize()
+    R = int(s["n_valid"].item())
+    assert R == g["depth_sample"].shape[0]
+    for k in ["indices_b", "indices_h", "indices_w"]:
+        assert np.array_equal(s[k][:R].cpu().numpy(), g[k]), k
+    assert np.array_equal(s["depth_sample"][:R].cpu().numpy(), g["depth_sample"])
+    assert np.array_equal(s["norm_sample"][:R].cpu().numpy(), g["norm_sample"])
+    np.testing.assert_allclose(s["z_vals"][:R].cpu().numpy(), g["z_vals"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(s["pc"][:R].cpu().numpy(), g["pc"], rtol=0, atol=4e-6)
+    # forward + input gradient vs the reference
+    x = g["pc"].reshape(-1, 3)
+    sdf, grad = eng.sdf_eval(_dev(x), want_grad=True)
+    err = gu.rel_err(sdf.cpu().numpy(), g["sdf_nonoise"].reshape(-1))
+    gerr = gu.rel_err(grad.cpu().numpy(), g["sdf_grad"].reshape(-1, 3))
+    print("%s: sdf rel-L2 vs reference %.3e, d sdf/dx %.3e" % (case, err, gerr))
+    assert err < TOL_SDF, err
+    assert gerr < 1.5 * TOL_SDF_GRAD, gerr
+    # training step: the four loss means and the digests of all gradient tensors vs the reference; then vs the oracle
+    eng, s, dbg, terms, grads, R = _run_step(g)
+    N = R * s["S"]
+    _check_losses(eng, N, g)
+    _check_losses(eng, N, terms)
+    la, fa = eng.frame_avg(g["depth_batch"].shape[0])
+    np.testing.assert_allclose(fa.cpu().numpy(), g["frame_avg_loss"], rtol=5e-3, atol=1e-6)
+    worst = 0.0
+    prng = np.random.RandomState(1234)
+    for k in gu.params_of(g):
+        v = eng.grad_view(k).cpu().numpy().astype(np.float64) / N
+        probe = prng.standard_normal(v.shape)
+        nrm, dot = g["gdig/" + k]
+        worst = max(worst, abs(np.linalg.norm(v) - nrm) / nrm, abs((v * probe).sum() - dot) / (nrm * np.sqrt(v.size)),
+                    gu.rel_err(v, grads[k]))
+    print("%s: worst gradient deviation (reference norm / probe digests, oracle rel-L2) %.3e" % (case, worst))
+    _check_grads_vs_reference_digest(eng, N, g, tol=SHAPE_DW_TOL[case])
+    _check_grads_vs_oracle(eng, N, grads, tol=SHAPE_DW_TOL[case])

@@ -11,7 +11,13 @@ from tests import golden_util as gu
 EVAL_CASES = ["eval_small_ray", "eval_small_pc_l2", "eval_small_nograd", "eval_full_ray",
               # round 2: orien_loss, eikonal-only without normals (do_normal False), and BASELINE.json's own
               # configurations: 5 x 200 rays x 27 samples, default net, 680x1200 and 480x640
-              "eval_small_orien", "eval_small_eikonly", "eval_base_680x1200_ray", "eval_base_480x640_ray"]
+              "eval_small_orien", "eval_small_eikonly", "eval_base_680x1200_ray", "eval_base_480x640_ray",
+              # round 3: every network SHAPE the kernels are instantiated for and the realsense*.json constants --
+              # hidden_layers_block 3, n_freqs 9 / 10 / 11 (embedding.py:36-72, fc_map.py:77-92), 8 x 512 (BASELINE
+              # configs[4]), 720x1280 with scale_input 0.4 / 0.04, trunc_weight 30, trunc_distance 0.1,
+              # dist_behind_surf 0.01 and NO bounds transform (realsense*.json)
+              "eval_small_b3_f9", "eval_small_b3_f10", "eval_small_b3_f11", "eval_wide_512",
+              "eval_rs_realsense", "eval_rs_franka", "eval_rs_franka_offline"]
 
 
 def _sample(g):
