@@ -114,7 +114,11 @@ typedef struct isdf_sample_args {
    *   draw_u [R,n_strat] (torch.rand, sample.py:123), draw_n [R,n_surf-1]
    *   (torch.normal(0,0.1) on the CPU generator, sample.py:160-162), both
    *   indexed by COMPACTED ray.  rng_mode 1: in-kernel Philox4x32-10 keyed by
-   *   (seed, offset, ray, slot); not stream-compatible with torch.            */
+   *   (seed, offset): counter (drawn ray, 0) for the pixel, one call per four
+   *   consecutive-by-64 output points for the along-ray draws (surface
+   *   offsets: Box-Muller on the two 16-bit halves of a word); deterministic
+   *   for a given (seed, offset, configuration), not stream-compatible with
+   *   torch, and the mapping may change between ABI versions.                 */
   int32_t rng_mode;
   const int64_t* draw_h;
   const int64_t* draw_w;

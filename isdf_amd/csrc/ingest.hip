@@ -12,12 +12,21 @@
 
 namespace isdf {
 
+// A/B switch of round 3: 1 = hardware-rate sqrt / reciprocal (v_sqrt_f32, v_rcp_f32: 1 ulp) instead of
+// the correctly rounded sequences.  Decided by tests/test_gpu_parity.py::test_ingest_normals_vs_reference_fixture
+// (99.9 % of the pixels within 1e-4 of the reference) and profiles/r03_ingest_fastmath.txt.
+#ifndef ISDF_NORMALS_FAST
+#define ISDF_NORMALS_FAST 0
+#endif
+__device__ __forceinline__ float n_sqrt(float x) { return ISDF_NORMALS_FAST ? __builtin_amdgcn_sqrtf(x) : sqrtf(x); }
+__device__ __forceinline__ float n_div(float a, float b) { return ISDF_NORMALS_FAST ? a * __builtin_amdgcn_rcpf(b) : a / b; }
+
 __device__ __forceinline__ void pix_point(const float* __restrict__ depth, int H, int W, int i, int j, float fx,
                                           float fy, float cx, float cy, float& x, float& y, float& z) {
   if (i < 0 || i >= H || j < 0 || j >= W) { x = y = z = __int_as_float(0x7fc00000); return; }   // NaN padding
   z = depth[(int64_t)i * W + j];
-  x = __fmul_rn(z, (float)j - cx) / fx;     // transform.py:190-191
-  y = __fmul_rn(z, (float)i - cy) / fy;
+  x = n_div(__fmul_rn(z, (float)j - cx), fx);     // transform.py:190-191
+  y = n_div(__fmul_rn(z, (float)i - cy), fy);
 }
 
 // One block = 32 x 16 pixels, two per thread (1 594 blocks for a 680x1200 frame: ONE round on 256 CUs x 8 blocks).  The
@@ -52,7 +61,7 @@ __global__ __launch_bounds__(256) void normals_kernel(const float* __restrict__ 
     for (int k = 0; k < 8; ++k) {
       const float x = px[ty + 2 + ly[k]][tx + 2 + lx[k]], y = py[ty + 2 + ly[k]][tx + 2 + lx[k]], z = pz[ty + 2 + ly[k]][tx + 2 + lx[k]];
       qx[k] = x - p1x; qy[k] = y - p1y; qz[k] = z - p1z;
-      len[k] = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(qx[k], qx[k]), __fmul_rn(qy[k], qy[k])), __fmul_rn(qz[k], qz[k])));
+      len[k] = n_sqrt(__fadd_rn(__fadd_rn(__fmul_rn(qx[k], qx[k]), __fmul_rn(qy[k], qy[k])), __fmul_rn(qz[k], qz[k])));
     }
     float best = 0.f; int bk = 0;
 #pragma unroll
@@ -70,9 +79,9 @@ __global__ __launch_bounds__(256) void normals_kernel(const float* __restrict__ 
     const float nx = __fadd_rn(__fmul_rn(ay, bz), -__fmul_rn(az, by));
     const float ny = __fadd_rn(__fmul_rn(az, bx), -__fmul_rn(ax, bz));
     const float nz = __fadd_rn(__fmul_rn(ax, by), -__fmul_rn(ay, bx));
-    const float nn = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(nx, nx), __fmul_rn(ny, ny)), __fmul_rn(nz, nz)));
+    const float nn = n_sqrt(__fadd_rn(__fadd_rn(__fmul_rn(nx, nx), __fmul_rn(ny, ny)), __fmul_rn(nz, nz)));
     float* o = normals + ((int64_t)i * W + j) * 3;
-    o[0] = nx / nn; o[1] = ny / nn; o[2] = nz / nn;
+    o[0] = n_div(nx, nn); o[1] = n_div(ny, nn); o[2] = n_div(nz, nn);
   }
 }
 

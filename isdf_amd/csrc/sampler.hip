@@ -9,22 +9,18 @@
 // (sample.py:58-61): the block-loss bins are built from the ray list instead
 // (optim.hip).
 //
-// ONE launch.  A workgroup (256 threads) takes a chunk of 64 drawn rays: wave 0
-// draws / reads the pixel, gathers depth + normal (one 4-B and one 12-B random
-// read per ray -- the only reads of the keyframe buffers), decides validity and
-// compacts with a ballot; the chunk's offset in the ORDERED output comes, at
-// streaming sizes, from a decoupled look-back over the chunks before it (8-byte
-// {epoch, flag, count} granules, agent-scope stores / polls; chunk ids are
-// handed out by an atomic ticket so a chunk never waits for one that has not
-// started) and, at the reference batch size (<= 4096 rays), from the workgroup
-// re-counting the valid rays before its chunk itself (no communication, one
-// memory round trip).  All four waves
-// then expand the chunk's valid rays into their S samples (z values + world
-// points) with consecutive lanes on consecutive points, i.e. fully coalesced
-// 4-B / 12-B stores: that is where 86 % of the bytes go (432 of 500 B per ray).
-// At the reference batch (1000 rays) this is 16 workgroups and latency-bound;
-// at >= 1e6 rays it is a streaming kernel (bench.py --sampler-scale).
-#include <cstdlib>
+// ONE launch of 1024-thread workgroups (16 waves), two instantiations of one kernel body:
+//   reference batch (<= 4096 drawn rays; 1000 in the BASELINE workload): a workgroup takes a chunk of 64 rays.  Wave 0
+//     draws / reads the pixel and gathers depth + normal + pose (one 4-B and one 12-B random read per ray -- the only
+//     reads of the keyframe buffers) while ALL 16 waves re-count the valid rays BEFORE the chunk themselves: every gather
+//     of the workgroup is in flight together, one memory round trip, no inter-workgroup traffic.
+//   streaming sizes: a chunk is 1024 rays (one per thread); chunk ids come from an atomic ticket (a chunk never waits
+//     for one that has not started) and the chunk's offset in the ORDERED output from a decoupled look-back over
+//     8-byte {epoch, flag, count} granules (agent-scope stores / polls, 64 predecessors per round).
+// All 16 waves then expand the chunk's kept rays into their S samples (z values + world points): a wave takes 256
+// consecutive points, lane l the points l, l+64, l+128, l+192 of them -- every store instruction is fully coalesced
+// (4-B / 12-B per lane), which is where 86 % of the bytes go (432 of 500 B per ray), and in Philox mode ONE
+// Philox4x32-10 call per lane feeds its four points (7.75 calls per ray instead of 28).
 #include "isdf_common.h"
 
 namespace isdf {
@@ -216,7 +212,17 @@ __global__ __launch_bounds__(SMP_NT) void sample_rays_kernel(const isdf_sample_a
 
   // ---- along-ray samples of the chunk's valid rays: point p of the chunk -> (ray j, sample s); consecutive
   // threads write consecutive points (sample.py:131-178)
-  for (int p = tid; p < cnt_ * S; p += NT) {
+  const int npts = cnt_ * S;
+  for (int G = wv; G * 256 < npts; G += NW) {
+    // in-kernel draws: one Philox call per lane and 256-point group, word m for the lane's m-th point; counter
+    // (chunk, 1 + group*64 + lane) never collides with the pixel draws' (ray, 0)
+    uint4 rnd = make_uint4(0u, 0u, 0u, 0u);
+    if (a.rng_mode != 0) rnd = ray_random(a, (uint32_t)c, 1u + (uint32_t)(G * 64 + lane));
+#pragma unroll
+   for (int m = 0; m < 4; ++m) {
+    const int p = G * 256 + m * 64 + lane;
+    if (p >= npts) continue;
+    const uint32_t word = m == 0 ? rnd.x : (m == 1 ? rnd.y : (m == 2 ? rnd.z : rnd.w));
     const int j = p / S, s = p - j * S;
     const int64_t r = (int64_t)base + j;             // compacted ray index: the draws are indexed by it
     const float* sr = sRay[j];
@@ -228,9 +234,9 @@ __global__ __launch_bounds__(SMP_NT) void sample_rays_kernel(const isdf_sample_a
       else {
         float off;
         if (a.rng_mode == 0) off = a.draw_n[r * (a.n_surf - 1) + (s - 1)];
-        else {  // Box-Muller, sigma 0.1 (sample.py:160-162)
-          const uint4 u = ray_random(a, (uint32_t)r, 1u + (uint32_t)s);
-          const float u1 = fmaxf(u01(u.x), 1e-7f), u2 = u01(u.y);
+        else {  // Box-Muller, sigma 0.1 (sample.py:160-162), from the two 16-bit halves of the point's word: radius
+          // resolved to 2^-16 (tail to 4.7 sigma; the offset is clamped to [min_depth, depth + dist_behind_surf] anyway)
+          const float u1 = ((float)(word >> 16) + 0.5f) * (1.f / 65536.f), u2 = (float)(word & 0xffffu) * (1.f / 65536.f);
           off = 0.1f * sqrtf(-2.f * __logf(u1)) * __cosf(6.2831853f * u2);
         }
         z = fminf(fmaxf(__fadd_rn(depth, off), a.min_depth), maxd);  // clamp, sample.py:167-171
@@ -239,7 +245,7 @@ __global__ __launch_bounds__(SMP_NT) void sample_rays_kernel(const isdf_sample_a
       const int k = s - a.n_surf, nb = a.n_strat;
       float U;
       if (a.rng_mode == 0) U = a.draw_u[r * nb + k];
-      else U = u01(ray_random(a, (uint32_t)r, 64u + (uint32_t)k).x);
+      else U = u01(word);
       // torch.linspace(0, 1, nb+1)[k] in fp32 (symmetric evaluation), sample.py:96-98
       const float step = 1.f / (float)nb;
       const float lin = k < (nb + 1) / 2 ? __fmul_rn(step, (float)k) : __fadd_rn(1.f, -__fmul_rn(step, (float)(nb - k)));
@@ -253,6 +259,7 @@ __global__ __launch_bounds__(SMP_NT) void sample_rays_kernel(const isdf_sample_a
 #pragma unroll
     for (int i = 0; i < 3; ++i)  // pc = origins + dirs_W * z, sample.py:176
       o.pc[n * 3 + i] = __fadd_rn(sr[1 + i], __fmul_rn(sr[4 + i], z));
+   }
   }
 
   if (SMALL) return;
@@ -274,7 +281,7 @@ int64_t sample_scan_bytes(int64_t max_rays) { return 16 + 8 * ((max_rays + SMP_C
 
 int launch_sample_rays(const isdf_sample_args& a, const isdf_sample_out& o, void* scan_ws, hipStream_t st) {
   const int total = a.n_frames * a.n_rays;
-  if (total <= SMP_SMALL_MAX_RAYS && !getenv("ISDF_SAMPLER_FORCE_LOOKBACK")) {
+  if (total <= SMP_SMALL_MAX_RAYS) {
     const int nChunks = (total + SMP_CHUNK_SMALL - 1) / SMP_CHUNK_SMALL;
     hipLaunchKernelGGL(sample_rays_kernel<SMP_CHUNK_SMALL>, dim3((unsigned)nChunks), dim3(SMP_NT), 0, st, a, o, (uint32_t*)scan_ws, nChunks);
   } else {

@@ -11,7 +11,7 @@ single-process `mean` exactly even when ranks drop different numbers of
 invalid-depth rays (sample.py:39-55).  No other collective is on the step path:
 keyframe selection stays identical across ranks because its inputs are
 (frame_avg_losses from the reduced bins; a private numpy stream seeded
-identically by graft(), hot_path.HotPath.select_keyframes), and the shared
+identically by graft(), hot_path.HotPath._select_window), and the shared
 virtual clock rides in the same message -- `world` extra floats at its tail,
 one slot per rank holding that rank's PREVIOUS step time (hot_path.HotPath._step).
 Per-FRAME traffic (new keyframe broadcast, keyframe decision) is separate.

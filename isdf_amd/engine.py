@@ -114,31 +114,39 @@ class SampleConfig:
         return self.n_strat + self.n_surf
 
 
-_PINNED_STREAM = None      # (torch.cuda.Stream, c_void_p) while a caller has pinned the launch stream
+_PINNED = {}      # device index -> (torch.cuda.Stream, c_void_p) while a caller has pinned that device's launch stream
 
 
-def _stream():
-    """hipStream_t of torch's current stream.  `torch.cuda.current_stream()` costs ~5 us of host time per call (it
-    re-derives the device index through torch.cuda.is_available() -> os.getenv), which sits in front of every launch of
-    a device-synchronised step: `pinned_stream()` looks it up once per step instead."""
-    if _PINNED_STREAM is not None:
-        return _PINNED_STREAM[1]
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+def _stream(device=None):
+    """hipStream_t of torch's current stream ON `device` (an Engine passes its own device: a trainer on cuda:1 must not
+    launch on cuda:0's stream because that happens to be the current device).  `torch.cuda.current_stream()` costs ~5 us
+    of host time per call, which sits in front of every launch of a device-synchronised step: `pinned_stream()` looks it
+    up once per step instead."""
+    idx = torch.cuda.current_device() if device is None or device.index is None else device.index
+    p = _PINNED.get(idx)
+    if p is not None:
+        return p[1]
+    return C.c_void_p(torch.cuda.current_stream(idx).cuda_stream)
 
 
 class pinned_stream:
-    """with pinned_stream() as st: every Engine call inside launches on `st` (torch's current stream at entry)."""
+    """with pinned_stream(device) as st: every Engine call on that device inside launches on `st` (torch's current
+    stream of the device at entry).  Keyed per device, so trainers on different devices do not overwrite each other."""
+
+    def __init__(self, device=None):
+        self.idx = torch.cuda.current_device() if device is None or torch.device(device).index is None else torch.device(device).index
 
     def __enter__(self):
-        global _PINNED_STREAM
-        self.prev = _PINNED_STREAM
-        st = torch.cuda.current_stream()
-        _PINNED_STREAM = (st, C.c_void_p(st.cuda_stream))
+        self.prev = _PINNED.get(self.idx)
+        st = torch.cuda.current_stream(self.idx)
+        _PINNED[self.idx] = (st, C.c_void_p(st.cuda_stream))
         return st
 
     def __exit__(self, *exc):
-        global _PINNED_STREAM
-        _PINNED_STREAM = self.prev
+        if self.prev is None:
+            _PINNED.pop(self.idx, None)
+        else:
+            _PINNED[self.idx] = self.prev
 
 
 class Engine:
@@ -190,7 +198,7 @@ class Engine:
 
     def pack(self):
         _ffi.check(self.lib.isdf_pack_weights(C.byref(self.cnet), _ffi.ptr(self.params),
-                                              _ffi.ptr(self.shadow), _stream()), "isdf_pack_weights")
+                                              _ffi.ptr(self.shadow), _stream(self.device)), "isdf_pack_weights")
 
     def workspace(self, max_points, train):
         key = (int(max_points), bool(train))
@@ -259,7 +267,7 @@ class Engine:
         if self._scan_ws is None or self._scan_ws.numel() < need:
             self._scan_ws = torch.zeros(max(need, 4096), dtype=torch.uint8, device=dev)
         _ffi.check(self.lib.isdf_sample_rays(C.byref(a), C.byref(o), _ffi.ptr(self._scan_ws), self._scan_ws.numel(),
-                                             _stream()), "isdf_sample_rays")
+                                             _stream(self.device)), "isdf_sample_rays")
         out["max_rays"] = R0
         out["S"] = S
         out["n_frames"] = F
@@ -279,7 +287,7 @@ class Engine:
         nz = None if noise is None else noise.reshape(-1).to(device=self.device, dtype=torch.float32).contiguous()
         _ffi.check(self.lib.isdf_sdf_eval(C.byref(self.cnet), _ffi.ptr(self.params), _ffi.ptr(self.shadow),
                                           _ffi.ptr(x), n, _ffi.ptr(nz), _ffi.ptr(sdf), _ffi.ptr(grad),
-                                          _ffi.ptr(ws), 0 if ws is None else ws.numel(), _stream()),
+                                          _ffi.ptr(ws), 0 if ws is None else ws.numel(), _stream(self.device)),
                    "isdf_sdf_eval")
         if want_grad:
             return sdf.view(*shp), grad.view(*shp, 3)
@@ -335,7 +343,7 @@ class Engine:
             _ffi.check(self.lib.isdf_bounds_pc(_ffi.ptr(smp["n_valid"]), R0, S, _ffi.ptr(smp["pc"]),
                                                _ffi.ptr(smp["z_vals"]), _ffi.ptr(smp["depth_sample"]),
                                                _ffi.ptr(surf), 0 if surf is None else surf.shape[0],
-                                               _ffi.ptr(pb), _ffi.ptr(pg), _stream()), "isdf_bounds_pc")
+                                               _ffi.ptr(pb), _ffi.ptr(pg), _stream(self.device)), "isdf_bounds_pc")
             a.pc_bounds, a.pc_grad_vec = pb.data_ptr(), pg.data_ptr()
             keep += [pb, pg]
         o = _ffi.StepOut()
@@ -353,12 +361,12 @@ class Engine:
         if optim is not None:
             q = self._optim_args(optim, F, dbg, keep)
             _ffi.check(self.lib.isdf_train_step_adamw(C.byref(self.cnet), C.byref(closs), C.byref(a), C.byref(o),
-                                                      C.byref(q), _ffi.ptr(ws), ws.numel(), _stream()),
+                                                      C.byref(q), _ffi.ptr(ws), ws.numel(), _stream(self.device)),
                        "isdf_train_step_adamw")
         else:
             _ffi.check(self.lib.isdf_train_step(C.byref(self.cnet), C.byref(closs), _ffi.ptr(self.params),
                                                 _ffi.ptr(self.shadow), C.byref(a), C.byref(o), _ffi.ptr(ws),
-                                                ws.numel(), _stream()), "isdf_train_step")
+                                                ws.numel(), _stream(self.device)), "isdf_train_step")
         dbg["_keep"] = keep
         return dbg
 
@@ -390,7 +398,7 @@ class Engine:
         dbg, keep = {}, []
         q = self._optim_args(optim, n_frames, dbg, keep)
         _ffi.check(self.lib.isdf_train_step_finish(C.byref(self.cnet), C.byref(q), _ffi.ptr(self.reduce_buf), int(n_frames),
-                                                   _stream()), "isdf_train_step_finish")
+                                                   _stream(self.device)), "isdf_train_step_finish")
         dbg["_keep"] = keep
         return dbg
 
@@ -412,7 +420,7 @@ class Engine:
             assert index is None or (index.dtype == torch.int32 and index.numel() == n_frames)
             fa = out
         _ffi.check(self.lib.isdf_frame_avg(_ffi.ptr(self.reduce_buf), self.n_params, n_frames, _ffi.ptr(la),
-                                           _ffi.ptr(fa), _ffi.ptr(index), _stream()), "isdf_frame_avg")
+                                           _ffi.ptr(fa), _ffi.ptr(index), _stream(self.device)), "isdf_frame_avg")
         return la, fa
 
     # ---- per-frame ingest / keyframe test -------------------------------
@@ -421,7 +429,7 @@ class Engine:
         d = depth.to(device=self.device, dtype=torch.float32).contiguous()
         out = torch.empty(d.shape[0], d.shape[1], 3, dtype=torch.float32, device=self.device)
         _ffi.check(self.lib.isdf_estimate_normals(_ffi.ptr(d), d.shape[0], d.shape[1], sc.fx, sc.fy, sc.cx, sc.cy,
-                                                  _ffi.ptr(out), _stream()), "isdf_estimate_normals")
+                                                  _ffi.ptr(out), _stream(self.device)), "isdf_estimate_normals")
         return out
 
     def render_depth(self, z_vals, sdf, depth_sample=None, kf_dist_th=0.1, n_valid=None):
@@ -431,7 +439,7 @@ class Engine:
         below = torch.zeros(1, dtype=torch.int32, device=self.device)
         _ffi.check(self.lib.isdf_render_depth(_ffi.ptr(n_valid), R, R, S, _ffi.ptr(z_vals.contiguous()),
                                               _ffi.ptr(sdf.contiguous()), _ffi.ptr(depth_sample), float(kf_dist_th),
-                                              _ffi.ptr(view), _ffi.ptr(below), _stream()), "isdf_render_depth")
+                                              _ffi.ptr(view), _ffi.ptr(below), _stream(self.device)), "isdf_render_depth")
         return view, below
 
     # ---- AdamW ----------------------------------------------------------------------
@@ -445,4 +453,4 @@ class Engine:
                                        _ffi.ptr(self.exp_avg_sq), _ffi.ptr(self.reduce_buf), _ffi.ptr(cnt),
                                        float(grad_scale), float(lr), float(betas[0]), float(betas[1]),
                                        float(eps), float(weight_decay), int(self.opt_step),
-                                       _ffi.ptr(self.shadow), _stream()), "isdf_adamw")
+                                       _ffi.ptr(self.shadow), _stream(self.device)), "isdf_adamw")

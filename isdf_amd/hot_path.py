@@ -328,7 +328,7 @@ class HotPath:
         if self._hip.device.type != "cuda":
             return self._step(None)
         from .engine import pinned_stream
-        with pinned_stream() as st:
+        with torch.cuda.device(self._hip.device), pinned_stream(self._hip.device) as st:
             return self._step(st)
 
     def _step(self, st):
@@ -337,7 +337,7 @@ class HotPath:
 
         K = self.frames.T_WC_batch.shape[0]
         if len(self.frames) > self.window_size and self.incremental:
-            idxs = self.select_keyframes()             # replicated under data parallelism without a collective (below)
+            idxs = self._select_window()               # the reference's select_keyframes; replicated under data parallelism
         else:
             idxs = np.arange(K)
         self.active_idxs = idxs
@@ -398,19 +398,19 @@ class HotPath:
         self.steps_since_frame += 1
         return losses, step_time
 
-    def select_keyframes(self):
-        """The reference's window draw (trainer.py:652-674) runs unchanged.  Under data parallelism every rank must pick
-        the SAME window, and it does without a collective: the inputs are bit-identical on every rank
+    def _select_window(self):
+        """The reference's window draw (`select_keyframes`, trainer.py:652-674) runs unchanged.  Under data parallelism
+        every rank must pick the SAME window, and it does without a collective: the inputs are bit-identical on every rank
         (`frames.frame_avg_losses` comes from the all-reduced bins) and `np.random.choice` draws from a private stream
         that graft() seeded identically everywhere -- swapped in for the call, so nothing else that touches numpy's
         global generator on one rank can de-synchronise it."""
         hip = self._hip
         if hip.dist_group is None:
-            return super().select_keyframes()
+            return self.select_keyframes()
         saved = np.random.get_state()
         np.random.set_state(hip.window_rng_state)
         try:
-            return super().select_keyframes()
+            return self.select_keyframes()
         finally:
             hip.window_rng_state = np.random.get_state()
             np.random.set_state(saved)
@@ -425,14 +425,16 @@ class HotPath:
                                         _shared_key=hip.dist_group is not None)
         s = sample_pts["_raw"]
         pc = s["pc"]
+        n = int(sample_pts["pc"].shape[0])           # R valid rays (sample_points already synchronised on it)
         noise = None
-        if self.noise_std is not None:
-            noise = torch.randn(pc.shape[:-1], device=hip.device) * self.noise_std
+        if self.noise_std is not None:               # drawn on the CUT tensor like upstream (trainer.py:594-595,
+            noise = torch.zeros(pc.shape[:-1], device=hip.device)     # fc_map.py:106): the generator advances by R x S
+            noise[:n] = torch.randn(n, pc.shape[1], device=hip.device) * self.noise_std
         sdf = self.frozen_sdf_map.engine.sdf_eval(pc, noise=noise)           # frozen net, no grad (trainer.py:594-595)
         view, below = self.engine.render_depth(s["z_vals"], sdf, s["depth_sample"], self.kf_dist_th,
                                                n_valid=s["n_valid"])
-        n = int(s["n_valid"].item())
-        below_th_prop = float(below.item()) / max(n, 1)
+        # no valid ray: upstream divides 0 by 0 -> NaN -> `NaN < ratio` is False (trainer.py:606-609)
+        below_th_prop = float(below.item()) / n if n > 0 else float("nan")
         is_keyframe = below_th_prop < self.kf_pixel_ratio
         print("Proportion of loss below threshold", below_th_prop, "for KF should be less than",
               self.kf_pixel_ratio, " ---> is keyframe:", is_keyframe)
@@ -473,9 +475,13 @@ class HotPath:
             "model_state_dict": {k: v.detach().clone() for k, v in self.sdf_map.state_dict().items()},
             "optimizer_state_dict": self.optimiser.state_dict(),
             "frozen_state_dict": None if frozen is None else {k: v.detach().clone() for k, v in frozen.state_dict().items()},
+            # EVERY field of the keyframe store (data_util.py:11-43): the device batches the hot path reads AND the host
+            # twins / tracked / ground-truth poses / frame count the reference's visualisation and evaluation index
+            # (trainer.py:1021-1067,1152-1157,1228-1231) -- a resumed run appends to all of them consistently
             "frames": {k: (None if getattr(fr, k, None) is None else
-                           (getattr(fr, k).copy() if isinstance(getattr(fr, k), np.ndarray) else getattr(fr, k).clone()))
-                       for k in ("frame_id", "im_batch", "depth_batch", "T_WC_batch", "normal_batch", "frame_avg_losses")},
+                           (getattr(fr, k).copy() if isinstance(getattr(fr, k), np.ndarray) else
+                            (getattr(fr, k).clone() if torch.is_tensor(getattr(fr, k)) else copy.deepcopy(getattr(fr, k)))))
+                       for k in FRAME_FIELDS if hasattr(fr, k)},
             "clock": dict(tot_step_time=self.tot_step_time, steps_since_frame=self.steps_since_frame,
                           last_is_keyframe=self.last_is_keyframe, optim_frames=self.optim_frames,
                           noise_std=self.noise_std, step_count=hip.step_count),
@@ -496,6 +502,11 @@ class HotPath:
         fr = type(self.frames)()
         for k, v in f.items():
             setattr(fr, k, v)
+        # checkpoints written before the host twins were saved: rebuild them from the device batches so that the next
+        # add_frame_data appends at the right length
+        for twin, src in (("im_batch_np", "im_batch"), ("depth_batch_np", "depth_batch"), ("T_WC_batch_np", "T_WC_batch")):
+            if twin not in f and getattr(fr, src, None) is not None and hasattr(fr, twin):
+                setattr(fr, twin, getattr(fr, src).detach().cpu().numpy())
         self.frames = fr
         c = sd["clock"]
         self.tot_step_time, self.steps_since_frame = c["tot_step_time"], c["steps_since_frame"]
@@ -510,6 +521,10 @@ class HotPath:
         if r.get("torch_cuda") is not None:
             torch.cuda.set_rng_state(r["torch_cuda"], hip.device)
 
+
+# data_util.FrameData's fields (isdf/datasets/data_util.py:11-43) incl. the reference's frame counter
+FRAME_FIELDS = ("frame_id", "im_batch", "im_batch_np", "depth_batch", "depth_batch_np", "T_WC_batch", "T_WC_batch_np",
+                "normal_batch", "frame_avg_losses", "T_WC_track", "T_WC_gt", "count")
 
 ENGINE_FACTORY = None      # host-logic tests on GPU-less machines install an oracle-backed stand-in here; never set by the product
 
@@ -551,14 +566,18 @@ def graft(trainer, rng="philox", seed=1, dist_group=None, fix_normal_window=Fals
                                    transform=pe_old.transform)
         n_block = len(old.mid1)
         hidden = old.out_alpha.in_features
-        new = SDFMapHIP(pe, hidden_size=hidden, hidden_layers_block=n_block, scale_output=old.scale_output,
-                        device=dev, fwd_operand=fwd_operand, engine_factory=engine_factory)
+        with torch.random.fork_rng(devices=[]):    # grafting mid-run must not advance the caller's generator: the initial
+            new = SDFMapHIP(pe, hidden_size=hidden, hidden_layers_block=n_block, scale_output=old.scale_output,   # weights
+                            device=dev, fwd_operand=fwd_operand, engine_factory=engine_factory)    # are overwritten below
         new.load_state_dict({k: v.detach() for k, v in old.state_dict().items()})
         new.train(old.training)
         trainer.sdf_map = new
         og = trainer.optimiser.param_groups[0]
+        old_state = trainer.optimiser.state_dict()
         trainer.optimiser = FlatAdamW(new, lr=og["lr"], weight_decay=og["weight_decay"], betas=tuple(og["betas"]),
                                       eps=og["eps"])
+        if old_state.get("state"):     # a trainer that has already stepped (or loaded optimiser state): keep exp_avg /
+            trainer.optimiser.load_state_dict(old_state)    # exp_avg_sq / step; parameter order = named_parameters() order
         if getattr(trainer, "frozen_sdf_map", None) is not None:
             fz = copy.deepcopy(new)
             fz.load_state_dict({k: v.detach() for k, v in trainer.frozen_sdf_map.state_dict().items()})

@@ -94,9 +94,10 @@ class SDFMapHIP(nn.Module):
     def __deepcopy__(self, memo):
         """`copy.deepcopy(self.sdf_map)` (trainer.py:576): a frozen snapshot with its own buffers."""
         pe = copy.copy(self.positional_encoding)
-        new = SDFMapHIP(pe, self.engine.net.hidden, self.engine.net.blocks, self.scale_output,
-                        device=self.engine.device, fwd_operand=self.engine.net.fwd_operand,
-                        engine_factory=self._engine_factory)
+        with torch.random.fork_rng(devices=[]):    # the throw-away initial weights must not advance the caller's generator
+            new = SDFMapHIP(pe, self.engine.net.hidden, self.engine.net.blocks, self.scale_output,   # (upstream's deepcopy
+                            device=self.engine.device, fwd_operand=self.engine.net.fwd_operand,      # draws nothing)
+                            engine_factory=self._engine_factory)
         new.engine.params.copy_(self.engine.params)
         new.engine.pack()
         new.train(self.training)

@@ -912,23 +912,41 @@ def test_realsense_config_nets_match_oracle(blocks, n_freqs, E):
     assert torch.equal(kept, eng.shadow)
 
 
-def test_sampler_lookback_mode_at_reference_batch_size(monkeypatch):
-    """the streaming-mode compaction (ticket + decoupled look-back) forced onto the 5 x 200-ray batch: bit-identical
-    to the reference fixture and to the small-batch mode"""
-    g = gu.load("eval_base_480x640_ray")
-    eng = _engine(g)
-    lc, sc = _cfgs(g)
-    a = _sample_hip(eng, g, sc)
-    monkeypatch.setenv("ISDF_SAMPLER_FORCE_LOOKBACK", "1")
-    for rep in range(3):
-        b = _sample_hip(eng, g, sc)
+def test_sampler_philox_draws_are_in_distribution_and_deterministic():
+    """rng_mode 1 (in-kernel Philox; one call feeds four output points): pixels uniform over the image, one stratified
+    sample per bin and uniform inside it (sample.py:96-128), surface offsets N(0, 0.1) before the clamp (sample.py:160-171);
+    same (seed, offset) -> same draws, another offset -> other draws; both compaction modes."""
+    from isdf_amd.engine import Engine, NetConfig, SampleConfig
+    cam = dict(H=120, W=160, fx=150.0, fy=150.0, cx=79.5, cy=59.5)
+    F = 2
+    depth = np.full((F, cam["H"], cam["W"]), 3.0, np.float32)          # constant depth: bins and clamps are known
+    T = np.tile(np.eye(4, dtype=np.float32), (F, 1, 1))
+    eng = Engine(NetConfig(), "cuda")
+    idx = torch.arange(F, dtype=torch.int32, device="cuda")
+    for n in (1500, 40000):                                            # 3000 rays: re-count mode; 80000: look-back mode
+        sc = SampleConfig(n_rays=n, **cam)
+        run = lambda off: eng.sample(_dev(depth), _dev(T), None, idx, None, sc, seed=11, offset=off)
+        a, b, c = run(5), run(5), run(6)
         torch.cuda.synchronize()
-        R = int(b["n_valid"].item())
-        assert R == g["depth_sample"].shape[0] == int(a["n_valid"].item())
-        for k in ("indices_b", "indices_h", "indices_w", "depth_sample", "norm_sample", "dirs_C_sample", "dirs_W_sample",
-                  "T_WC_sample", "z_vals", "pc"):
-            assert torch.equal(a[k][:R], b[k][:R]), k
-        assert np.array_equal(b["indices_h"][:R].cpu().numpy(), g["indices_h"])
+        R = int(a["n_valid"].item())
+        assert R == F * n
+        for k in ("indices_h", "indices_w", "z_vals", "pc"):
+            assert torch.equal(a[k], b[k]), k
+        assert not torch.equal(a["z_vals"], c["z_vals"]) and not torch.equal(a["indices_h"], c["indices_h"])
+        h, w = a["indices_h"].cpu().numpy(), a["indices_w"].cpu().numpy()
+        assert h.min() == 0 and h.max() == cam["H"] - 1 and w.min() == 0 and w.max() == cam["W"] - 1
+        assert abs(h.mean() / (cam["H"] - 1) - 0.5) < 0.02 and abs(w.mean() / (cam["W"] - 1) - 0.5) < 0.02
+        z = a["z_vals"].cpu().numpy().astype(np.float64)
+        lo, hi = sc.min_depth, 3.0 + sc.dist_behind_surf
+        u = (z[:, sc.n_surf:] - lo) / ((hi - lo) / sc.n_strat) - np.arange(sc.n_strat)[None, :]   # position inside the bin
+        assert u.min() >= -1e-4 and u.max() <= 1 + 1e-4
+        assert abs(u.mean() - 0.5) < 0.01 and abs(u.std() - 12 ** -0.5) < 0.01
+        assert abs(np.corrcoef(u[:, 0], u[:, 1])[0, 1]) < 0.05 and abs(np.corrcoef(u[:-1, 3], u[1:, 3])[0, 1]) < 0.05
+        off = z[:, 1:sc.n_surf] - 3.0
+        free = off < sc.dist_behind_surf - 1e-6                         # not clamped at depth + dist_behind_surf
+        assert 0.80 < free.mean() < 0.88                                # P(N(0, 0.1) < 0.1) = 0.841
+        assert abs(off[off < 0].std() / 0.1 - 0.6028) < 0.02            # half-normal: sigma * sqrt(1 - 2/pi)
+        assert abs((off < 0).mean() - 0.5) < 0.01
 
 
 def test_sampler_ordered_compaction_at_a_million_rays():

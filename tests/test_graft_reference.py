@@ -96,6 +96,36 @@ def test_grafted_reference_trainer_reproduces_reference_step_trajectory(ref_mods
 
 
 @needs_ref
+def test_graft_after_reference_steps_keeps_the_optimiser_state(ref_mods):
+    """a reference Trainer that has ALREADY taken optimiser steps keeps exp_avg / exp_avg_sq / step through
+    graft() -- one reference step + two grafted steps == three steps (fixture step_small_k7: windows, draws, AdamW)."""
+    mg, mods = ref_mods
+    from isdf_amd.hot_path import graft
+    g = gu.load("step_small_k7")
+    tr = _reference_trainer(mg, mods, g, int(g["window_size"][0]))
+    tr.frames.frame_avg_losses = torch.from_numpy(g["frame_avg_losses0"].copy())
+    seed = int(g["seed"][0])
+    np.random.seed(seed); torch.manual_seed(seed)
+    with contextlib.redirect_stdout(io.StringIO()):
+        tr.step()                                                            # the reference's own step (torch AdamW)
+        assert float(tr.optimiser.state_dict()["state"][0]["step"]) == 1.0
+        graft(tr, rng="torch", engine_factory=FakeEngine)
+    st = tr.optimiser.state_dict()["state"]
+    assert float(st[0]["step"]) == 1.0 and float(st[0]["exp_avg"].abs().sum()) > 0   # carried over, not reset
+    for s in range(1, int(g["n_steps"][0])):
+        losses, _ = tr.step()
+        assert list(tr.active_idxs) == list(g["s%d/idxs" % s])
+        ref = g["s%d/total_loss" % s][0]
+        assert abs(float(losses["total_loss"]) - ref) < 1e-4 * abs(ref), (s, float(losses["total_loss"]), ref)
+    st = tr.optimiser.state_dict()["state"]
+    for i, k in enumerate(gu.params_of(g)):
+        assert gu.rel_err(tr.sdf_map.state_dict()[k].numpy(), g["param_after/" + k]) < 2e-4, k
+        assert gu.rel_err(st[i]["exp_avg"].numpy(), g["exp_avg/" + k]) < 2e-3, k
+        assert gu.rel_err(st[i]["exp_avg_sq"].numpy(), g["exp_avg_sq/" + k]) < 4e-3, k
+        assert float(st[i]["step"]) == 3.0
+
+
+@needs_ref
 def test_integration_md_snippet_runs_on_the_reference_trainer(ref_mods, monkeypatch):
     """The code block INTEGRATION.md tells a maintainer to add is executed VERBATIM on a real reference Trainer
     (the engine stand-in is installed through the module hook, because this container has no GPU)."""
@@ -226,6 +256,12 @@ def test_reference_driver_loop_on_hiptrainer_standin():
     tr2 = HipTrainer("cpu", cfg, inv_bounds_transform=gu.bounds_transform(), rng="philox", seed=3,
                      virtual_step_ms=12.0, engine_factory=FakeEngine)
     tr2.load_state_dict(sd)
+    # every FrameData field is resumed: the host twins have the keyframe count, so the next ingest appends
+    # / overwrites consistently instead of restarting them at length 1
+    for k in ("depth_batch_np", "T_WC_batch_np", "im_batch_np"):
+        a_, b_ = getattr(tr.frames, k, None), getattr(tr2.frames, k, None)
+        assert (a_ is None) == (b_ is None) and (a_ is None or (len(a_) == len(tr.frames) and np.array_equal(a_, b_))), k
+    assert len(tr2.frames) == len(tr.frames)
     with contextlib.redirect_stdout(io.StringIO()):
         a, b = tr.check_keyframe_latest(), tr2.check_keyframe_latest()
     assert a == b and tr.last_is_keyframe == tr2.last_is_keyframe

@@ -16,7 +16,7 @@ def main():
     for name, flags in variants:
         mine = dict(objs)
         jobs = []
-        for src in ("chain.hip", "chain_pair.hip", "dw.hip", "optim.hip", "sampler.hip"):
+        for src in ("chain.hip", "dw.hip", "optim.hip", "sampler.hip", "ingest.hip", "capi.hip"):
             if not flags:
                 continue
             o = os.path.join(ROOT, "variants", "%s_%s.o" % (name, src[:-4]))
