@@ -192,6 +192,15 @@ typedef struct isdf_step_args {
   uint64_t noise_offset;      /* (fc_map.py:106-108)                            */
   const float* pc_bounds;     /* [max_rays,S]   bounds_method "pc" only        */
   const float* pc_grad_vec;   /* [max_rays,S,3] bounds_method "pc" only        */
+  /* caller-owned tail of the reduction message (data parallel): reduce_buf may be
+   * followed by `extra_floats` floats that ride in the same all-reduce; the step
+   * writes extra_value into slot extra_slot and 0 into the others (one slot per
+   * rank: after the SUM all-reduce every rank holds every rank's value -- the
+   * host mirror carries the ranks' step times this way, no second collective) */
+  int32_t extra_floats;
+  int32_t extra_slot;
+  float extra_value;
+  int32_t reserved1;
 } isdf_step_args;
 
 typedef struct isdf_step_out {
@@ -203,6 +212,11 @@ typedef struct isdf_step_out {
   void** prof_events;   /* optional HOST array of 4 hipEvent_t recorded on `stream`:
                            [0] before the chain kernel, [1] after it, [2] after
                            the dW kernel, [3] after the reductions (bench.py)    */
+  float* host_mailbox;  /* optional PINNED HOST memory (device-mapped, >= 8 floats): the
+                           step's last launch also stores loss_sums[8] there, so the
+                           `losses` of Trainer.step (trainer.py:1016; loss.py:187-200)
+                           need no device->host copy command -- they are valid after the
+                           caller's closing stream synchronisation (metrics.py:27-30)   */
 } isdf_step_out;
 
 /* layout of loss_sums inside reduce_buf (after the n_params gradient floats) */
@@ -252,7 +266,9 @@ int isdf_train_step_adamw(const isdf_net_cfg* net, const isdf_loss_cfg* loss, co
  * isdf_train_step + all-reduce + isdf_train_step_finish == isdf_train_step_adamw on the union batch
  * (tests/test_dp_gpu.py).                                                                                          */
 int isdf_train_step_finish(const isdf_net_cfg* net, const isdf_optim_args* opt, const float* reduce_buf,
-                           int32_t n_frames, void* stream);
+                           int32_t n_frames, int32_t extra_floats, float* host_mailbox, void* stream);
+/* extra_floats / host_mailbox (optional, pinned host memory of 8 + extra_floats floats): the same launch stores the
+ * REDUCED loss_sums[8] followed by the message's caller-owned tail there (isdf_step_args.extra_floats).          */
 
 /* nearest-surface-point bounds (bounds_method "pc", loss.py:56-89): for every sample point the distance to
  * the nearest SURFACE sample (sign from z vs depth) and the unit vector from it.  surf_pts == NULL: the

@@ -64,12 +64,13 @@ class StepArgs(C.Structure):
                 ("indices_w", C.c_void_p), ("noise", C.c_void_p), ("noise_std", C.c_float),
                 ("reserved0", C.c_uint32), ("noise_seed", C.c_uint64), ("noise_offset", C.c_uint64),
                 ("pc_bounds", C.c_void_p),
-                ("pc_grad_vec", C.c_void_p)]
+                ("pc_grad_vec", C.c_void_p), ("extra_floats", C.c_int32), ("extra_slot", C.c_int32),
+                ("extra_value", C.c_float), ("reserved1", C.c_int32)]
 
 
 class StepOut(C.Structure):
     _fields_ = [("reduce_buf", C.c_void_p), ("sdf", C.c_void_p), ("sdf_grad", C.c_void_p),
-                ("tot_loss_mat", C.c_void_p), ("prof_events", C.POINTER(C.c_void_p))]
+                ("tot_loss_mat", C.c_void_p), ("prof_events", C.POINTER(C.c_void_p)), ("host_mailbox", C.c_void_p)]
 
 
 class OptimArgs(C.Structure):
@@ -116,7 +117,7 @@ def lib():
     L.isdf_sdf_eval.argtypes = [P(NetCfg), vp, vp, vp, i64, vp, vp, vp, vp, i64, vp]
     L.isdf_train_step.argtypes = [P(NetCfg), P(LossCfg), vp, vp, P(StepArgs), P(StepOut), vp, i64, vp]
     L.isdf_train_step_adamw.argtypes = [P(NetCfg), P(LossCfg), P(StepArgs), P(StepOut), P(OptimArgs), vp, i64, vp]
-    L.isdf_train_step_finish.argtypes = [P(NetCfg), P(OptimArgs), vp, i32, vp]
+    L.isdf_train_step_finish.argtypes = [P(NetCfg), P(OptimArgs), vp, i32, i32, vp, vp]
     L.isdf_bounds_pc.argtypes = [vp, i32, i32, vp, vp, vp, vp, i64, vp, vp, vp]
     L.isdf_frame_avg.argtypes = [vp, i64, i32, vp, vp, vp, vp]
     L.isdf_adamw.argtypes = [P(NetCfg), vp, vp, vp, vp, vp, f32, f32, f32, f32, f32, f32, i32, vp, vp]

@@ -18,13 +18,14 @@ int launch_pack(const NetLayout& L, const float* params, uint16_t* shadow, hipSt
 int launch_adamw_pack(const NetLayout& L, float* params, float* m, float* v, uint16_t* shadow, const float* grad,
                       const float* count_ptr, float grad_scale, float lr, float b1, float b2, float eps, float wd,
                       int step, hipStream_t st, int n_frames = 0, const float* bl = nullptr, const float* bc = nullptr,
-                      float* la = nullptr, float* fa = nullptr, const int32_t* fa_index = nullptr);
+                      float* la = nullptr, float* fa = nullptr, const int32_t* fa_index = nullptr,
+                      const float* loss_sums = nullptr, const float* extra = nullptr, int n_extra = 0, float* mailbox = nullptr);
 int launch_step_tail(int phase, const NetLayout& L, const float* dwPart, const float* vecPart, int vecStride, float* grad,
                      float* params, float* m, float* v, uint16_t* shadow, float grad_scale, float lr, float b1, float b2,
                      float eps, float wd, int step, const float* wg_loss, int64_t maxTiles, const int32_t* n_valid, int S,
                      const float* tot_ws, const int64_t* ib, const int64_t* ih, const int64_t* iw, int F, int H, int W,
                      float* loss_sums, float* bl, float* bc, float* la_out, float* fa_out, const int32_t* fa_index,
-                     hipStream_t st);
+                     hipStream_t st, float* mailbox, float* extra, int n_extra, int extra_slot, float extra_value);
 int launch_frame_avg(const float* bl, const float* bc, int F, float* la, float* fa, const int32_t* fa_index,
                      hipStream_t st);
 int launch_bounds_pc(const int32_t* n_valid, int max_rays, int S, const float* pc, const float* z, const float* depth,
@@ -186,12 +187,16 @@ static int train_step_impl(const isdf_net_cfg* net, const isdf_loss_cfg* loss, c
   float* lossSums = o->reduce_buf + l.n_params;
   float* blockLoss = lossSums + 8;
   float* blockCnt = blockLoss + (int64_t)a->n_frames * 64;
+  float* extra = blockCnt + (int64_t)a->n_frames * 64;   // caller-owned tail (extra_floats), right behind isdf_reduce_floats
+  if (a->extra_floats < 0 || a->extra_floats > 1016 || (a->extra_floats > 0 && (a->extra_slot < 0 || a->extra_slot >= a->extra_floats)))
+    return ISDF_EINVAL;
   if (opt) {   // single-GPU tail: slab reduction + AdamW + operand repack + loss/bin finalisation in one launch
     rc = launch_step_tail(0, l, dwPart, vecPart, w.vecStride, o->reduce_buf, opt->params, opt->exp_avg, opt->exp_avg_sq,
                           (uint16_t*)opt->shadow, opt->grad_scale, opt->lr, opt->beta1, opt->beta2, opt->eps,
                           opt->weight_decay, opt->step, wgLoss, w.nTiles, a->n_valid, a->S, totLoss, a->indices_b,
                           a->indices_h, a->indices_w, a->n_frames, a->H, a->W, lossSums, blockLoss, blockCnt,
-                          opt->loss_approx, opt->frame_avg, opt->frame_avg_index, st);
+                          opt->loss_approx, opt->frame_avg, opt->frame_avg_index, st, o->host_mailbox, extra, a->extra_floats,
+                          a->extra_slot, a->extra_value);
     if (rc) return rc;
     if (ev && hipEventRecord(ev[3], st) != hipSuccess) return ISDF_EHIP;
     return ISDF_OK;
@@ -201,7 +206,7 @@ static int train_step_impl(const isdf_net_cfg* net, const isdf_loss_cfg* loss, c
   rc = launch_step_tail(1, l, dwPart, vecPart, w.vecStride, o->reduce_buf, nullptr, nullptr, nullptr, nullptr, 1.f, 0.f,
                         0.f, 0.f, 0.f, 0.f, 1, wgLoss, w.nTiles, a->n_valid, a->S, totLoss, a->indices_b, a->indices_h,
                         a->indices_w, a->n_frames, a->H, a->W, lossSums, blockLoss, blockCnt, nullptr, nullptr, nullptr,
-                        st);
+                        st, o->host_mailbox, extra, a->extra_floats, a->extra_slot, a->extra_value);
   if (rc) return rc;
   if (ev && hipEventRecord(ev[3], st) != hipSuccess) return ISDF_EHIP;
   return ISDF_OK;
@@ -222,7 +227,7 @@ int isdf_train_step_adamw(const isdf_net_cfg* net, const isdf_loss_cfg* loss, co
 }
 
 int isdf_train_step_finish(const isdf_net_cfg* net, const isdf_optim_args* opt, const float* reduce_buf, int32_t n_frames,
-                           void* stream) {
+                           int32_t extra_floats, float* host_mailbox, void* stream) {
   isdf_clear_stale_hip_error();
   NetLayout l; int rc = make_layout(net, &l);
   if (rc) return rc;
@@ -230,13 +235,15 @@ int isdf_train_step_finish(const isdf_net_cfg* net, const isdf_optim_args* opt, 
   if (!opt || !opt->params || !opt->exp_avg || !opt->exp_avg_sq || !opt->shadow || opt->step < 1 || !reduce_buf) return ISDF_EINVAL;
   if ((opt->loss_approx == nullptr) != (opt->frame_avg == nullptr)) return ISDF_EINVAL;   // both or neither
   if (opt->loss_approx && n_frames < 1) return ISDF_EINVAL;
+  if (extra_floats < 0 || extra_floats > 1016 || n_frames < 0) return ISDF_EINVAL;
   const float* lossSums = reduce_buf + l.n_params;
   const float* bl = lossSums + 8;
   const int F = opt->loss_approx ? n_frames : 0;
   return launch_adamw_pack(l, opt->params, opt->exp_avg, opt->exp_avg_sq, (uint16_t*)opt->shadow, reduce_buf,
                            lossSums + ISDF_LS_COUNT, opt->grad_scale, opt->lr, opt->beta1, opt->beta2, opt->eps,
                            opt->weight_decay, opt->step, (hipStream_t)stream, F, bl, bl + (int64_t)n_frames * 64,
-                           opt->loss_approx, opt->frame_avg, opt->frame_avg_index);
+                           opt->loss_approx, opt->frame_avg, opt->frame_avg_index, lossSums, bl + (int64_t)n_frames * 128,
+                           extra_floats, host_mailbox);
 }
 
 int isdf_bounds_pc(const int32_t* n_valid, int32_t max_rays, int32_t S, const float* pc, const float* z_vals,

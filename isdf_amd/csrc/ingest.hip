@@ -6,20 +6,17 @@
 // The reference runs the normal estimation as ~10 eager ops with a 70 MB index
 // tensor per 680x1200 frame (0.37 s on 8 CPU threads).  Here it is one stencil
 // pass: 4 B read + 12 B written per pixel, 13 MB per 680x1200 frame (2.5 us of HBM
-// time).  Measured 13.5 us: the pass is VALU-bound -- ~600 instructions per pixel (eight
-// correctly rounded sqrt, five IEEE divisions, the argmin with the reference's NaN rule).
+// time).  The pass is VALU-bound (nine square roots, five divisions and the argmin with the
+// reference's NaN rule per pixel): 13.1 us per frame with correctly rounded sqrt / division, 9.0 us
+// with the hardware-rate v_sqrt_f32 / v_rcp_f32 (1 ulp) it ships with -- the reference fixture
+// (99.9 % of the pixels within 1e-4) passes either way: profiles/r03_ingest_fastmath.txt.
 #include "isdf_common.h"
 
 namespace isdf {
 
-// A/B switch of round 3: 1 = hardware-rate sqrt / reciprocal (v_sqrt_f32, v_rcp_f32: 1 ulp) instead of
-// the correctly rounded sequences.  Decided by tests/test_gpu_parity.py::test_ingest_normals_vs_reference_fixture
-// (99.9 % of the pixels within 1e-4 of the reference) and profiles/r03_ingest_fastmath.txt.
-#ifndef ISDF_NORMALS_FAST
-#define ISDF_NORMALS_FAST 0
-#endif
-__device__ __forceinline__ float n_sqrt(float x) { return ISDF_NORMALS_FAST ? __builtin_amdgcn_sqrtf(x) : sqrtf(x); }
-__device__ __forceinline__ float n_div(float a, float b) { return ISDF_NORMALS_FAST ? a * __builtin_amdgcn_rcpf(b) : a / b; }
+// hardware-rate square root and reciprocal (1 ulp each): the 1e-4 bar on the normals does not need correct rounding
+__device__ __forceinline__ float n_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+__device__ __forceinline__ float n_div(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
 
 __device__ __forceinline__ void pix_point(const float* __restrict__ depth, int H, int W, int i, int j, float fx,
                                           float fy, float cx, float cy, float& x, float& y, float& z) {
@@ -32,8 +29,7 @@ __device__ __forceinline__ void pix_point(const float* __restrict__ depth, int H
 // One block = 32 x 16 pixels, two per thread (1 594 blocks for a 680x1200 frame: ONE round on 256 CUs x 8 blocks).  The
 // camera-frame points of the block and its 2-pixel halo (36 x 20) are computed ONCE into LDS (two IEEE divisions per
 // point); the 8 neighbours of a pixel are then three LDS reads each.  (The first version recomputed the nine points per
-// pixel -- 18 divisions and 9 global loads per thread -- in 3 188 blocks, i.e. two rounds: 17.0 us per frame = 0.77 TB/s of
-// the 13 MB the frame moves.)  Same arithmetic per point and per pixel: bit-identical normals.
+// pixel -- 18 divisions and 9 global loads per thread -- in 3 188 blocks, i.e. two rounds: 17.0 us per frame.)
 constexpr int NRM_BH = 16;
 __global__ __launch_bounds__(256) void normals_kernel(const float* __restrict__ depth, int H, int W, float fx,
                                                       float fy, float cx, float cy, float* __restrict__ normals) {

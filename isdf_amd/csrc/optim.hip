@@ -119,6 +119,8 @@ struct FinalizeArgs {
   // optional (single-GPU tail only): the per-frame averages of loss.frame_avg written straight away --
   // loss_approx [F,8,8] and frame_avg[fa_index ? fa_index[f] : f] (the keyframe store's frame_avg_losses)
   float *la_out, *fa_out; const int32_t* fa_index;
+  // optional: loss sums mirrored into pinned host memory; caller-owned tail of the reduction message
+  float* mailbox; float* extra; int n_extra, extra_slot; float extra_value;
 };
 // binS: 32.32 fixed point -- integer LDS atomics are order-independent, so the bins (hence frame_avg_losses and
 // the keyframe-selection probabilities built from them) are bit-reproducible; float atomics are not
@@ -153,7 +155,9 @@ __device__ __forceinline__ void finalize_block(int block, const FinalizeArgs& a,
       float v = 0.f;
       if (tid < 5) for (int k = 0; k < 16; ++k) v += sh[k][tid];
       loss_sums[tid] = v;
+      if (a.mailbox) a.mailbox[tid] = v;   // pinned host memory: valid after the caller's closing stream synchronisation
     }
+    if (tid < a.n_extra) a.extra[tid] = tid == a.extra_slot ? a.extra_value : 0.f;
     return;
   }
   const int f = block - 1;
@@ -266,7 +270,10 @@ __global__ __launch_bounds__(1024) void step_tail_kernel(const TailParams p) {
   const int b = blockIdx.x;
   if (b >= p.nW + p.nV) {
     if (PHASE != 2) finalize_block(b - p.nW - p.nV, p.fin, lds);
-    else frame_avg_block(b - p.nW - p.nV, threadIdx.x, p.fin.block_loss, p.fin.block_cnt, p.fin.la_out, p.fin.fa_out, p.fin.fa_index);
+    else if (b - p.nW - p.nV < p.fin.n_frames)
+      frame_avg_block(b - p.nW - p.nV, threadIdx.x, p.fin.block_loss, p.fin.block_cnt, p.fin.la_out, p.fin.fa_out, p.fin.fa_index);
+    else if ((int)threadIdx.x < 8 + p.fin.n_extra)   // last block of isdf_train_step_finish: the host's view of the reduced message
+      p.fin.mailbox[threadIdx.x] = threadIdx.x < 8 ? p.fin.loss_sums[threadIdx.x] : p.fin.extra[threadIdx.x - 8];
     return;
   }
   const int64_t P = PHASE == 2 ? 0 : (int64_t)(*p.fin.n_valid) * p.fin.S;
@@ -432,7 +439,8 @@ int launch_pack(const NetLayout& L, const float* params, uint16_t* shadow, hipSt
 static FinalizeArgs finalize_args(const float* wg_loss, int64_t maxTiles, const int32_t* n_valid, int S, const float* tot_ws,
                                   const int64_t* ib, const int64_t* ih, const int64_t* iw, int F, int H, int W,
                                   float* loss_sums, float* bl, float* bc) {
-  FinalizeArgs a = {wg_loss, maxTiles, n_valid, S, tot_ws, ib, ih, iw, F, H, W, loss_sums, bl, bc, nullptr, nullptr, nullptr};
+  FinalizeArgs a = {wg_loss, maxTiles, n_valid, S, tot_ws, ib, ih, iw, F, H, W, loss_sums, bl, bc, nullptr, nullptr, nullptr,
+                    nullptr, nullptr, 0, 0, 0.f};
   return a;
 }
 // phase 0: params/m/v/shadow + optim scalars + finalize args; phase 1: grad + finalize args only;
@@ -442,7 +450,7 @@ int launch_step_tail(int phase, const NetLayout& L, const float* dwPart, const f
                      float eps, float wd, int step, const float* wg_loss, int64_t maxTiles, const int32_t* n_valid, int S,
                      const float* tot_ws, const int64_t* ib, const int64_t* ih, const int64_t* iw, int F, int H, int W,
                      float* loss_sums, float* bl, float* bc, float* la_out, float* fa_out, const int32_t* fa_index,
-                     hipStream_t st) {
+                     hipStream_t st, float* mailbox, float* extra, int n_extra, int extra_slot, float extra_value) {
   TailParams p = {};
   p.lay = L; p.dwPart = dwPart; p.vecPart = vecPart; p.vecStride = vecStride; p.grad = grad;
   p.params = params; p.m = m; p.v = v; p.shadow = shadow; p.grad_scale = grad_scale;
@@ -450,6 +458,7 @@ int launch_step_tail(int phase, const NetLayout& L, const float* dwPart, const f
     p.c = AdamwCoef{lr, b1, b2, eps, wd, 1.f - powf(b1, (float)step), sqrtf(1.f - powf(b2, (float)step))};
   p.fin = finalize_args(wg_loss, maxTiles, n_valid, S, tot_ws, ib, ih, iw, F, H, W, loss_sums, bl, bc);
   if (la_out && fa_out) { p.fin.la_out = la_out; p.fin.fa_out = fa_out; p.fin.fa_index = fa_index; }
+  p.fin.mailbox = mailbox; p.fin.extra = extra; p.fin.n_extra = n_extra; p.fin.extra_slot = extra_slot; p.fin.extra_value = extra_value;
   const int64_t total = (int64_t)dw_units(L) * DW_BLK * DW_BLK;
   p.nW = (int)((total + 1023) / 1024);
   p.nV = (L.L * L.HD + L.HD + 1 + 63) / 64;
@@ -463,17 +472,20 @@ int launch_step_tail(int phase, const NetLayout& L, const float* dwPart, const f
 int launch_adamw_pack(const NetLayout& L, float* params, float* m, float* v, uint16_t* shadow, const float* grad,
                       const float* count_ptr, float grad_scale, float lr, float b1, float b2, float eps, float wd,
                       int step, hipStream_t st, int n_frames = 0, const float* bl = nullptr, const float* bc = nullptr,
-                      float* la = nullptr, float* fa = nullptr, const int32_t* fa_index = nullptr) {
+                      float* la = nullptr, float* fa = nullptr, const int32_t* fa_index = nullptr,
+                      const float* loss_sums = nullptr, const float* extra = nullptr, int n_extra = 0, float* mailbox = nullptr) {
   TailParams p = {};
   p.fin.block_loss = const_cast<float*>(bl); p.fin.block_cnt = const_cast<float*>(bc);
-  p.fin.la_out = la; p.fin.fa_out = fa; p.fin.fa_index = fa_index;
+  p.fin.la_out = la; p.fin.fa_out = fa; p.fin.fa_index = fa_index; p.fin.n_frames = n_frames;
+  p.fin.loss_sums = const_cast<float*>(loss_sums); p.fin.extra = const_cast<float*>(extra); p.fin.n_extra = n_extra;
+  p.fin.mailbox = mailbox;
   p.lay = L; p.grad = const_cast<float*>(grad); p.params = params; p.m = m; p.v = v; p.shadow = shadow;
   p.grad_scale = grad_scale; p.count_ptr = count_ptr;
   p.c = AdamwCoef{lr, b1, b2, eps, wd, 1.f - powf(b1, (float)step), sqrtf(1.f - powf(b2, (float)step))};
   const int64_t total = (int64_t)dw_units(L) * DW_BLK * DW_BLK;
   p.nW = (int)((total + 1023) / 1024);
   p.nV = (L.L * L.HD + L.HD + 1 + 63) / 64;
-  hipLaunchKernelGGL(step_tail_kernel<2>, dim3((unsigned)(p.nW + p.nV + n_frames)), dim3(1024), 0, st, p);
+  hipLaunchKernelGGL(step_tail_kernel<2>, dim3((unsigned)(p.nW + p.nV + n_frames + (mailbox ? 1 : 0))), dim3(1024), 0, st, p);
   return isdf_launch_status();
 }
 int launch_frame_avg(const float* bl, const float* bc, int F, float* la, float* fa, const int32_t* fa_index,

@@ -275,10 +275,10 @@ class HotPath:
                 kw["optim"].update(frame_avg_out=frame_avg_dst[0], frame_avg_index=frame_avg_dst[1])
         if hip.dist_group is not None and self.bounds_method == "pc":
             kw["surf_group"] = hip.dist_group
+        if hip.clock_slots:              # this rank's previous step time rides in the message's tail (one slot per rank)
+            kw.update(extra_slot=hip.rank, extra_value=hip.prev_step_ms)
         dbg = eng.train_step(s, self._loss_cfg(), sc, noise=noise, **kw)
         if hip.dist_group is not None:   # sums over ranks; AdamW divides by the reduced count
-            if hip.time_src is not None:   # this rank's previous step time rides in the message's tail (one slot per rank)
-                eng.reduce_buf[eng.reduce_floats:].copy_(hip.time_src, non_blocking=True)
             dp.allreduce_(eng.reduce_buf, hip.dist_group)   # THE collective of the step
         return dbg
 
@@ -377,22 +377,31 @@ class HotPath:
                     self.frames.frame_avg_losses[fidx.long()] = fa      # trainer.py:979
             if not fused:
                 self.optimiser.step()                  # AdamW on the (all-reduced) gradient sums
-        hip.loss_host.copy_(eng.loss_sums(), non_blocking=True)   # rides on the closing synchronisation
-        if hip.time_src is not None:
-            hip.time_host.copy_(eng.reduce_buf[eng.reduce_floats:], non_blocking=True)
+        # `losses`: the step's last launch stored the (reduced) loss sums -- and, data parallel, the ranks' step times -- in
+        # pinned host memory (eng.mailbox); they are valid after the closing synchronisation below.  No copy command.
+        if getattr(eng, "mailbox", None) is None:      # engines without a host mailbox (tests' CPU stand-in)
+            hip.loss_host.copy_(eng.loss_sums(), non_blocking=True)
+            mailbox = hip.loss_host
+        else:
+            mailbox = eng.mailbox
+            if hip.dist_group is not None and not (not fused and direct and hip.fuse_optimiser):
+                # reference call sequence (separate AdamW launch): the reduced sums were not mirrored by a closing launch
+                mailbox[:8].copy_(eng.loss_sums(), non_blocking=True)
+                if hip.clock_slots:
+                    mailbox[8:].copy_(eng.reduce_buf[eng.reduce_floats:], non_blocking=True)
 
         step_time = self._timing_end(st, start, end)
         clock_ms = step_time
         if hip.virtual_step_ms is not None:            # pinned schedule (parity / accuracy runs)
             clock_ms = step_time = float(hip.virtual_step_ms)
-        elif hip.time_src is not None:
+        elif hip.clock_slots:
             # ONE virtual clock for all ranks (the frame schedule is a function of it) WITHOUT a second collective: every
             # rank's time of the PREVIOUS step came back in the tail of this step's all-reduce message; the clock advances
             # by the slowest rank's, one step late (step 0 advances it by 0).  This step's own time goes out with the next.
-            clock_ms = float(hip.time_host.max())
-            hip.time_src.zero_()
-            hip.time_src[hip.rank] = step_time
-        losses = StepLosses(hip.loss_host, self.grad_weight != 0, self.eik_weight != 0)
+            clock_ms = float(mailbox[8:8 + hip.clock_slots].max()) if mailbox.numel() >= 8 + hip.clock_slots else \
+                float(eng.reduce_buf[eng.reduce_floats:].max())
+            hip.prev_step_ms = float(np.float32(step_time))
+        losses = StepLosses(mailbox[:8], self.grad_weight != 0, self.eik_weight != 0)
         hip.step_count += 1
         self.tot_step_time += (1 / self.frac_time_perception) * (clock_ms / 1000.0)
         self.steps_since_frame += 1
@@ -595,7 +604,7 @@ def graft(trainer, rng="philox", seed=1, dist_group=None, fix_normal_window=Fals
     base = trainer.__class__
     if not issubclass(base, HotPath):
         trainer.__class__ = type("Hip" + base.__name__, (HotPath, base), {"__module__": HotPath.__module__})
-    hip.time_src = hip.time_host = None
+    hip.clock_slots, hip.prev_step_ms, hip.rank = 0, 0.0, 0
     if dist_group is not None:                           # replicated weights / moments
         eng = trainer.sdf_map.engine
         for t in (eng.params, eng.exp_avg, eng.exp_avg_sq):
@@ -604,8 +613,5 @@ def graft(trainer, rng="philox", seed=1, dist_group=None, fix_normal_window=Fals
         hip.rank, hip.world = torch.distributed.get_rank(dist_group), torch.distributed.get_world_size(dist_group)
         hip.window_rng_state = np.random.RandomState(hip.seed + 104729).get_state()   # replicated select_keyframes stream
         if hip.virtual_step_ms is None:                  # per-rank step-time slots in the tail of the all-reduce message
-            pin = dev.type == "cuda"
-            hip.time_src = torch.zeros(hip.world, dtype=torch.float32, pin_memory=pin)
-            hip.time_host = torch.zeros(hip.world, dtype=torch.float32, pin_memory=pin)
-            eng.reduce_extra = hip.world
+            hip.clock_slots = eng.reduce_extra = hip.world
     return trainer

@@ -85,7 +85,7 @@ class FakeEngine:
 
     # ---- training step: reduce_buf = [grad SUMS | loss sums(8) | block_loss | block_cnt]
     def train_step(self, smp, lc, sc, noise=None, debug=False, prof_events=None, noise_std=0.0, noise_seed=0,
-                   noise_offset=0, optim=None, surf_group=None):
+                   noise_offset=0, optim=None, surf_group=None, extra_slot=0, extra_value=0.0):
         R = int(smp["n_valid"].item())
         F, S = smp["n_frames"], smp["S"]
         if noise is None and noise_std:
@@ -104,6 +104,8 @@ class FakeEngine:
         nred = self.n_params + 8 + 2 * F * 64
         self.reduce_floats = nred
         self.reduce_buf = torch.zeros(nred + self.reduce_extra)
+        if self.reduce_extra:
+            self.reduce_buf[nred + extra_slot] = extra_value     # caller-owned tail: one slot per rank
         self._F = F
         for k, (off, shp) in self.slices.items():
             self.reduce_buf[off:off + int(np.prod(shp))] = torch.from_numpy((grads[k].astype(np.float64) * N).astype(np.float32).reshape(-1))

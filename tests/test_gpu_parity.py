@@ -1033,7 +1033,7 @@ def test_public_seams_match_step_and_autograd_callers_work():
     g = torch.autograd.grad(sdf, x, torch.ones_like(sdf))[0]
     sdf_k, g_k = b.sdf_map.forward_with_grad(x.detach())
     assert torch.equal(sdf.detach(), sdf_k) and torch.equal(g, g_k)
-    eps = 0.05      # (the 2e-5 fp16-operand noise of the outputs rules out a small step)
+    eps = 0.02      # (the operand-rounding noise of the outputs, ~1e-5, rules out a much smaller step)
     fd = (b.sdf_map(x.detach() + torch.tensor([eps, 0, 0], device="cuda")) - b.sdf_map(x.detach() - torch.tensor([eps, 0, 0], device="cuda"))) / (2 * eps)
     assert float((fd - g[:, 0]).abs().max()) < 5e-2 * float(g[:, 0].abs().max())
 
