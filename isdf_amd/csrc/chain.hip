@@ -513,6 +513,7 @@ __global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 && EP == HD ? 4 : 2)) voi
   refresh();
   if constexpr (!WIDE_E) {
   gemm<F16, (2 * HD) / 16, FB, PB, ROWB, T::CKF>(acc, wq, rsW, wptr(setBwdA, L.bwdG, 2 * HD), X, 0, lane, loss_inputs);
+  TS();   // (development build: G gemm done)
   // g_x' = J_pe^T Eg.  Eg goes through the (now idle) X tile as fp32 [BM][HD] so the contraction can run in
   // the PE stage's (point, direction-slice) mapping: 2*nf sin/cos per direction per thread and wave-uniform
   // direction constants, instead of one cos + index arithmetic per accumulator element (which took
@@ -532,6 +533,7 @@ __global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 && EP == HD ? 4 : 2)) voi
       }
     }
   lds_barrier();
+  TS();   // (Eg staged in LDS)
   {
     // a wave = (BM / NW points) x (direction slices): rows are 1 KB apart, i.e. 8 banks -- 64 points per wave was 8-way conflicted
     const int pt = (tid % (BM / T::NW)) + (BM / T::NW) * (tid / 64), prt = (tid % 64) / (BM / T::NW);
@@ -558,6 +560,7 @@ __global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 && EP == HD ? 4 : 2)) voi
     dst[0] = g0; dst[1] = g1; dst[2] = g2;
   }
   lds_barrier();
+  TS();   // (J_pe^T contraction done)
   } else {
     // EP = 2 HD: the X tile cannot hold fp32 [BM][EP] next to nothing, and the G operands (p_0 | p_cat in the
     // first 2 HD columns) must survive the first row half.  So: one GEMM per row half of G (HD embedding
@@ -700,6 +703,7 @@ __global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 && EP == HD ? 4 : 2)) voi
     }
   }
   if (MODE != 2) return;
+  TS();   // (loss + adjoints done)
   if (tid < BM) {  // per-wave loss / sbar sums -> LDS, one thread combines (deterministic)
     float v5[5] = {lsum[0], lsum[1], lsum[2], lsum[3], gbs[tid * 4 + 3]};
 #pragma unroll
@@ -722,6 +726,7 @@ __global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 && EP == HD ? 4 : 2)) voi
     vecTile[L.L * HD + 2 * HD] = s[4];   // d b_out = sum sbar*so
   }
 
+  TS();   // (loss sums written)
   // ------------------------------------------------------------------ Ebar = J_pe gbar  -> region 2 (bf16)
   if (tid < HD / 4) ((float4*)part)[tid] = ((const float4*)(p.params + L.offWout))[tid];   // w_out for the top epilogue
   {
@@ -750,8 +755,10 @@ __global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 && EP == HD ? 4 : 2)) voi
     }
   }
   lds_barrier();
+  TS();   // (Ebar in region 2)
   spill_region(HD, p.sp.GB[0], std::false_type{});
   if (WIDE_E) spill_region(2 * HD, p.sp.GB[0] + p.sp.tensorElems, std::false_type{});
+  TS();   // (Ebar spilled)
 
   // ------------------------------------------------------------------ adjoint of the first reverse sweep (upward)
   // The top layer's epilogue also IS the top of the ordinary reverse sweep (zbar_L needs only a_L, the

@@ -16,18 +16,20 @@ namespace isdf {
 struct ChainDebug {
   int32_t alias;              // ISDF_DEBUG_ALIAS_SPILL=n: tiles share n spill regions (timing only, results garbage)
   int32_t stagger;            // ISDF_DEBUG_STAGGER=k: odd tiles start k kilo-cycles late
+  int32_t stagger_gen;        // ISDF_DEBUG_STAGGER_GEN=1: ... the SECOND workgroup of every CU (dispatch round) instead of odd tiles
   unsigned long long* times;  // ISDF_DEBUG_TIMELINE: [0..127] s_memtime stamps of workgroup 100, [128..] wall clocks
 };
 inline void chain_debug_from_env(ChainDebug& d, void* stamp_area) {
   if (const char* e = getenv("ISDF_DEBUG_ALIAS_SPILL")) d.alias = atoi(e);
   if (const char* e = getenv("ISDF_DEBUG_STAGGER")) d.stagger = atoi(e);
+  if (const char* e = getenv("ISDF_DEBUG_STAGGER_GEN")) d.stagger_gen = atoi(e);
   if (getenv("ISDF_DEBUG_TIMELINE")) d.times = (unsigned long long*)stamp_area;
 }
 #if defined(__HIPCC__)
 struct ChainStamps {
   const ChainDebug& d; int n = 0;
   __device__ explicit ChainStamps(const ChainDebug& dd) : d(dd) {
-    if (d.stagger && (blockIdx.x & 1)) {   // de-phase odd tiles
+    if (d.stagger && ((d.stagger_gen ? (blockIdx.x >> 8) : blockIdx.x) & 1)) {   // de-phase odd tiles / second-round workgroups
       const unsigned long long t0 = __builtin_amdgcn_s_memtime();
       while (__builtin_amdgcn_s_memtime() - t0 < (unsigned long long)d.stagger * 1000ull) __builtin_amdgcn_s_sleep(64);
     }

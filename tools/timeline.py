@@ -9,7 +9,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from isdf_amd.engine import Engine, NetConfig, LossConfig, SampleConfig
 from isdf_amd import synthetic
-eng = Engine(NetConfig(transform=synthetic.bounds_transform()), "cuda")
+eng = Engine(NetConfig(transform=synthetic.bounds_transform(), fwd_operand=os.environ.get("ISDF_FWD_OPERAND", "fp16x2")), "cuda")
 torch.manual_seed(0); eng.params.normal_(0, 0.06); eng.pack()
 cam = dict(synthetic.SCANNET_CAM)
 d, n, T = synthetic.keyframes(5, cam, seed=1)
