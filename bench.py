@@ -53,6 +53,16 @@ class HipEvents:
         return out.value
 
 
+def latest_profile(suffix):
+    """newest committed profiles/rNN_<suffix> (PMC passes cannot run inside the timed region: bench.py quotes the committed
+    rocprofv3 --pmc measurement of this same command)"""
+    for r in range(9, 0, -1):
+        p = os.path.join(ROOT, "profiles", "r%02d_%s" % (r, suffix))
+        if os.path.exists(p):
+            return p
+    return None
+
+
 def reference_config():
     """replicaCAD.json defaults (isdf/train/configs/replicaCAD.json) for the hot path."""
     return {
@@ -179,8 +189,8 @@ def sampler_scale(args, tr, eng, cam, rank):
     R = int(s["n_valid"].item())
     alg = 16.0 * rays + 496.0 * R
     traffic, src = None, None
-    tpath = os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")
-    if os.path.exists(tpath):
+    tpath = latest_profile("hbm_traffic.json")
+    if tpath:
         with open(tpath) as f:
             tj = json.load(f)
         if tj.get("sampler_scale", {}).get("rays") == rays:
@@ -405,13 +415,16 @@ def main():
     # metrics.start_timing/end_timing measure it (metrics.py:13-38): includes the host's
     # time-to-first-launch that the pipelined figure above overlaps.  Not part of `value`.
     tr.noise_std = tr.noise_kf
-    for _ in range(10):
+    for _ in range(30):                      # >= 200 timed steps after >= 20 warm-up steps
         tr.step()
-    n_sync = 100
+    n_sync = 200
+    per_step = np.empty(n_sync)
     ts = time.perf_counter()
-    for _ in range(n_sync):
+    for i in range(n_sync):
+        t_a = time.perf_counter()
         tr.step()
-    sync_step_ms = (time.perf_counter() - ts) / n_sync * 1e3
+        per_step[i] = time.perf_counter() - t_a
+    sync_step_ms = (time.perf_counter() - ts) / n_sync * 1e3      # the MEAN; median / p90 show host hiccups
 
     # ---- per-kernel timing from the HIP events recorded inside the timed region
     chain_us = np.array([events.ms(4 * i, 4 * i + 1) for i in range(K)]) * 1e3
@@ -429,10 +442,8 @@ def main():
     final_loss = float(ls[3] / max(ls[4], 1))
 
     traffic, traffic_src = None, None
-    tpath = os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")
-    if not os.path.exists(tpath):
-        tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
-    if os.path.exists(tpath) and args.rays_per_frame == 200 and not args.wide:     # PMC passes cannot run inside the timed region:
+    tpath = latest_profile("hbm_traffic.json")
+    if tpath and args.rays_per_frame == 200 and not args.wide:     # PMC passes cannot run inside the timed region:
         with open(tpath) as f:                                    # the committed rocprofv3 --pmc measurement of this
             tj = json.load(f)                                     # command (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)
         traffic, traffic_src = tj["chain_kernel"]["hbm_bytes"], tj["source"]
@@ -471,8 +482,12 @@ def main():
             # end_timing bracket it (metrics.py:13-38): that is this second figure, on HipTrainer.step() itself.
             "pipelined": {"steps_per_s": round(world * K / elapsed, 2), "ms_per_step": round(1e3 * elapsed / K, 4)},
             "synchronised_step": {"steps_per_s": round(1e3 / sync_step_ms, 2), "ms_per_step": round(sync_step_ms, 4),
-                                  "n": n_sync, "what": "HipTrainer.step(): sync + event, sampler, step kernels, AdamW, "
-                                  "frame averages, 8-float loss copy, sync (per step, as Trainer.step is timed upstream)"},
+                                  "median_ms": round(float(np.median(per_step)) * 1e3, 4),
+                                  "p90_ms": round(float(np.percentile(per_step, 90)) * 1e3, 4),
+                                  "slowest": [[int(i), round(float(per_step[i]) * 1e3, 3)] for i in np.argsort(per_step)[::-1][:5]],
+                                  "n": n_sync, "warmup": 30,
+                                  "what": "HipTrainer.step(): sync + event, sampler, step kernels (AdamW, frame averages and the "
+                                  "loss sums' host copy inside the last launch), sync -- per step, as Trainer.step is timed upstream"},
             "trainer_step_sync_ms": round(sync_step_ms, 4),
             "clock_ramp": {"untimed_steps_before_warmup": ramp_steps, "seconds": args.ramp_seconds},
             "chain_us_per_step": {"first5": [round(float(v), 1) for v in chain_us[:5]], "min": round(float(chain_us.min()), 1),

@@ -75,6 +75,7 @@ __global__ __launch_bounds__(SMP_NT) void sample_rays_kernel(const isdf_sample_a
   __shared__ uint32_t sEpoch;
   __shared__ int sPre[NW], sWaveCnt[NW];
   __shared__ float sRay[CHUNK][8];   // depth, origin xyz, dirs_W xyz, pad  (compacted order within the chunk)
+  __shared__ __attribute__((aligned(16))) float sPc[NW][768];   // a wave's 256 world points, staged for 16-byte stores
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   unsigned long long* state = (unsigned long long*)(ws + 4);
   const int total = a.n_frames * a.n_rays;
@@ -213,7 +214,11 @@ __global__ __launch_bounds__(SMP_NT) void sample_rays_kernel(const isdf_sample_a
   // ---- along-ray samples of the chunk's valid rays: point p of the chunk -> (ray j, sample s); consecutive
   // threads write consecutive points (sample.py:131-178)
   const int npts = cnt_ * S;
+  struct __attribute__((packed, aligned(4))) f4u { float x, y, z, w; };   // 16-byte store at 4-byte alignment
   for (int G = wv; G * 256 < npts; G += NW) {
+    // full groups write their 256 x 3 floats of `pc` as three 16-byte stores per lane (1 KB per wave instruction) through a
+    // per-wave LDS transpose instead of twelve 4-byte stores at a 12-byte lane stride (a third of every line per instruction)
+    const bool fullGroup = G * 256 + 256 <= npts;
     // in-kernel draws: one Philox call per lane and 256-point group, word m for the lane's m-th point; counter
     // (chunk, 1 + group*64 + lane) never collides with the pixel draws' (ray, 0)
     uint4 rnd = make_uint4(0u, 0u, 0u, 0u);
@@ -257,9 +262,24 @@ __global__ __launch_bounds__(SMP_NT) void sample_rays_kernel(const isdf_sample_a
     const int64_t n = r * S + s;
     o.z_vals[n] = z;
 #pragma unroll
-    for (int i = 0; i < 3; ++i)  // pc = origins + dirs_W * z, sample.py:176
-      o.pc[n * 3 + i] = __fadd_rn(sr[1 + i], __fmul_rn(sr[4 + i], z));
+    for (int i = 0; i < 3; ++i) {  // pc = origins + dirs_W * z, sample.py:176
+      const float v = __fadd_rn(sr[1 + i], __fmul_rn(sr[4 + i], z));
+      if (fullGroup) sPc[wv][(m * 64 + lane) * 3 + i] = v;
+      else o.pc[n * 3 + i] = v;
+    }
    }
+    if (fullGroup) {   // wave-uniform
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      float* dst = o.pc + ((int64_t)base * S + (int64_t)G * 256) * 3;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const float4 v = *(const float4*)&sPc[wv][(k * 64 + lane) * 4];
+        *(f4u*)(dst + (k * 64 + lane) * 4) = f4u{v.x, v.y, v.z, v.w};
+      }
+      __builtin_amdgcn_wave_barrier();   // the next group of this wave overwrites sPc
+    }
   }
 
   if (SMALL) return;

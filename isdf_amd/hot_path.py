@@ -308,9 +308,11 @@ class HotPath:
         (torch.cuda.synchronize() itself costs ~5 us of host time per call in index / env lookups)."""
         if st is not None:
             st.synchronize()
-            start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            start.record(st)
-            return start, end
+            ev = self._hip.timing_events          # ONE pair of events re-recorded every step: no event creation on the step path
+            if ev is None:
+                ev = self._hip.timing_events = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record(st)
+            return ev
         import time
         return time.perf_counter(), None
 
@@ -596,7 +598,7 @@ def graft(trainer, rng="philox", seed=1, dist_group=None, fix_normal_window=Fals
 
     hip = types.SimpleNamespace(rng=rng, seed=int(seed), dist_group=dist_group, fix_normal_window=bool(fix_normal_window),
                                 fuse_optimiser=bool(fuse_optimiser), device=dev, draw_count=0, noise_count=0,
-                                step_count=0, idx_cache=None,
+                                step_count=0, idx_cache=None, timing_events=None,
                                 virtual_step_ms=None if virtual_step_ms is None else float(virtual_step_ms),
                                 loss_host=torch.zeros(8, dtype=torch.float32,
                                                       pin_memory=(dev.type == "cuda")))
