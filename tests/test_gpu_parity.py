@@ -1079,7 +1079,8 @@ SHAPE_CASES = ["eval_wide_512", "eval_rs_realsense", "eval_rs_franka", "eval_rs_
 # summed weight gradients of the high-frequency nets: the loss is NOT smooth (L1 / eikonal signs, free-space branch,
 # loss.py:122-164, trainer.py:814-816) and with 9-11 PE octaves a random-init field oscillates so fast that the forward
 # rounding of a 16-bit-operand implementation flips some of those signs; measured bounds per fixture (rel to the norm)
-SHAPE_DW_TOL = {"eval_wide_512": 2e-2, "eval_rs_realsense": 2e-2, "eval_rs_franka": 3e-2, "eval_rs_franka_offline": 3e-2}
+# (measured worst deviation: 4.6e-3, 3.9e-3, 1.7e-2, 6.0e-3 -- only scale_input 0.4, the fastest-oscillating field, leaves 1e-2)
+SHAPE_DW_TOL = {"eval_wide_512": 1e-2, "eval_rs_realsense": 1e-2, "eval_rs_franka": 3e-2, "eval_rs_franka_offline": 1e-2}
 
 
 @pytest.mark.parametrize("case", SHAPE_CASES)
@@ -1105,7 +1106,7 @@ def test_other_network_shapes_vs_reference(case):
     gerr = gu.rel_err(grad.cpu().numpy(), g["sdf_grad"].reshape(-1, 3))
     print("%s: sdf rel-L2 vs reference %.3e, d sdf/dx %.3e" % (case, err, gerr))
     assert err < TOL_SDF, err
-    assert gerr < 1.5 * TOL_SDF_GRAD, gerr
+    assert gerr < TOL_SDF_GRAD, gerr
     # training step: the four loss means and the digests of all gradient tensors vs the reference; then vs the oracle
     eng, s, dbg, terms, grads, R = _run_step(g)
     N = R * s["S"]
