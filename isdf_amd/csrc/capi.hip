@@ -153,6 +153,7 @@ static int train_step_impl(const isdf_net_cfg* net, const isdf_loss_cfg* loss, c
   if (loss->loss_type != 0 && loss->loss_type != 1) return ISDF_EINVAL;
   if (loss->grad_weight != 0.f && !a->norm_sample) return ISDF_EINVAL;
   const int64_t maxPts = (int64_t)a->max_rays * a->S;
+  if (maxPts > 0x7fffffff) return ISDF_EINVAL;   // the loss stage indexes points with 32-bit arithmetic
   WorkspaceLayout w; make_workspace(l, maxPts, a->max_rays, true, &w);
   if (workspace_bytes < w.totalBytes) return ISDF_EWORKSPACE;
   hipStream_t st = (hipStream_t)stream;

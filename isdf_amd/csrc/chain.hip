@@ -499,8 +499,8 @@ __global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 && EP == HD ? 4 : 2)) voi
     if (MODE != 2 || tid >= BM) return;
     const int64_t n = n0 + tid;
     if (n >= P) return;
-    const int64_t ray = n / p.S;
-    if (p.loss.bounds_method == 0) {  // loss.py:13-22
+    const int64_t ray = (int64_t)((uint32_t)n / (uint32_t)p.S);   // 32-bit division: max_rays * S < 2^31 (capi.hip), and this wave
+    if (p.loss.bounds_method == 0) {  // loss.py:13-22                //   sits on the tile's critical path between the sweeps
       li_c[0] = p.dirsC[ray * 3]; li_c[1] = p.dirsC[ray * 3 + 1]; li_c[2] = p.dirsC[ray * 3 + 2];
       li_dz[0] = p.depth[ray]; li_dz[1] = p.z_vals[n];
       li_t[0] = p.dirsW[ray * 3]; li_t[1] = p.dirsW[ray * 3 + 1]; li_t[2] = p.dirsW[ray * 3 + 2];
@@ -635,7 +635,7 @@ __global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 && EP == HD ? 4 : 2)) voi
     float sbar = 0.f, bx = 0.f, by = 0.f, bz = 0.f;
     if (MODE == 2 && n < P) {
       const isdf_loss_cfg& lc = p.loss;
-      const int64_t ray = n / p.S;
+      const int64_t ray = (int64_t)((uint32_t)n / (uint32_t)p.S);
       const int s = (int)(n - ray * p.S);
       float bnd = li_bnd, tx = li_t[0], ty = li_t[1], tz = li_t[2];   // bound and target gradient direction
       if (lc.bounds_method == 0) {
