@@ -428,8 +428,12 @@ def main():
     # freshly booted box stalls one step for ~35-40 ms about half a second into its run (seen three times, at step 32-35 of this
     # loop, never in a second process; per-step times are in "slowest"), a one-time driver event that is not the step's cost
     t_w, n_warm = time.perf_counter(), 0
-    while n_warm < 30 or time.perf_counter() - t_w < 1.2:
-        tr.step(); n_warm += 1
+    if group is None:
+        while n_warm < 30 or time.perf_counter() - t_w < 1.2:
+            tr.step(); n_warm += 1
+    else:   # every rank must issue the SAME number of collectives: a fixed count instead of a time budget
+        for _ in range(1500):
+            tr.step(); n_warm += 1
     n_sync = 200
     per_step = np.empty(n_sync)
     ts = time.perf_counter()

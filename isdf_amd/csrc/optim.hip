@@ -31,7 +31,7 @@ __global__ void adamw_kernel(float* __restrict__ p, float* __restrict__ m, float
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   float gs = grad_scale;
-  if (count_ptr) gs /= *count_ptr;
+  if (count_ptr) { if (*count_ptr == 0.f) return; gs /= *count_ptr; }   // empty batch: no update (see step_tail_kernel)
   adamw_update(p, m, v, i, g[i], gs, c);
 }
 
@@ -280,6 +280,10 @@ __global__ __launch_bounds__(1024) void step_tail_kernel(const TailParams p) {
   float gs = p.grad_scale;
   if (PHASE == 0) gs /= (float)P;
   if (PHASE == 2 && p.count_ptr) gs /= *p.count_ptr;
+  // A batch without a single valid ray (all sampled depths 0): upstream the means over empty tensors are NaN and AdamW poisons
+  // every weight (loss.py:187-202).  Here the update is SKIPPED -- sums and the count (0) are still reported, so the caller sees
+  // what happened -- the one deliberate deviation from the reference's arithmetic on this path.
+  const bool emptyBatch = (PHASE == 0 && P == 0) || (PHASE == 2 && p.count_ptr && *p.count_ptr == 0.f);
   if (b < p.nW) {
     // ---- weights (dw_reduce_kernel's mapping: one thread per element of a 256x256 dW unit)
     const int64_t idx = (int64_t)b * 1024 + threadIdx.x;
@@ -306,6 +310,7 @@ __global__ __launch_bounds__(1024) void step_tail_kernel(const TailParams p) {
       p.grad[pi] = s;
       if (PHASE == 1) return;
     }
+    if (emptyBatch) return;
     const float w = adamw_update(p.params, p.m, p.v, pi, s, gs, p.c);
     // packed operand copies (pack_kernel's sources, inverted): forward orientation ...
     const int KpF = li == 0 ? L.EP : (li == L.cat ? HD + L.EP : HD);
@@ -328,7 +333,7 @@ __global__ __launch_bounds__(1024) void step_tail_kernel(const TailParams p) {
   else if (v < L.L * HD + HD) { slotA = v; slotB = v + HD; dst = L.offWout + (v - L.L * HD); }
   else if (v < nVec) { slotA = L.L * HD + 2 * HD; dst = L.offBout; }
   if (PHASE == 2) {
-    if (g == 0 && dst >= 0) adamw_update(p.params, p.m, p.v, dst, p.grad[dst], gs, p.c);
+    if (g == 0 && dst >= 0 && !emptyBatch) adamw_update(p.params, p.m, p.v, dst, p.grad[dst], gs, p.c);
     return;
   }
   float s = 0.f, s2 = 0.f;
@@ -371,7 +376,7 @@ __global__ __launch_bounds__(1024) void step_tail_kernel(const TailParams p) {
 #pragma unroll
     for (int k = 0; k < 16; ++k) t += sh[k][pi];
     p.grad[dst] = t;
-    if (PHASE == 0) adamw_update(p.params, p.m, p.v, dst, t, gs, p.c);
+    if (PHASE == 0 && !emptyBatch) adamw_update(p.params, p.m, p.v, dst, t, gs, p.c);
   }
 }
 

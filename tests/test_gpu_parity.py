@@ -949,6 +949,32 @@ def test_sampler_philox_draws_are_in_distribution_and_deterministic():
         assert abs((off < 0).mean() - 0.5) < 0.01
 
 
+def test_batch_without_a_valid_ray_neither_hangs_nor_poisons_the_weights():
+    """Edge case: every sampled depth is 0 (sample.py:39-40 drops all rays).  Upstream the loss means over empty tensors are NaN
+    and AdamW turns every weight into NaN; here the step reports count 0 and SKIPS the update (documented deviation)."""
+    from isdf_amd.engine import Engine, NetConfig, LossConfig, SampleConfig
+    cam = dict(H=120, W=160, fx=150.0, fy=150.0, cx=79.5, cy=59.5)
+    F = 2
+    depth = torch.zeros(F, cam["H"], cam["W"], device="cuda")
+    normal = torch.zeros(F, cam["H"], cam["W"], 3, device="cuda")
+    T = torch.eye(4, device="cuda").repeat(F, 1, 1).contiguous()
+    idx = torch.arange(F, dtype=torch.int32, device="cuda")
+    eng = Engine(NetConfig(), "cuda")
+    eng.params.normal_(0, 0.05); eng.pack()
+    before = eng.params.clone()
+    sc, lc = SampleConfig(n_rays=50, **cam), LossConfig()
+    for fused in (True, False):
+        s = eng.sample(depth, T, normal, idx, idx, sc, seed=3, offset=1)
+        eng.train_step(s, lc, sc, noise_std=0.04, noise_seed=1, noise_offset=1, optim=dict(lr=0.0013, weight_decay=0.012) if fused else None)
+        if not fused:
+            eng.adamw()
+        torch.cuda.synchronize()
+        assert int(s["n_valid"].item()) == 0
+        ls = eng.loss_sums().cpu().numpy()
+        assert ls[4] == 0 and np.all(ls[:4] == 0)
+        assert torch.equal(eng.params, before) and bool(torch.isfinite(eng.exp_avg).all())
+
+
 def test_sampler_ordered_compaction_at_a_million_rays():
     """The sampler as a streaming kernel (>= 1e6 rays): 15 625 chunks, look-back windows longer than
     one wave.  Ordered compaction, gathers and the surface sample are checked against torch on the same draws."""
