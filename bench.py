@@ -226,6 +226,9 @@ def infer_bench(args, tr, eng, rank):
         e2 = Engine(dataclasses.replace(eng.net, fwd_operand="fp16"), tr.device)
         e2.params.copy_(eng.params); e2.pack()
         engines["fp16"] = e2
+        e3 = Engine(dataclasses.replace(eng.net, fwd_operand="fp16x2_full"), tr.device)   # exact-forward instrument (one workgroup per CU)
+        e3.params.copy_(eng.params); e3.pack()
+        engines["fp16x2_full"] = e3
     for op, en in engines.items():
         for name, wg, flop in (("forward", False, 2.0 * M), ("forward_with_input_gradient", True, 4.0 * M)):
             n = N if not wg else max(N // 4, 1)
@@ -292,7 +295,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--rays-per-frame", type=int, default=200)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--fwd-operand", default="fp16x2", choices=["fp16x2", "fp16", "bf16"])
+    ap.add_argument("--fwd-operand", default="fp16x2", choices=["fp16x2", "fp16", "bf16", "fp16x2_full"])
     ap.add_argument("--ramp-seconds", type=float, default=0.4,
                     help="untimed clock-ramp phase before the W warm-up steps (a fresh box runs the first ~100 ms at idle "
                          "clocks: 25 cold steps measured 13 %% slower than steady state in round 1); reported in the JSON line")
@@ -476,6 +479,7 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": {"fp16x2": "f16 (compensated forward: hi+lo operands past the cat layer) / bf16 MFMA operands, f32 accumulate",
+                      "fp16x2_full": "f16 (exact-forward instrument: hi+lo operands in every forward layer) / bf16 MFMA operands, f32 accumulate",
                       "fp16": "f16/bf16 MFMA operands, f32 accumulate", "bf16": "bf16 MFMA operands, f32 accumulate"}[args.fwd_operand],
             "fwd_operand": args.fwd_operand,
             "data": "synthetic",

@@ -60,8 +60,13 @@ typedef struct isdf_net_cfg {
                             fp16 residual of their weights, the layers past it
                             the fp16 residual of their input too -- which is
                             what meets the reference's fp32 sdf to 1e-3
-                            (fc_map.py:94-111).  isdf_shadow_bytes
-                            grows by one forward set for mode 2.               */
+                            (fc_map.py:94-111); 3 "fp16x2_full" =
+                            the same compensation in EVERY forward layer, the
+                            embedding included (exact-forward instrument: sdf
+                            ~1e-6 and d sdf/dx < 1e-3 of the reference;
+                            hidden 256 with a padded embedding of 256 only,
+                            other shapes ISDF_EUNSUPPORTED).  isdf_shadow_bytes
+                            grows by one forward set for modes 2 and 3.        */
   int32_t reserved;
 } isdf_net_cfg;
 

@@ -28,10 +28,14 @@ namespace isdf {
 // ("fp16x2", NetLayout::fwd_x2): layers >= cat also multiply the fp16 RESIDUAL of their weights, and the layers past
 // the cat layer the fp16 residual of their input activation (kept in region 2 of the tile, idle there), i.e.
 // W x ~= Wh xh + Wl xh + Wh xl -- what brings sdf within 1e-3 of the fp32 reference at BASELINE size.
+// 3 "fp16x2_full": the same three products in EVERY forward layer, embedding included -- the exact-forward instrument
+// (sdf ~1e-6 of the fp32 reference, d sdf/dx within 1e-3).  It keeps four operand regions in the tile (a, emb, a_lo,
+// emb_lo: 128 KB at <256, 256>), so one workgroup per CU; only instantiated for <256, 256>.
 constexpr bool oper_f16(int oper) { return oper >= 1; }
-constexpr bool oper_x2(int oper) { return oper == 2; }
+constexpr bool oper_x2(int oper) { return oper >= 2; }
+constexpr bool oper_x2_all(int oper) { return oper == 3; }
 
-template <int HD, int EP>
+template <int HD, int EP, bool LO_REGIONS = false>
 struct Tile {
   static constexpr int BM = TILE_PTS;
   static constexpr int NW = CHAIN_NW;
@@ -39,7 +43,7 @@ struct Tile {
   static constexpr int FB = HD / (NW * 32);   // 32-row feature blocks per wave
   static constexpr int PB = BM / 32;          // 32-point blocks
   static constexpr int R2 = (EP > HD ? EP : HD);
-  static constexpr int XK = HD + R2;          // elements per LDS row
+  static constexpr int XK = (HD + R2) * (LO_REGIONS ? 2 : 1);   // elements per LDS row: [a | emb] (+ [a_lo | emb_lo])
   static constexpr int ROWB = XK * 2;
   static constexpr int XBYTES = BM * ROWB;
   // small fp32 arrays after the X tile
@@ -146,9 +150,11 @@ __device__ __forceinline__ int frag16_off(int w, int fb, int pb, int qp, int lan
 }
 
 template <int HD, int EP, int OPER, int MODE>
-__global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 && EP == HD ? 4 : 2)) void chain_kernel(const ChainParams p) {
-  typedef Tile<HD, EP> T;
-  constexpr bool F16 = oper_f16(OPER), X2 = oper_x2(OPER);
+__global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 && EP == HD && !oper_x2_all(OPER) ? 4 : 2)) void chain_kernel(const ChainParams p) {
+  typedef Tile<HD, EP, oper_x2_all(OPER)> T;
+  constexpr bool F16 = oper_f16(OPER), X2 = oper_x2(OPER), X2ALL = oper_x2_all(OPER);
+  static_assert(!X2ALL || (HD == 256 && EP == 256), "fp16x2_full: four operand regions only fit the <256, 256> tile");
+  constexpr int LO = X2ALL ? (HD + EP) : HD;   // first column of the residual of the running activation (a_lo)
   static_assert(EP == HD || EP == 2 * HD, "padded embedding width is one or two hidden widths");
   constexpr bool WIDE_E = T::WIDE_E;
   constexpr int BM = T::BM, FB = T::FB, PB = T::PB, ROWB = T::ROWB;
@@ -242,6 +248,7 @@ __global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 && EP == HD ? 4 : 2)) voi
     char* row = X + pt * ROWB;
     auto put = [&](int feat, float v) {
       *(opT*)(row + swz(pt, (HD + feat) * 2)) = (opT)v;
+      if (X2ALL) *(opT*)(row + swz(pt, (LO + HD + feat) * 2)) = (opT)(v - (float)(opT)v);   // emb_lo
       if (MODE == 2 && !WIDE_E) *(__bf16*)(row + swz(pt, feat * 2)) = (__bf16)v;   // bf16 copy staged for the spill
     };
     if (prt == 0) {
@@ -370,7 +377,7 @@ __global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 && EP == HD ? 4 : 2)) voi
 #pragma unroll
     for (int e = 0; e < 8; ++e) r[e] = v[e] - (float)(_Float16)v[e];
     put_x(true, fb, pb, qp, v, 0);
-    put_x(true, fb, pb, qp, r, HD);
+    put_x(true, fb, pb, qp, r, LO);
   };
   for (int li = 0; li < L.L; ++li) {
     refresh();
@@ -379,12 +386,19 @@ __global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 && EP == HD ? 4 : 2)) voi
     // its hidden columns moves sdf by 3e-5 and is skipped), the layers past it W_lo a and W a_lo (a_lo sits in region 2,
     // which the forward pass no longer needs once the cat layer has consumed the embedding).  Numpy model of these
     // numerics vs the reference at BASELINE size: tests/precision_model.py, tools/studies/split_precision_study.py.
-    const bool comp = X2 && li >= L.cat;
-    if (li == 0)
+    const bool comp = X2 && (X2ALL || li >= L.cat);
+    if (li == 0) {
       gemm<F16, EP / 16, FB, PB, ROWB, T::CKF>(acc, wq, rsW, fwdW(setFwdA, li), X, HD * 2, lane, [] {});
-    else if (li == L.cat) {
+      if (X2ALL) {   // W_lo emb and W emb_lo
+        gemm<F16, EP / 16, FB, PB, ROWB, T::CKF>(acc, wq, rsW, fwdW(setFwdLo, li), X, HD * 2, lane, [] {});
+        gemm<F16, EP / 16, FB, PB, ROWB, T::CKF>(acc, wq, rsW, fwdW(setFwdA, li), X, (LO + HD) * 2, lane, [] {});
+      }
+    } else if (li == L.cat) {
       gemm<F16, (HD + EP) / 16, FB, PB, ROWB, T::CKF>(acc, wq, rsW, fwdW(setFwdA, li), X, 0, lane, [] {});
-      if (comp) {
+      if (X2ALL) {   // W_lo [a | emb] and W [a_lo | emb_lo]
+        gemm<F16, (HD + EP) / 16, FB, PB, ROWB, T::CKF>(acc, wq, rsW, fwdW(setFwdLo, li), X, 0, lane, [] {});
+        gemm<F16, (HD + EP) / 16, FB, PB, ROWB, T::CKF>(acc, wq, rsW, fwdW(setFwdA, li), X, LO * 2, lane, [] {});
+      } else if (comp) {
         WRef wl = fwdW(setFwdLo, li);
         wl.soff += (HD / 16) * 1024;   // k-steps HD/16 .. of every row block: the embedding columns
         gemm<F16, EP / 16, FB, PB, ROWB, T::CKF>(acc, wq, rsW, wl, X, HD * 2, lane, [] {});
@@ -393,7 +407,7 @@ __global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 && EP == HD ? 4 : 2)) voi
       gemm<F16, HD / 16, FB, PB, ROWB, T::CKF>(acc, wq, rsW, fwdW(setFwdA, li), X, 0, lane, [] {});
       if (comp) {
         gemm<F16, HD / 16, FB, PB, ROWB, T::CKF>(acc, wq, rsW, fwdW(setFwdLo, li), X, 0, lane, [] {});
-        gemm<F16, HD / 16, FB, PB, ROWB, T::CKF>(acc, wq, rsW, fwdW(setFwdA, li), X, HD * 2, lane, [] {});
+        gemm<F16, HD / 16, FB, PB, ROWB, T::CKF>(acc, wq, rsW, fwdW(setFwdA, li), X, LO * 2, lane, [] {});
       }
     }
     TS();
@@ -409,7 +423,7 @@ __global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 && EP == HD ? 4 : 2)) voi
 #pragma unroll
         for (int e = 0; e < 8; ++e) a[e] = softplus_f(acc[fb][pb][8 * qp + e] + bv[e]);
         if (MODE >= 1) store_tile8(p.sp.A[li + 1], fb, pb, qp, a);
-        if (comp) put_x_hilo(fb, pb, qp, a);
+        if (X2 && (X2ALL || li + 1 > L.cat)) put_x_hilo(fb, pb, qp, a);   // the NEXT layer reads a_lo
         else put_x(F16, fb, pb, qp, a, 0);
       });
     } else {
@@ -891,7 +905,7 @@ __global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 && EP == HD ? 4 : 2)) voi
 // ---------------------------------------------------------------------------
 template <int HD, int EP, int OPER, int MODE>
 static int launch_one(const ChainParams& p, int64_t nTiles, hipStream_t st) {
-  typedef Tile<HD, EP> T;
+  typedef Tile<HD, EP, oper_x2_all(OPER)> T;
   auto k = chain_kernel<HD, EP, OPER, MODE>;
   if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES) != hipSuccess) return ISDF_EHIP;
   hipLaunchKernelGGL(k, dim3((unsigned)nTiles), dim3(T::NW * 64), T::LDS_BYTES, st, p);
@@ -900,6 +914,10 @@ static int launch_one(const ChainParams& p, int64_t nTiles, hipStream_t st) {
 
 template <int HD, int EP, int MODE>
 static int launch_oper(const ChainParams& p, int64_t nTiles, hipStream_t st) {
+  if (p.lay.fwd_x2_all) {
+    if constexpr (HD == 256 && EP == 256) return launch_one<HD, EP, 3, MODE>(p, nTiles, st);
+    else return ISDF_EUNSUPPORTED;
+  }
   if (p.lay.fwd_x2) return launch_one<HD, EP, 2, MODE>(p, nTiles, st);
   return p.lay.fwd_f16 ? launch_one<HD, EP, 1, MODE>(p, nTiles, st) : launch_one<HD, EP, 0, MODE>(p, nTiles, st);
 }

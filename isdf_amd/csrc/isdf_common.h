@@ -31,6 +31,8 @@ struct NetLayout {
   int fwd_f16;                 // 1: fp16 operands in forward/first-backward GEMMs
   int fwd_x2;                  // 1: compensated forward ("fp16x2"): layers >= cat add W_lo * x (and, past the cat layer,
                                //    W * x_lo) so that sdf meets the reference to 1e-3
+  int fwd_x2_all;             // 1: "fp16x2_full" -- EVERY forward layer is compensated (weights and inputs, embedding included): the
+                               //    exact-forward instrument, sdf ~1e-6 of the fp32 reference; <256, 256> nets only
   int has_transform;
   float scale_input, scale_output;
   float T[12];
@@ -44,7 +46,7 @@ struct NetLayout {
   int64_t fwdSetElems, bwdSetElems;
   // the four sets inside the shadow buffer (element offsets)
   int64_t setFwdA, setFwdB, setBwdA, setBwdB;  // A: fwd_operand type, B: bf16
-  int64_t setFwdLo;            // fp16 residuals W - fp16(W) of the forward matrices of layers >= cat (fwd_x2 only)
+  int64_t setFwdLo;            // fp16 residuals W - fp16(W) of the forward matrices of layers >= cat (fwd_x2; all layers with fwd_x2_all)
   int64_t shadowElems;
 };
 
@@ -101,9 +103,10 @@ inline int make_layout(const isdf_net_cfg* c, NetLayout* l) {
   // shares region 2 of the activation tile with hidden-width operands)
   l->EP = round_up(l->E, 256) > l->HD ? round_up(l->E, 256) : l->HD;
   l->L = 2 * c->blocks + 2; l->cat = c->blocks + 1;
-  if (c->fwd_operand < 0 || c->fwd_operand > 2) return ISDF_EINVAL;
+  if (c->fwd_operand < 0 || c->fwd_operand > 3) return ISDF_EINVAL;
   l->fwd_f16 = c->fwd_operand ? 1 : 0;
-  l->fwd_x2 = c->fwd_operand == 2 ? 1 : 0;
+  l->fwd_x2 = c->fwd_operand >= 2 ? 1 : 0;
+  l->fwd_x2_all = c->fwd_operand == 3 ? 1 : 0;
   l->has_transform = c->has_transform;
   l->scale_input = c->scale_input; l->scale_output = c->scale_output;
   for (int i = 0; i < 12; ++i) l->T[i] = c->has_transform ? c->bounds_T[i] : (i % 5 == 0 ? 1.f : 0.f);
@@ -135,6 +138,8 @@ inline int make_layout(const isdf_net_cfg* c, NetLayout* l) {
 // n_freqs 6 -> E 255), <256, 512> (realsense*.json: hidden 256, n_freqs 9 / 11 -> E 381 / 465) and <512, 512>
 // (BASELINE configs[4]).  Other shapes: ISDF_EUNSUPPORTED.
 inline bool layout_supported(const NetLayout& l) {
+  // "fp16x2_full" keeps four operand regions (a, emb and their residuals) in the LDS tile: 128 KB at <256, 256>, too much beyond
+  if (l.fwd_x2_all) return l.HD == 256 && l.EP == 256;
   return (l.HD == 256 && (l.EP == 256 || l.EP == 512)) || (l.HD == 512 && l.EP == 512);
 }
 

@@ -94,7 +94,7 @@ __global__ void pack_kernel(NetLayout L, const float* __restrict__ P, uint16_t* 
   const uint4 hB = make_uint4(abf.x, abf.y, bbf.x, bbf.y);
   *(uint4*)(shadow + (isFwd ? L.setFwdA : L.setBwdA) + e0) = hA;
   *(uint4*)(shadow + (isFwd ? L.setFwdB : L.setBwdB) + e0) = hB;
-  if (L.fwd_x2 && isFwd && e0 >= L.fwdMat[L.cat]) {   // fp16 residuals of the compensated layers' weights
+  if (L.fwd_x2 && isFwd && (L.fwd_x2_all || e0 >= L.fwdMat[L.cat])) {   // fp16 residuals of the compensated layers' weights
     float r[8];
 #pragma unroll
     for (int t = 0; t < 8; ++t) r[t] = f16_residual(v[t]);
@@ -314,7 +314,7 @@ __global__ __launch_bounds__(1024) void step_tail_kernel(const TailParams p) {
     const float w = adamw_update(p.params, p.m, p.v, pi, s, gs, p.c);
     // packed operand copies (pack_kernel's sources, inverted): forward orientation ...
     const int KpF = li == 0 ? L.EP : (li == L.cat ? HD + L.EP : HD);
-    shadow_put(L, p.shadow, true, L.fwdMat[li] + packed_elem(o, col, KpF), w, L.fwd_x2 && li >= L.cat);
+    shadow_put(L, p.shadow, true, L.fwdMat[li] + packed_elem(o, col, KpF), w, L.fwd_x2 && (L.fwd_x2_all || li >= L.cat));
     // ... W^T restricted to the first HD inputs (layers >= 1) ...
     if (li >= 1 && col < HD) shadow_put(L, p.shadow, false, L.bwdMat[li] + packed_elem(col, o, HD), w);
     // ... and the embedding-gradient matrix [W_in^T | W_cat[:, HD:]^T]

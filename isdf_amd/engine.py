@@ -17,7 +17,7 @@ import torch
 from . import _ffi
 
 N_DIRS = 21
-FWD_OPERANDS = ("bf16", "fp16", "fp16x2")   # isdf_net_cfg.fwd_operand = index
+FWD_OPERANDS = ("bf16", "fp16", "fp16x2", "fp16x2_full")   # isdf_net_cfg.fwd_operand = index
 
 
 @dataclass
@@ -32,6 +32,8 @@ class NetConfig:
     # MFMA operand type of the forward / first-backward GEMMs (include/isdf_hip.h `fwd_operand`):
     #   "fp16x2" (default) fp16 with the compensated forward of layers >= cat -- sdf within 1e-3 of the reference
     #   "fp16"   plain fp16 operands (fast mode: sdf 0.9e-3 .. 1.5e-3 at BASELINE size);  "bf16" plain bf16 (1.1e-2)
+    #   "fp16x2_full"  every forward layer compensated (exact-forward instrument: sdf ~1e-6, d sdf/dx < 1e-3 of the reference;
+    #            hidden 256 / n_freqs <= 6 nets only, one workgroup per CU: slower)
     fwd_operand: str = "fp16x2"
 
     @property

@@ -21,22 +21,30 @@ def bf16(x):
 
 def forward(params, cfg, x, operand="fp16"):
     """operand "fp16x2": the compensated forward (isdf_amd/csrc/chain.hip, OPER 2) -- the cat layer adds W_lo[:, H:] emb,
-    the layers past it W_lo x and W x_lo (W_lo = fp16(W - fp16(W)), x_lo = fp16(x - fp16(x)))."""
+    the layers past it W_lo x and W x_lo (W_lo = fp16(W - fp16(W)), x_lo = fp16(x - fp16(x))).
+    "fp16x2_full" (OPER 3): those three products in EVERY layer, the embedding included."""
     x2 = operand == "fp16x2"
+    full = operand == "fp16x2_full"
     q = bf16 if operand == "bf16" else f16
     x = np.asarray(x, np.float32).reshape(-1, 3)
-    e = q(orc.positional_encoding(x, cfg.transform, cfg.scale_input, cfg.n_freqs))
-    a = e
+    ef = orc.positional_encoding(x, cfg.transform, cfg.scale_input, cfg.n_freqs)
+    e = q(ef)
+    e_lo = f16(ef - e)
+    a, a_lo = e, e_lo
     for li, n in enumerate(cfg.names):
         inp = np.concatenate([a, e], -1) if li == cfg.cat else a
         W = params[n + ".weight"]
         z = inp @ q(W).T
-        if x2 and li == cfg.cat:      # residual of the embedding columns only
+        if full:
+            inp_lo = np.concatenate([a_lo, e_lo], -1) if li == cfg.cat else a_lo
+            z = z + inp @ f16(W - f16(W)).T + inp_lo @ f16(W).T
+        elif x2 and li == cfg.cat:      # residual of the embedding columns only
             z = z + e @ f16(W - f16(W))[:, cfg.H:].T
         elif x2 and li > cfg.cat:
             z = z + inp @ f16(W - f16(W)).T + f16(af - a) @ f16(W).T
         z = z + params[n + ".bias"]
         af = orc.softplus(z)
         a = q(af)
+        a_lo = f16(af - a)
     raw = af @ params["out_alpha.weight"][0] + params["out_alpha.bias"][0]
     return raw * np.float32(cfg.scale_output)

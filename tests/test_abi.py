@@ -46,8 +46,12 @@ def test_size_queries_default_net(lib):
     assert sh == 2 * (3 * fwd + 2 * bwd)      # default "fp16x2": + one forward set of fp16 weight residuals
     for op, sets in (("fp16", 2), ("bf16", 2)):
         assert lib.isdf_shadow_bytes(C.byref(NetConfig(fwd_operand=op).to_c())) == 2 * (sets * fwd + 2 * bwd)
+    full = NetConfig(fwd_operand="fp16x2_full").to_c()       # exact-forward instrument: same residual set, used by every layer
+    assert lib.isdf_shadow_bytes(C.byref(full)) == sh and lib.isdf_check_net(C.byref(full)) == 0
+    for wide in (NetConfig(fwd_operand="fp16x2_full", n_freqs=9, blocks=3), NetConfig(fwd_operand="fp16x2_full", hidden=512, n_freqs=10)):
+        assert lib.isdf_check_net(C.byref(wide.to_c())) == -2     # ISDF_EUNSUPPORTED: four operand regions do not fit those tiles
     bad = NetConfig().to_c()
-    bad.fwd_operand = 3
+    bad.fwd_operand = 4
     assert lib.isdf_shadow_bytes(C.byref(bad)) == -1
     assert lib.isdf_workspace_bytes(C.byref(c), 27000, 1) > lib.isdf_workspace_bytes(C.byref(c), 27000, 0) > 0
 

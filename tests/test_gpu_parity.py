@@ -686,9 +686,14 @@ def test_base_size_sampler_bit_exact_vs_reference(case):
 # rounding of the weights and inputs of the last three hidden layers): it is checked against the MODEL and not held to
 # the north star; FAST_MODE_SDF_FLOOR only bounds it from above so a regression would show.
 FAST_MODE_SDF_FLOOR = 2e-3
+# "fp16x2_full" (OPER 3, every forward layer compensated): the exact-forward instrument SURVEY 8c asks for.  It settles on
+# the hardware that what separates the shipped modes from the reference is operand rounding and nothing else (sdf at the
+# fp32 level), and it is the mode in which d sdf/dx meets SURVEY 8c's 1e-3 (first reverse sweep still plain fp16).
+SDF_BAR = {"fp16x2": TOL_SDF, "fp16": FAST_MODE_SDF_FLOOR, "fp16x2_full": 2e-5}
+SDF_GRAD_BAR = {"fp16x2": TOL_SDF_GRAD, "fp16": 2.5e-3, "fp16x2_full": 1e-3}
 
 
-@pytest.mark.parametrize("fwd_operand", ["fp16x2", "fp16"])
+@pytest.mark.parametrize("fwd_operand", ["fp16x2", "fp16", "fp16x2_full"])
 @pytest.mark.parametrize("case", BASE_CASES + ["eval_full_ray"])
 def test_base_size_forward_and_input_gradient_vs_reference(case, fwd_operand):
     from tests import precision_model as pm
@@ -707,11 +712,24 @@ def test_base_size_forward_and_input_gradient_vs_reference(case, fwd_operand):
     floor = gu.rel_err(model, ref)
     print("%s %s: sdf rel-L2 vs reference %.3e, vs operand model %.3e, model vs reference %.3e; d sdf/dx %.3e"
           % (case, fwd_operand, err, err_model, floor, gerr))
-    assert err_model < 6e-4, err_model   # accumulation order, v_sin/v_exp/v_log approximations, fp16 subnormal operands
+    assert err_model < (2e-5 if fwd_operand == "fp16x2_full" else 6e-4), err_model   # accumulation order, v_sin/v_exp/v_log approximations, fp16 subnormal operands
     # (2) against the REFERENCE
-    assert err < (TOL_SDF if fwd_operand == "fp16x2" else FAST_MODE_SDF_FLOOR), err
-    assert _scaled_err(sdf, ref, 0.14) < TOL_SDF          # max error on the scale of the network output
-    assert gerr < (TOL_SDF_GRAD if fwd_operand == "fp16x2" else 2.5e-3), gerr
+    assert err < SDF_BAR[fwd_operand], err
+    assert _scaled_err(sdf, ref, 0.14) < (1e-4 if fwd_operand == "fp16x2_full" else TOL_SDF)   # max error on the scale of the network output
+    assert gerr < SDF_GRAD_BAR[fwd_operand], gerr
+
+
+def test_exact_forward_mode_trains_like_the_reference():
+    """The training step in the exact-forward mode (MODE 2 of OPER 3: one workgroup per CU, four operand regions) at BASELINE
+    size: losses, d sdf/dx (1e-3) and all 14 gradients against the reference's digests."""
+    g = gu.load("eval_base_480x640_ray")
+    eng, s, dbg, terms, grads, R = _run_step(g, fwd_operand="fp16x2_full")
+    N = R * s["S"]
+    _check_losses(eng, N, g)
+    assert gu.rel_err(dbg["sdf"][:R].cpu().numpy(), terms["sdf"]) < 2e-5
+    assert gu.rel_err(dbg["sdf_grad"][:R].cpu().numpy(), terms["sdf_grad"]) < 1e-3
+    _check_grads_vs_reference_digest(eng, N, g)
+    _check_grads_vs_oracle(eng, N, grads)
 
 
 @pytest.mark.parametrize("fwd_operand", ["fp16x2", "fp16"])
