@@ -81,7 +81,9 @@ __device__ __forceinline__ void load_w(WChunk<FBN, CKF>& wq, rsrc_t rw, WRef r, 
       wq.v[s][fb] = bload16<0>(rw, lane16 + (s & 3) * 1024, r.soff + fb * r.rb + chunk * CK * 1024 + (s >> 2) * 4096);
 }
 
-template <bool F16, int KSTEPS, int FBN, int PBN, int ROWB, int CKF, typename Hook>
+// ZERO: the accumulators start from zero -- the first k-step's MFMAs take the inline constant 0 as their C operand instead of
+// 16 * FBN * PBN v_mov_b32 zeroing the registers beforehand (8 % of the kernel's VALU instructions).
+template <bool F16, int KSTEPS, int FBN, int PBN, int ROWB, int CKF, bool ZERO = false, typename Hook>
 __device__ __forceinline__ void gemm(f32x16 (&acc)[FBN][PBN], WChunk<FBN, CKF>& wq, rsrc_t rw, WRef wr, const char* xl,
                                      int colByteBase, int lane, Hook&& postHook) {
   constexpr int CK = CKF / FBN;                  // k-steps per chunk: CK*FBN uint4 = 32 VGPRs
@@ -98,7 +100,7 @@ __device__ __forceinline__ void gemm(f32x16 (&acc)[FBN][PBN], WChunk<FBN, CKF>& 
   load_w(wq, rw, wr, lane16, 0);
   // One chunk: the activation operand is read one k-step ahead of the MFMAs that consume it; the weight registers are
   // re-requested for the next chunk after the chunk's last MFMA.
-  auto chunk = [&](int ch, auto refill) {
+  auto chunk = [&](int ch, auto refill, auto zero) {
     const int k0 = ch * CK;
     int xch = (xlane ^ ((k0 & 7) * 32)) + (k0 >> 3) * 256 + colByteBase;
     // opaque to the optimiser: otherwise the 8 per-k-step addresses (xch ^ s*32) are hoisted out of the layer loops as
@@ -119,7 +121,8 @@ __device__ __forceinline__ void gemm(f32x16 (&acc)[FBN][PBN], WChunk<FBN, CKF>& 
       for (int fb = 0; fb < FBN; ++fb)
 #pragma unroll
         for (int pb = 0; pb < PBN; ++pb)
-          acc[fb][pb] = Op<F16>::mfma(__builtin_bit_cast(v8, wq.v[s][fb]), b[s & 1][pb], acc[fb][pb]);
+          acc[fb][pb] = Op<F16>::mfma(__builtin_bit_cast(v8, wq.v[s][fb]), b[s & 1][pb],
+                                      (decltype(zero)::value && s == 0) ? f32x16(0.f) : acc[fb][pb]);
       __builtin_amdgcn_sched_barrier(0);
     }
     if (decltype(refill)::value) {
@@ -127,10 +130,12 @@ __device__ __forceinline__ void gemm(f32x16 (&acc)[FBN][PBN], WChunk<FBN, CKF>& 
       __builtin_amdgcn_sched_barrier(0);
     }
   };
+  static_assert(NCH >= 2, "the first chunk is peeled");
+  chunk(0, std::true_type{}, std::integral_constant<bool, ZERO>{});
 #pragma unroll 1
-  for (int ch = 0; ch < NCH - 1; ++ch) chunk(ch, std::true_type{});
+  for (int ch = 1; ch < NCH - 1; ++ch) chunk(ch, std::true_type{}, std::false_type{});
   __builtin_amdgcn_sched_barrier(0);
-  chunk(NCH - 1, std::false_type{});
+  chunk(NCH - 1, std::false_type{}, std::false_type{});
   postHook();
 }
 
@@ -381,20 +386,19 @@ __global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 && EP == HD && !oper_x2_a
   };
   for (int li = 0; li < L.L; ++li) {
     refresh();
-    zero_acc(acc);
     // compensated layers (OPER 2): the cat layer adds W_lo[:, HD:] emb (the residual of its embedding columns; the one of
     // its hidden columns moves sdf by 3e-5 and is skipped), the layers past it W_lo a and W a_lo (a_lo sits in region 2,
     // which the forward pass no longer needs once the cat layer has consumed the embedding).  Numpy model of these
     // numerics vs the reference at BASELINE size: tests/precision_model.py, tools/studies/split_precision_study.py.
     const bool comp = X2 && (X2ALL || li >= L.cat);
     if (li == 0) {
-      gemm<F16, EP / 16, FB, PB, ROWB, T::CKF>(acc, wq, rsW, fwdW(setFwdA, li), X, HD * 2, lane, [] {});
+      gemm<F16, EP / 16, FB, PB, ROWB, T::CKF, true>(acc, wq, rsW, fwdW(setFwdA, li), X, HD * 2, lane, [] {});
       if (X2ALL) {   // W_lo emb and W emb_lo
         gemm<F16, EP / 16, FB, PB, ROWB, T::CKF>(acc, wq, rsW, fwdW(setFwdLo, li), X, HD * 2, lane, [] {});
         gemm<F16, EP / 16, FB, PB, ROWB, T::CKF>(acc, wq, rsW, fwdW(setFwdA, li), X, (LO + HD) * 2, lane, [] {});
       }
     } else if (li == L.cat) {
-      gemm<F16, (HD + EP) / 16, FB, PB, ROWB, T::CKF>(acc, wq, rsW, fwdW(setFwdA, li), X, 0, lane, [] {});
+      gemm<F16, (HD + EP) / 16, FB, PB, ROWB, T::CKF, true>(acc, wq, rsW, fwdW(setFwdA, li), X, 0, lane, [] {});
       if (X2ALL) {   // W_lo [a | emb] and W [a_lo | emb_lo]
         gemm<F16, (HD + EP) / 16, FB, PB, ROWB, T::CKF>(acc, wq, rsW, fwdW(setFwdLo, li), X, 0, lane, [] {});
         gemm<F16, (HD + EP) / 16, FB, PB, ROWB, T::CKF>(acc, wq, rsW, fwdW(setFwdA, li), X, LO * 2, lane, [] {});
@@ -404,7 +408,7 @@ __global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 && EP == HD && !oper_x2_a
         gemm<F16, EP / 16, FB, PB, ROWB, T::CKF>(acc, wq, rsW, wl, X, HD * 2, lane, [] {});
       }
     } else {
-      gemm<F16, HD / 16, FB, PB, ROWB, T::CKF>(acc, wq, rsW, fwdW(setFwdA, li), X, 0, lane, [] {});
+      gemm<F16, HD / 16, FB, PB, ROWB, T::CKF, true>(acc, wq, rsW, fwdW(setFwdA, li), X, 0, lane, [] {});
       if (comp) {
         gemm<F16, HD / 16, FB, PB, ROWB, T::CKF>(acc, wq, rsW, fwdW(setFwdLo, li), X, 0, lane, [] {});
         gemm<F16, HD / 16, FB, PB, ROWB, T::CKF>(acc, wq, rsW, fwdW(setFwdA, li), X, LO * 2, lane, [] {});
@@ -482,9 +486,8 @@ __global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 && EP == HD && !oper_x2_a
   PRIO(1);
   for (int li = L.L - 1; li >= 1; --li) {
     Pre preA;   // a_{li-1}: sigma'(z_{li-1}) is re-derived from it
-    zero_acc(acc);
     refresh();
-    gemm<F16, HD / 16, FB, PB, ROWB, T::CKF>(acc, wq, rsW, wptr(setBwdA, L.bwdMat[li], HD), X, 0, lane,
+    gemm<F16, HD / 16, FB, PB, ROWB, T::CKF, true>(acc, wq, rsW, wptr(setBwdA, L.bwdMat[li], HD), X, 0, lane,
                                              [&] { prefetch(p.sp.A[li], preA); });
     TS();
     lds_barrier();
@@ -505,7 +508,6 @@ __global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 && EP == HD && !oper_x2_a
     TS();
   }
   // Eg = [W_in^T | W_cat[:,HD:]^T] [p_0 ; p_cat]   (rows = embedding features)
-  zero_acc(acc);
   // the loss stage's per-ray inputs are requested behind the G gemm so that its single working wave
   // does not start with a dependent HBM round trip
   float li_bnd = 0.f, li_c[3] = {0.f, 0.f, 0.f}, li_dz[2] = {0.f, 0.f}, li_t[3] = {0.f, 0.f, 0.f}, li_n[3] = {0.f, 0.f, 0.f};
@@ -526,7 +528,7 @@ __global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 && EP == HD && !oper_x2_a
   };
   refresh();
   if constexpr (!WIDE_E) {
-  gemm<F16, (2 * HD) / 16, FB, PB, ROWB, T::CKF>(acc, wq, rsW, wptr(setBwdA, L.bwdG, 2 * HD), X, 0, lane, loss_inputs);
+  gemm<F16, (2 * HD) / 16, FB, PB, ROWB, T::CKF, true>(acc, wq, rsW, wptr(setBwdA, L.bwdG, 2 * HD), X, 0, lane, loss_inputs);
   TS();   // (development build: G gemm done)
   // g_x' = J_pe^T Eg.  Eg goes through the (now idle) X tile as fp32 [BM][HD] so the contraction can run in
   // the PE stage's (point, direction-slice) mapping: 2*nf sin/cos per direction per thread and wave-uniform
@@ -586,11 +588,11 @@ __global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 && EP == HD && !oper_x2_a
     const int half = N_DIRS * nf;
 #pragma unroll
     for (int rh = 0; rh < EP / HD; ++rh) {
-      if (rh > 0) { zero_acc(acc); refresh(); }
+      if (rh > 0) refresh();
       WRef wg = wptr(setBwdA, L.bwdG, 2 * HD);
       wg.soff += rh * (HD / 32) * ((2 * HD) / 16) * 1024;
-      if (rh == 0) gemm<F16, (2 * HD) / 16, FB, PB, ROWB, T::CKF>(acc, wq, rsW, wg, X, 0, lane, loss_inputs);
-      else gemm<F16, (2 * HD) / 16, FB, PB, ROWB, T::CKF>(acc, wq, rsW, wg, X, 0, lane, [] {});
+      if (rh == 0) gemm<F16, (2 * HD) / 16, FB, PB, ROWB, T::CKF, true>(acc, wq, rsW, wg, X, 0, lane, loss_inputs);
+      else gemm<F16, (2 * HD) / 16, FB, PB, ROWB, T::CKF, true>(acc, wq, rsW, wg, X, 0, lane, [] {});
       refresh();
 #pragma unroll
       for (int pb = 0; pb < PB; ++pb) {
@@ -780,14 +782,13 @@ __global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 && EP == HD && !oper_x2_a
   // starts at layer L-2 with its operand already in the X tile.
   PRIO(2);
   auto adj_gemm = [&](int li, auto&& pf) {
-    zero_acc(acc);
     refresh();
     if (li == 0)
-      gemm<false, EP / 16, FB, PB, ROWB, T::CKF>(acc, wq, rsW, fwdW(setFwdB, li), X, HD * 2, lane, pf);
+      gemm<false, EP / 16, FB, PB, ROWB, T::CKF, true>(acc, wq, rsW, fwdW(setFwdB, li), X, HD * 2, lane, pf);
     else if (li == L.cat)
-      gemm<false, (HD + EP) / 16, FB, PB, ROWB, T::CKF>(acc, wq, rsW, fwdW(setFwdB, li), X, 0, lane, pf);
+      gemm<false, (HD + EP) / 16, FB, PB, ROWB, T::CKF, true>(acc, wq, rsW, fwdW(setFwdB, li), X, 0, lane, pf);
     else
-      gemm<false, HD / 16, FB, PB, ROWB, T::CKF>(acc, wq, rsW, fwdW(setFwdB, li), X, 0, lane, pf);
+      gemm<false, HD / 16, FB, PB, ROWB, T::CKF, true>(acc, wq, rsW, fwdW(setFwdB, li), X, 0, lane, pf);
   };
   for (int li = 0; li < L.L - 1; ++li) {
     Pre preA, preP;
@@ -866,9 +867,8 @@ __global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 && EP == HD && !oper_x2_a
   PRIO(3);
   for (int li = L.L - 2; li >= 0; --li) {
     Pre preA, preI;
-    zero_acc(acc);
     refresh();
-    gemm<false, HD / 16, FB, PB, ROWB, T::CKF>(acc, wq, rsW, wptr(setBwdB, L.bwdMat[li + 1], HD), X, 0, lane,
+    gemm<false, HD / 16, FB, PB, ROWB, T::CKF, true>(acc, wq, rsW, wptr(setBwdB, L.bwdMat[li + 1], HD), X, 0, lane,
                                                [&] { prefetch(p.sp.A[li + 1], preA); prefetch(p.sp.INJ[li], preI); });
     TS();
     lds_barrier();
