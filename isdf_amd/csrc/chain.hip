@@ -83,9 +83,11 @@ __device__ __forceinline__ void load_w(WChunk<FBN, CKF>& wq, rsrc_t rw, WRef r, 
 
 // ZERO: the accumulators start from zero -- the first k-step's MFMAs take the inline constant 0 as their C operand instead of
 // 16 * FBN * PBN v_mov_b32 zeroing the registers beforehand (8 % of the kernel's VALU instructions).
-template <bool F16, int KSTEPS, int FBN, int PBN, int ROWB, int CKF, bool ZERO = false, typename Hook>
+// TWO: every weight fragment also multiplies a SECOND activation operand at column colByteBase2 (W a_hi + W a_lo of a compensated
+// layer in one pass over W: the vector-memory path is the kernel's busiest unit, a second pass would fetch the matrix again).
+template <bool F16, int KSTEPS, int FBN, int PBN, int ROWB, int CKF, bool ZERO = false, bool TWO = false, typename Hook>
 __device__ __forceinline__ void gemm(f32x16 (&acc)[FBN][PBN], WChunk<FBN, CKF>& wq, rsrc_t rw, WRef wr, const char* xl,
-                                     int colByteBase, int lane, Hook&& postHook) {
+                                     int colByteBase, int lane, Hook&& postHook, int colByteBase2 = 0) {
   constexpr int CK = CKF / FBN;                  // k-steps per chunk: CK*FBN uint4 = 32 VGPRs
   static_assert(KSTEPS % CK == 0, "K must be a multiple of the chunk");
   static_assert((ROWB & 255) == 0, "row base must leave the swizzle bits (4-7) clear");
@@ -106,12 +108,18 @@ __device__ __forceinline__ void gemm(f32x16 (&acc)[FBN][PBN], WChunk<FBN, CKF>& 
     // opaque to the optimiser: otherwise the 8 per-k-step addresses (xch ^ s*32) are hoisted out of the layer loops as
     // lane constants, spilled, and reloaded in the middle of the MFMA stream behind an s_waitcnt vmcnt(0)
     asm volatile("" : "+v"(xch));
-    auto readb = [&](int s, v8 (&b)[PBN]) {
+    constexpr int NB = TWO ? 2 * PBN : PBN;
+    auto readb = [&](int s, v8 (&b)[NB]) {
 #pragma unroll
       for (int pb = 0; pb < PBN; ++pb)
         b[pb] = __builtin_bit_cast(v8, *(const uint4*)(xl + ((xch ^ (s * 32)) + pb * 32 * ROWB)));
+      if constexpr (TWO) {
+#pragma unroll
+        for (int pb = 0; pb < PBN; ++pb)
+          b[PBN + pb] = __builtin_bit_cast(v8, *(const uint4*)(xl + ((xch ^ (s * 32)) + pb * 32 * ROWB + (colByteBase2 - colByteBase))));
+      }
     };
-    v8 b[2][PBN];
+    v8 b[2][NB];
     readb(0, b[0]);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -123,6 +131,13 @@ __device__ __forceinline__ void gemm(f32x16 (&acc)[FBN][PBN], WChunk<FBN, CKF>& 
         for (int pb = 0; pb < PBN; ++pb)
           acc[fb][pb] = Op<F16>::mfma(__builtin_bit_cast(v8, wq.v[s][fb]), b[s & 1][pb],
                                       (decltype(zero)::value && s == 0) ? f32x16(0.f) : acc[fb][pb]);
+      if constexpr (TWO) {
+#pragma unroll
+        for (int fb = 0; fb < FBN; ++fb)
+#pragma unroll
+          for (int pb = 0; pb < PBN; ++pb)
+            acc[fb][pb] = Op<F16>::mfma(__builtin_bit_cast(v8, wq.v[s][fb]), b[s & 1][PBN + pb], acc[fb][pb]);
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
     if (decltype(refill)::value) {
@@ -314,6 +329,7 @@ __global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 && EP == HD && !oper_x2_a
     return wptr(set, L.fwdMat[li], li == 0 ? EP : (li == L.cat ? HD + EP : HD));
   };
   WChunk<FB, T::CKF> wq;   // the weight-fragment registers of the running gemm
+  WChunk<FB, T::CKF / 2> wq2;   // ... of a two-operand gemm: half the k-steps per chunk, twice the activation registers
   // iterate the wave's accumulator as (fb, pb, qp) blocks of 8 values:
   // values v[0..3] -> features f0..f0+3, v[4..7] -> f0+8..f0+11, point row = pb*32+j
   auto for_blocks2 = [&](auto&& fn, auto&& tail) {
@@ -392,26 +408,30 @@ __global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 && EP == HD && !oper_x2_a
     // numerics vs the reference at BASELINE size: tests/precision_model.py, tools/studies/split_precision_study.py.
     const bool comp = X2 && (X2ALL || li >= L.cat);
     if (li == 0) {
-      gemm<F16, EP / 16, FB, PB, ROWB, T::CKF, true>(acc, wq, rsW, fwdW(setFwdA, li), X, HD * 2, lane, [] {});
-      if (X2ALL) {   // W_lo emb and W emb_lo
+      if (X2ALL) {   // W (emb + emb_lo) in one pass over W, then W_lo emb
+        gemm<F16, EP / 16, FB, PB, ROWB, T::CKF / 2, true, true>(acc, wq2, rsW, fwdW(setFwdA, li), X, HD * 2, lane, [] {}, (LO + HD) * 2);
         gemm<F16, EP / 16, FB, PB, ROWB, T::CKF>(acc, wq, rsW, fwdW(setFwdLo, li), X, HD * 2, lane, [] {});
-        gemm<F16, EP / 16, FB, PB, ROWB, T::CKF>(acc, wq, rsW, fwdW(setFwdA, li), X, (LO + HD) * 2, lane, [] {});
+      } else {
+        gemm<F16, EP / 16, FB, PB, ROWB, T::CKF, true>(acc, wq, rsW, fwdW(setFwdA, li), X, HD * 2, lane, [] {});
       }
     } else if (li == L.cat) {
-      gemm<F16, (HD + EP) / 16, FB, PB, ROWB, T::CKF, true>(acc, wq, rsW, fwdW(setFwdA, li), X, 0, lane, [] {});
-      if (X2ALL) {   // W_lo [a | emb] and W [a_lo | emb_lo]
+      if (X2ALL) {   // W ([a | emb] + [a_lo | emb_lo]) in one pass over W, then W_lo [a | emb]
+        gemm<F16, (HD + EP) / 16, FB, PB, ROWB, T::CKF / 2, true, true>(acc, wq2, rsW, fwdW(setFwdA, li), X, 0, lane, [] {}, LO * 2);
         gemm<F16, (HD + EP) / 16, FB, PB, ROWB, T::CKF>(acc, wq, rsW, fwdW(setFwdLo, li), X, 0, lane, [] {});
-        gemm<F16, (HD + EP) / 16, FB, PB, ROWB, T::CKF>(acc, wq, rsW, fwdW(setFwdA, li), X, LO * 2, lane, [] {});
-      } else if (comp) {
+      } else {
+        gemm<F16, (HD + EP) / 16, FB, PB, ROWB, T::CKF, true>(acc, wq, rsW, fwdW(setFwdA, li), X, 0, lane, [] {});
+      }
+      if (!X2ALL && comp) {
         WRef wl = fwdW(setFwdLo, li);
         wl.soff += (HD / 16) * 1024;   // k-steps HD/16 .. of every row block: the embedding columns
         gemm<F16, EP / 16, FB, PB, ROWB, T::CKF>(acc, wq, rsW, wl, X, HD * 2, lane, [] {});
       }
     } else {
-      gemm<F16, HD / 16, FB, PB, ROWB, T::CKF, true>(acc, wq, rsW, fwdW(setFwdA, li), X, 0, lane, [] {});
-      if (comp) {
+      if (comp) {   // W (a + a_lo) in one pass over W, then W_lo a
+        gemm<F16, HD / 16, FB, PB, ROWB, T::CKF / 2, true, true>(acc, wq2, rsW, fwdW(setFwdA, li), X, 0, lane, [] {}, LO * 2);
         gemm<F16, HD / 16, FB, PB, ROWB, T::CKF>(acc, wq, rsW, fwdW(setFwdLo, li), X, 0, lane, [] {});
-        gemm<F16, HD / 16, FB, PB, ROWB, T::CKF>(acc, wq, rsW, fwdW(setFwdA, li), X, LO * 2, lane, [] {});
+      } else {
+        gemm<F16, HD / 16, FB, PB, ROWB, T::CKF, true>(acc, wq, rsW, fwdW(setFwdA, li), X, 0, lane, [] {});
       }
     }
     TS();
