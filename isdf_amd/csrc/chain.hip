@@ -244,9 +244,17 @@ __global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 && EP == HD && !oper_x2_a
     for (int e = 0; e < 4; ++e) { o[e] = __uint_as_float(a[e]); o[4 + e] = __uint_as_float(b[e]); }
   };
   // per-workgroup partial of a bias / out-layer gradient entry: sum over the half-wave's 32 points
-  auto vec_store = [&](float v, int elemUniform) {
-    v = half_wave_sum(v);
-    if (j == 0) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsV, 16 * hi, elemUniform * 4, 0);
+  // The 8 values of an accumulator block (features elemUniform + 4*hi + {0..3, 8..11}) go out in ONE store: after the butterflies
+  // every lane holds all eight sums, lane j < 8 of each half keeps sum j and writes it to its feature.  (One store per VALUE made
+  // these two-dword partials half of the kernel's store instructions, and the vector-memory path is its busiest unit.)
+  auto vec_store8 = [&](float (&v)[8], int elemUniform) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = half_wave_sum(v[e]);
+    const bool b0 = j & 1, b1 = j & 2, b2 = j & 4;
+    const float t0 = b0 ? v[1] : v[0], t1 = b0 ? v[3] : v[2], t2 = b0 ? v[5] : v[4], t3 = b0 ? v[7] : v[6];
+    const float u0 = b1 ? t1 : t0, u1 = b1 ? t3 : t2;
+    const float r = b2 ? u1 : u0;   // = v[j & 7]
+    if (j < 8) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(r), rsV, 16 * hi + 4 * (j & 3) + 32 * (j >> 2), elemUniform * 4, 0);
   };
 
   // ------------------------------------------------------------------ PE stage
@@ -870,13 +878,12 @@ __global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 && EP == HD && !oper_x2_a
       if (li > 0) put_x(false, fb, pb, qp, zb, 0);
     }, [&](int fb, int qp) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const int f = ubase(fb, qp) + (e & 3) + 8 * (e >> 2);   // + 4*hi in the lane offset
-        vec_store(so * qsum[e], L.L * HD + f);        // d w_out += so * sum_pts qbar_L
-        vec_store(wsum[e], L.L * HD + HD + f);        // d w_out += sum_pts sbar*so * a_L
-        vec_store(bsum[e], li * HD + f);
-        qsum[e] = 0.f; bsum[e] = 0.f; wsum[e] = 0.f;
-      }
+      for (int e = 0; e < 8; ++e) qsum[e] *= so;
+      vec_store8(qsum, L.L * HD + ubase(fb, qp));        // d w_out += so * sum_pts qbar_L
+      vec_store8(wsum, L.L * HD + HD + ubase(fb, qp));   // d w_out += sum_pts sbar*so * a_L
+      vec_store8(bsum, li * HD + ubase(fb, qp));
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { qsum[e] = 0.f; bsum[e] = 0.f; wsum[e] = 0.f; }
     });
     TS();
     lds_barrier();
@@ -909,11 +916,9 @@ __global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 && EP == HD && !oper_x2_a
       store_tile8_dw(p.sp.ZB[li], fb, pb, qp, zb);
       if (li > 0) put_x(false, fb, pb, qp, zb, 0);
     }, [&](int fb, int qp) {
+      vec_store8(bsum, li * HD + ubase(fb, qp));
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        vec_store(bsum[e], li * HD + ubase(fb, qp) + (e & 3) + 8 * (e >> 2));
-        bsum[e] = 0.f;
-      }
+      for (int e = 0; e < 8; ++e) bsum[e] = 0.f;
     });
     TS();
     lds_barrier();
