@@ -67,7 +67,8 @@ struct Tile {
 // and the k-steps are fully unrolled.  `postHook` (the epilogue's spill-tile requests) is issued right
 // after the last MFMA, when the weight registers are dead: vmcnt retires in order, so a request in front
 // of a weight load would put its HBM round trip into the MFMA stream, and requesting earlier costs
-// registers the 128-VGPR budget does not have (measured variants: profiles/r02_ab_chain_variants.txt).
+// registers the 128-VGPR budget does not have (measured variants: profiles/r02_ab_chain_variants.txt; issuing the
+// requests behind the LAST weight request in the middle of the GEMM measured +2 .. +9 %: profiles/r03_whatif_spill_traffic.txt).
 template <int FBN, int CKF> struct WChunk { uint4 v[CKF / FBN][FBN]; };   // one chunk of packed weight fragments (32 VGPRs)
 struct WRef { int soff; int rb; };   // byte offset of a wave's slice of a packed matrix in the shadow buffer + row-block stride (bytes)
 
@@ -152,15 +153,6 @@ __device__ __forceinline__ void gemm(f32x16 (&acc)[FBN][PBN], WChunk<FBN, CKF>& 
   __builtin_amdgcn_sched_barrier(0);
   chunk(NCH - 1, std::false_type{}, std::false_type{});
   postHook();
-}
-
-template <int FBN, int PBN> __device__ __forceinline__ void zero_acc(f32x16 (&acc)[FBN][PBN]) {
-#pragma unroll
-  for (int fb = 0; fb < FBN; ++fb)
-#pragma unroll
-    for (int pb = 0; pb < PBN; ++pb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[fb][pb][r] = 0.f;
 }
 
 // frag16 spill order: element offset inside a tile for (wave, fb, pb, qp, lane)
