@@ -368,7 +368,7 @@ __global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 && EP == HD && !oper_x2_a
     bstore16_nt<true>(make_uint4(a.x, a.y, b.x, b.y), srdS, lane16, sbase(tensorOff), cidx(fb, pb, qp));
   };
   // tensors that only the dW kernel re-reads (GB, ZB) are stored with the default cache policy (chain -2.3 %, dW unchanged);
-  // everything the chain kernel itself re-reads (A, P, INJ) stays non-temporal
+  // A and P, which the chain kernel itself re-reads most, stay non-temporal
   auto store_tile8_dw = [&](int64_t tensorOff, int fb, int pb, int qp, const float (&v)[8]) {
     const uint2 a = pack4<false>(v[0], v[1], v[2], v[3]), b = pack4<false>(v[4], v[5], v[6], v[7]);
     bstore16_nt<false>(make_uint4(a.x, a.y, b.x, b.y), srdS, lane16, sbase(tensorOff), cidx(fb, pb, qp));
@@ -798,7 +798,7 @@ __global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 && EP == HD && !oper_x2_a
 
   // ------------------------------------------------------------------ adjoint of the first reverse sweep (upward)
   // The top layer's epilogue also IS the top of the ordinary reverse sweep (zbar_L needs only a_L, the
-  // injection just computed and sbar*w_out), so INJ[L-1] never leaves registers and the reverse sweep
+  // injection just computed and sbar*w_out), so it never leaves registers and the reverse sweep
   // starts at layer L-2 with its operand already in the X tile.
   PRIO(2);
   auto adj_gemm = [&](int li, auto&& pf) {
@@ -810,25 +810,21 @@ __global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 && EP == HD && !oper_x2_a
     else
       gemm<false, HD / 16, FB, PB, ROWB, T::CKF, true>(acc, wq, rsW, fwdW(setFwdB, li), X, 0, lane, pf);
   };
+  // The injected second-order term of layer li, u q sigma''(z) = beta (u sigma') (q sigma') (1 - sigma') / sigma', is NOT spilled:
+  // the reverse sweep rebuilds it from GB[li+1] = u sigma' and P[li] = q sigma', which the dW kernel needs in memory anyway --
+  // one re-read moves from this sweep to the reverse sweep and five tensor stores per tile disappear.
   for (int li = 0; li < L.L - 1; ++li) {
-    Pre preA, preP;
-    adj_gemm(li, [&] { prefetch(p.sp.A[li + 1], preA); prefetch(p.sp.P[li], preP); });
+    Pre preA;
+    adj_gemm(li, [&] { prefetch(p.sp.A[li + 1], preA); });
     TS();
     lds_barrier();
     TS();
     refresh();
     for_blocks([&](int fb, int pb, int qp, int row) {
-      float a[8], pv[8], qb[8], inj[8];
+      float a[8], qb[8];
       load_s1(preA, fb, pb, qp, a);   // a[] = sigma'
-      load_tile8(preP, fb, pb, qp, pv);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const float u = acc[fb][pb][8 * qp + e];
-        const float s1 = a[e];
-        qb[e] = u * s1;
-        inj[e] = kBeta * u * pv[e] * (1.f - s1);   // u * q * sigma''(z),  q*sigma' = p
-      }
-      store_tile8(p.sp.INJ[li], fb, pb, qp, inj);
+      for (int e = 0; e < 8; ++e) qb[e] = acc[fb][pb][8 * qp + e] * a[e];
       put_x(false, fb, pb, qp, qb, 0);
       store_tile8_dw(p.sp.GB[li + 1], fb, pb, qp, qb);
     });
@@ -885,10 +881,10 @@ __global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 && EP == HD && !oper_x2_a
   // ------------------------------------------------------------------ ordinary reverse sweep with injection
   PRIO(3);
   for (int li = L.L - 2; li >= 0; --li) {
-    Pre preA, preI;
+    Pre preA, preG, preP;
     refresh();
     gemm<false, HD / 16, FB, PB, ROWB, T::CKF, true>(acc, wq, rsW, wptr(setBwdB, L.bwdMat[li + 1], HD), X, 0, lane,
-                                               [&] { prefetch(p.sp.A[li + 1], preA); prefetch(p.sp.INJ[li], preI); });
+                                               [&] { prefetch(p.sp.A[li + 1], preA); prefetch(p.sp.GB[li + 1], preG); prefetch(p.sp.P[li], preP); });
     TS();
     lds_barrier();
     TS();
@@ -897,12 +893,16 @@ __global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 && EP == HD && !oper_x2_a
 #pragma unroll
     for (int e = 0; e < 8; ++e) bsum[e] = 0.f;
     for_blocks2([&](int fb, int pb, int qp, int row) {
-      float a[8], inj[8], zb[8];
+      float a[8], gq[8], pv[8], zb[8];
       load_s1(preA, fb, pb, qp, a);   // a[] = sigma'
-      load_tile8(preI, fb, pb, qp, inj);
+      load_tile8(preG, fb, pb, qp, gq);
+      load_tile8(preP, fb, pb, qp, pv);
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        zb[e] = acc[fb][pb][8 * qp + e] * a[e] + inj[e];
+        const float s1 = a[e];
+        // injected term; sigma' -> 0 takes u sigma' and q sigma' with it (and a bf16 activation of 0 gives sigma' = 0 exactly)
+        const float inj = s1 > 0.f ? kBeta * gq[e] * pv[e] * (1.f - s1) * __builtin_amdgcn_rcpf(s1) : 0.f;
+        zb[e] = acc[fb][pb][8 * qp + e] * s1 + inj;
         bsum[e] += zb[e];
       }
       store_tile8_dw(p.sp.ZB[li], fb, pb, qp, zb);

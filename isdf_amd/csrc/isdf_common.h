@@ -59,7 +59,6 @@ struct SpillLayout {
   int64_t A[MAXL + 1];   // A[0] = embedding (EP/HD consecutive HD-wide tensors), A[li+1] = activation after layer li
   int64_t P[MAXL];       // d sdf / d z_li
   int64_t GB[MAXL];      // GB[0] = Ebar (EP/HD tensors), GB[li] = adjoint entering layer li (li >= 1)
-  int64_t INJ[MAXL];     // injected second-order term of layer li
   int64_t ZB[MAXL];      // d loss / d z_li
   int64_t totalElems;
 };
@@ -174,7 +173,6 @@ inline void make_workspace(const NetLayout& l, int64_t maxPts, int64_t maxRays, 
   if (train) {
     for (int i = 0; i < l.L; ++i) { s.P[i] = o; o += s.tensorElems; }
     for (int i = 0; i < l.L; ++i) { s.GB[i] = o; o += s.tensorElems * (i == 0 ? embT : 1); }
-    for (int i = 0; i < l.L; ++i) { s.INJ[i] = o; o += s.tensorElems; }
     for (int i = 0; i < l.L; ++i) { s.ZB[i] = o; o += s.tensorElems; }
   }
   s.tileStride = o;

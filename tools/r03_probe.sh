@@ -1,4 +1,5 @@
 #!/bin/bash
-# round 3: one-off A/B
-O=gpurun_out/r03x; mkdir -p $O
+# round 3: one-off A/B (parity suite first)
+O=gpurun_out/r03y; mkdir -p $O
+python -m pytest tests -m gpu -x -q -s 2>&1 | grep -i "worst rel-L2\|passed\|failed" | tail -12
 bash tools/ab_bench.sh > $O/ab.txt 2>&1; cat $O/ab.txt
