@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 3: one-off A/B (parity suite first)
+# round 3: one-off A/B
 O=gpurun_out/r03y; mkdir -p $O
-python -m pytest tests -m gpu -x -q -s 2>&1 | grep -i "worst rel-L2\|passed\|failed" | tail -12
+ISDF_HIP_LIB=$PWD/variants/lib_nomem.so python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "base_size_train or step_full" 2>&1 | tail -2
 bash tools/ab_bench.sh > $O/ab.txt 2>&1; cat $O/ab.txt
