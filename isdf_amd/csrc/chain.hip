@@ -388,6 +388,19 @@ __global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 && EP == HD && !oper_x2_a
     *(uint2*)(X + (lb ^ 16)) = b;    // features f0+8 .. f0+11
   };
 
+  // A wave's own pieces of one tensor, parked in region 2 of the tile across a few units when that region is idle (16 B per lane,
+  // the lane that parks a piece is the lane that takes it back: no barrier needed for it).  Saves the HBM re-read of a tensor whose
+  // consumer is only a few units away.
+  auto park_addr = [&](int c) {
+    const int off = (c * 64 + lane) * 16;                  // byte offset inside the wave's share of region 2
+    constexpr int RB = T::R2 * 2;                          // bytes of region 2 in one tile row
+    return (w * (BM / T::NW) + off / RB) * ROWB + HD * 2 + off % RB;
+  };
+  static_assert(FB * PB * 2 * 1024 <= (BM / T::NW) * T::R2 * 2, "a wave's pieces of one tensor fit its rows of region 2");
+  auto park_tile8 = [&](int fb, int pb, int qp, const float (&v)[8]) {
+    const uint2 a = pack4<false>(v[0], v[1], v[2], v[3]), b = pack4<false>(v[4], v[5], v[6], v[7]);
+    *(uint4*)(X + park_addr(cidx(fb, pb, qp))) = make_uint4(a.x, a.y, b.x, b.y);
+  };
   float rawp[PB];
 #pragma unroll
   for (int pb = 0; pb < PB; ++pb) rawp[pb] = 0.f;
@@ -827,6 +840,7 @@ __global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 && EP == HD && !oper_x2_a
       for (int e = 0; e < 8; ++e) qb[e] = acc[fb][pb][8 * qp + e] * a[e];
       put_x(false, fb, pb, qp, qb, 0);
       store_tile8_dw(p.sp.GB[li + 1], fb, pb, qp, qb);
+      if (li == L.L - 2) park_tile8(fb, pb, qp, qb);   // the reverse sweep's FIRST unit needs it back three units from here
     });
     TS();
     lds_barrier();
@@ -884,7 +898,11 @@ __global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 && EP == HD && !oper_x2_a
     Pre preA, preG, preP;
     refresh();
     gemm<false, HD / 16, FB, PB, ROWB, T::CKF, true>(acc, wq, rsW, wptr(setBwdB, L.bwdMat[li + 1], HD), X, 0, lane,
-                                               [&] { prefetch(p.sp.A[li + 1], preA); prefetch(p.sp.GB[li + 1], preG); prefetch(p.sp.P[li], preP); });
+                                               [&] {
+                                                 prefetch(p.sp.A[li + 1], preA);
+                                                 if (li != L.L - 2) prefetch(p.sp.GB[li + 1], preG);   // the top one is parked in the tile
+                                                 prefetch(p.sp.P[li], preP);
+                                               });
     TS();
     lds_barrier();
     TS();
@@ -895,6 +913,7 @@ __global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 && EP == HD && !oper_x2_a
     for_blocks2([&](int fb, int pb, int qp, int row) {
       float a[8], gq[8], pv[8], zb[8];
       load_s1(preA, fb, pb, qp, a);   // a[] = sigma'
+      if (li == L.L - 2) preG.v[fb][qp][pb] = *(const uint4*)(X + park_addr(cidx(fb, pb, qp)));
       load_tile8(preG, fb, pb, qp, gq);
       load_tile8(preP, fb, pb, qp, pv);
 #pragma unroll
