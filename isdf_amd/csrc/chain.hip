@@ -848,8 +848,8 @@ __global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 && EP == HD && !oper_x2_a
   }
   {   // top layer (peeled: its three partial-sum streams must not raise the register pressure of the loop above)
     const int li = L.L - 1;
-    Pre preA;   // p_L = so w_out sigma'(z_L) is rebuilt from a_L like sigma' itself: no re-read of P[L-1]
-    adj_gemm(li, [&] { prefetch(p.sp.A[li + 1], preA); });
+    Pre preA, preP;
+    adj_gemm(li, [&] { prefetch(p.sp.A[li + 1], preA); prefetch(p.sp.P[li], preP); });
     TS();
     lds_barrier();
     TS();
@@ -863,16 +863,16 @@ __global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 && EP == HD && !oper_x2_a
         const float4 w0 = *(const float4*)(part + f0), w1 = *(const float4*)(part + f0 + 8);
         wv[0] = w0.x; wv[1] = w0.y; wv[2] = w0.z; wv[3] = w0.w; wv[4] = w1.x; wv[5] = w1.y; wv[6] = w1.z; wv[7] = w1.w;
       }
-      float a[8], zb[8];
+      float a[8], pv[8], zb[8];
       load_tile8(preA, fb, pb, qp, a);
+      load_tile8(preP, fb, pb, qp, pv);
       const float sb = gbs[row * 4 + 3];
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const float u = acc[fb][pb][8 * qp + e];
         const float s1 = s1_from_a(a[e]);
-        const float pv = so * wv[e] * s1;   // p_L
         qsum[e] += u * s1;
-        zb[e] = sb * wv[e] * s1 + kBeta * u * pv * (1.f - s1);
+        zb[e] = sb * wv[e] * s1 + kBeta * u * pv[e] * (1.f - s1);
         bsum[e] += zb[e];
         wsum[e] += sb * a[e];
       }

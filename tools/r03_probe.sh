@@ -1,4 +1,6 @@
 #!/bin/bash
-# round 3: one-off A/B
-O=gpurun_out/r03y; mkdir -p $O
-bash tools/ab_bench.sh > $O/ab.txt 2>&1; cat $O/ab.txt
+# round 3: gradient parity numbers at BASELINE size for two builds
+for f in variants/lib_cfea06f.so variants/lib_head.so; do
+  echo "== $f"
+  ISDF_HIP_LIB=$PWD/$f python -m pytest tests/test_gpu_parity.py -m gpu -x -q -s -k "base_size_train_step and fp16x2" 2>&1 | grep -i "rel-L2\|passed\|failed"
+done
