@@ -63,10 +63,14 @@ def eval_points(depth, T, cam, rng, n_per_frame=16000):
     return np.concatenate(pts), np.concatenate(surf)
 
 
+FWD_OPERAND = "fp16x2"   # --fwd-operand: the HIP path's operand mode for the pinned-schedule runs
+
+
 def run_hip(seed, depth, normal, T, cam, steps_per_kf):
     from isdf_amd.trainer import HipTrainer, FrameData
     np.random.seed(seed); torch.manual_seed(seed)
-    tr = HipTrainer("cuda", config(cam), inv_bounds_transform=synthetic.bounds_transform(), rng="philox", seed=seed)
+    tr = HipTrainer("cuda", config(cam), inv_bounds_transform=synthetic.bounds_transform(), rng="philox", seed=seed,
+                    fwd_operand=FWD_OPERAND)
     dev = tr.device
     t_train = 0.0
     for k in range(depth.shape[0]):
@@ -185,7 +189,10 @@ def main():
                     help="reference driver frame scheduling + keyframe test (train.py:86-136) instead of the pinned schedule")
     ap.add_argument("--steps", type=int, default=1200)
     ap.add_argument("--virtual-step-ms", type=float, default=20.0)
+    ap.add_argument("--fwd-operand", default="fp16x2", choices=["fp16x2", "fp16", "bf16", "fp16x2_full"])
     a = ap.parse_args()
+    global FWD_OPERAND
+    FWD_OPERAND = a.fwd_operand
     cam = dict(synthetic.SCANNET_CAM)
     res = []
     if a.reference_schedule:

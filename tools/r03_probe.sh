@@ -1,6 +1,7 @@
 #!/bin/bash
-# round 3: accuracy control on the final kernels
+# round 3: accuracy control per forward operand mode (final kernels, pinned schedule 24 keyframes x 100 steps, seeds 1..5)
 O=gpurun_out/r03acc; mkdir -p $O
-python tests/accuracy_experiment.py --backend hip --seeds 1 2 3 4 5 --keyframes 24 --steps-per-kf 100 --out $O/final_24kf_x100.json > $O/final1.log 2>&1; tail -1 $O/final1.log
-python tests/accuracy_experiment.py --backend hip --seeds 1 2 3 4 5 --reference-schedule --steps 1000 --out $O/final_refsched.json > $O/final2.log 2>&1; python -c "
-import json,numpy as np; j=json.load(open('$O/final_refsched.json')); v=[r['l1_visible_m'] for r in j['runs']]; s=[r['l1_surface_m'] for r in j['runs']]; print('refsched', np.mean(v), np.std(v, ddof=1), np.mean(s))"
+for m in fp16 fp16x2_full bf16; do
+  python tests/accuracy_experiment.py --backend hip --seeds 1 2 3 4 5 --keyframes 24 --steps-per-kf 100 --fwd-operand $m --out $O/mode_$m.json > $O/mode_$m.log 2>&1
+  echo $m $(tail -1 $O/mode_$m.log)
+done
