@@ -273,7 +273,8 @@ int isdf_train_step_adamw(const isdf_net_cfg* net, const isdf_loss_cfg* loss, co
 int isdf_train_step_finish(const isdf_net_cfg* net, const isdf_optim_args* opt, const float* reduce_buf,
                            int32_t n_frames, int32_t extra_floats, float* host_mailbox, void* stream);
 /* extra_floats / host_mailbox (optional, pinned host memory of 8 + extra_floats floats): the same launch stores the
- * REDUCED loss_sums[8] followed by the message's caller-owned tail there (isdf_step_args.extra_floats).          */
+ * REDUCED loss_sums[8] followed by the message's caller-owned tail there (isdf_step_args.extra_floats).
+ * extra_floats > 0 without a host_mailbox is ISDF_EINVAL (the tail would be dropped silently).                    */
 
 /* nearest-surface-point bounds (bounds_method "pc", loss.py:56-89): for every sample point the distance to
  * the nearest SURFACE sample (sign from z vs depth) and the unit vector from it.  surf_pts == NULL: the

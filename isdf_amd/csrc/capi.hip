@@ -154,6 +154,9 @@ static int train_step_impl(const isdf_net_cfg* net, const isdf_loss_cfg* loss, c
   if (loss->grad_weight != 0.f && !a->norm_sample) return ISDF_EINVAL;
   const int64_t maxPts = (int64_t)a->max_rays * a->S;
   if (maxPts > 0x7fffffff) return ISDF_EINVAL;   // the loss stage indexes points with 32-bit arithmetic
+  // every argument check sits in front of the first launch: a rejected call leaves workspace and spills untouched
+  if (a->extra_floats < 0 || a->extra_floats > 1016 || (a->extra_floats > 0 && (a->extra_slot < 0 || a->extra_slot >= a->extra_floats)))
+    return ISDF_EINVAL;
   WorkspaceLayout w; make_workspace(l, maxPts, a->max_rays, true, &w);
   if (workspace_bytes < w.totalBytes) return ISDF_EWORKSPACE;
   hipStream_t st = (hipStream_t)stream;
@@ -189,8 +192,6 @@ static int train_step_impl(const isdf_net_cfg* net, const isdf_loss_cfg* loss, c
   float* blockLoss = lossSums + 8;
   float* blockCnt = blockLoss + (int64_t)a->n_frames * 64;
   float* extra = blockCnt + (int64_t)a->n_frames * 64;   // caller-owned tail (extra_floats), right behind isdf_reduce_floats
-  if (a->extra_floats < 0 || a->extra_floats > 1016 || (a->extra_floats > 0 && (a->extra_slot < 0 || a->extra_slot >= a->extra_floats)))
-    return ISDF_EINVAL;
   if (opt) {   // single-GPU tail: slab reduction + AdamW + operand repack + loss/bin finalisation in one launch
     rc = launch_step_tail(0, l, dwPart, vecPart, w.vecStride, o->reduce_buf, opt->params, opt->exp_avg, opt->exp_avg_sq,
                           (uint16_t*)opt->shadow, opt->grad_scale, opt->lr, opt->beta1, opt->beta2, opt->eps,
@@ -237,6 +238,7 @@ int isdf_train_step_finish(const isdf_net_cfg* net, const isdf_optim_args* opt, 
   if ((opt->loss_approx == nullptr) != (opt->frame_avg == nullptr)) return ISDF_EINVAL;   // both or neither
   if (opt->loss_approx && n_frames < 1) return ISDF_EINVAL;
   if (extra_floats < 0 || extra_floats > 1016 || n_frames < 0) return ISDF_EINVAL;
+  if (extra_floats > 0 && !host_mailbox) return ISDF_EINVAL;   // the reduced tail has nowhere to go: say so instead of dropping it
   const float* lossSums = reduce_buf + l.n_params;
   const float* bl = lossSums + 8;
   const int F = opt->loss_approx ? n_frames : 0;

@@ -228,6 +228,9 @@ class Engine:
             ring = getattr(self, "_smp_ring", None)      # TWO alternating buffer sets: the previous step's outputs
             if ring is None or ring[0] != key:           # (trainer.active_pixels) stay intact for one more step
                 ring = self._smp_ring = [key, [None, None], 0, [None, None]]
+                # the cached step plans hold raw pointers into the buffer sets just dropped: a later ring of the same shape may
+                # get `pc` back at its old address while the small tensors land elsewhere (clear_keyframes: F 5 -> 1 -> 5)
+                self._step_plans.clear()
             ring[2] ^= 1
             slot = ring[2]
             # ... and the call's ctypes structs are kept with the buffer set: a device-synchronised step() has ~40 us of
@@ -339,7 +342,10 @@ class Engine:
                 and lc.bounds_method == "ray"):
             fo = None if optim is None else optim.get("frame_avg_out")
             fi = None if optim is None else optim.get("frame_avg_index")
-            plan_key = (smp["_slot"], smp["pc"].data_ptr(), R0, S, F, sc.H, sc.W, lc.loss_type, lc.trunc_weight, lc.trunc_distance,
+            ns = smp.get("norm_sample")
+            plan_key = (smp["_slot"], smp["pc"].data_ptr(), smp["n_valid"].data_ptr(), smp["indices_b"].data_ptr(),
+                        smp["z_vals"].data_ptr(), 0 if ns is None else ns.data_ptr(),
+                        R0, S, F, sc.H, sc.W, lc.loss_type, lc.trunc_weight, lc.trunc_distance,
                         lc.eik_weight, lc.eik_apply_dist, lc.grad_weight, lc.orien_loss, optim is None,
                         0 if fo is None else fo.data_ptr(), 0 if fi is None else fi.data_ptr(), self.reduce_extra,
                         None if self.reduce_buf is None else self.reduce_buf.data_ptr(), None if self._ws is None else self._ws.data_ptr())
@@ -361,7 +367,8 @@ class Engine:
                     _ffi.check(self.lib.isdf_train_step(C.byref(self.cnet), C.byref(closs), self._params_ptr, self._shadow_ptr,
                                                         C.byref(a), C.byref(o), self._ws_ptr, ws.numel(), _stream(self.device)),
                                "isdf_train_step")
-                return dbg
+                return dict(dbg)      # a fresh dict per call; its `loss_approx` tensor is the plan's reused buffer (overwritten by
+                                      # the next step on this buffer set, two steps later)
         # [isdf_reduce_floats | reduce_extra caller-owned floats]: the kernels write the first part; the tail belongs to the
         # host protocol (data parallel: per-rank step-time slots riding in the same all-reduce message, hot_path.py)
         nred = int(self.lib.isdf_reduce_floats(C.byref(self.cnet), F))

@@ -495,7 +495,8 @@ class HotPath:
                        for k in FRAME_FIELDS if hasattr(fr, k)},
             "clock": dict(tot_step_time=self.tot_step_time, steps_since_frame=self.steps_since_frame,
                           last_is_keyframe=self.last_is_keyframe, optim_frames=self.optim_frames,
-                          noise_std=self.noise_std, step_count=hip.step_count),
+                          noise_std=self.noise_std, step_count=hip.step_count,
+                          prev_step_ms=hip.prev_step_ms),     # data parallel: the step time still to be added to the clock
             "rng": dict(draw_count=hip.draw_count, noise_count=hip.noise_count, seed=hip.seed,
                         window=getattr(hip, "window_rng_state", None),
                         numpy=np.random.get_state(), torch=torch.get_rng_state(),
@@ -517,12 +518,16 @@ class HotPath:
         # add_frame_data appends at the right length
         for twin, src in (("im_batch_np", "im_batch"), ("depth_batch_np", "depth_batch"), ("T_WC_batch_np", "T_WC_batch")):
             if twin not in f and getattr(fr, src, None) is not None and hasattr(fr, twin):
-                setattr(fr, twin, getattr(fr, src).detach().cpu().numpy())
+                t = getattr(fr, src).detach()
+                if twin == "im_batch_np":     # the host twin is the raw 0..255 image, the device batch is float in [0, 1]
+                    t = (t * 255).round().to(torch.uint8)          # (trainer.py:536-547)
+                setattr(fr, twin, t.cpu().numpy())
         self.frames = fr
         c = sd["clock"]
         self.tot_step_time, self.steps_since_frame = c["tot_step_time"], c["steps_since_frame"]
         self.last_is_keyframe, self.optim_frames = c["last_is_keyframe"], c["optim_frames"]
         self.noise_std, hip.step_count = c["noise_std"], c["step_count"]
+        hip.prev_step_ms = float(c.get("prev_step_ms", 0.0))
         r = sd["rng"]
         hip.draw_count, hip.noise_count, hip.seed = r["draw_count"], r["noise_count"], r["seed"]
         hip.idx_cache = None

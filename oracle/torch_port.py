@@ -142,9 +142,12 @@ class PortTrainer:
     (tests/accuracy_experiment.py --backend port --reference-schedule).  Method names, state fields and decision
     logic follow trainer.py:574-674,951-1016; the arithmetic is the op chain above."""
 
-    def __init__(self, cfg, cam, transform, seed, virtual_step_ms, fps=30):
+    def __init__(self, cfg, cam, transform, seed, virtual_step_ms, fps=30, device="cpu"):
+        """virtual_step_ms None: the clock advances by the MEASURED (device-synchronised) step time, like upstream
+        (metrics.py:13-38, trainer.py:1011-1013).  device "cuda": the same op chain as PyTorch-ROCm eager."""
         m, s, lo = cfg["model"], cfg["sample"], cfg["loss"]
         self.cam, self.fps, self.virtual_step_ms = cam, fps, virtual_step_ms
+        self.device = torch.device(device)
         self.sc = dict(n_rays=s["n_rays"], n_strat=s["n_strat_samples"], n_surf=s["n_surf_samples"],
                        min_depth=s["depth_range"][0], dist_behind_surf=s["dist_behind_surf"])
         self.n_rays_is_kf = s["n_rays_is_kf"]
@@ -155,14 +158,15 @@ class PortTrainer:
         self.kf_dist_th, self.kf_pixel_ratio = m["kf_dist_th"], m["kf_pixel_ratio"]
         self.frac_time_perception = m["frac_time_perception"]
         self.net = PortNet(m["hidden_feature_size"], m["hidden_layers_block"], m["embedding"]["n_embed_funcs"] + 1,
-                           m["embedding"]["scale_input"], m["scale_output"], transform)
+                           m["embedding"]["scale_input"], m["scale_output"], transform).to(self.device)
         self.opt = torch.optim.AdamW(self.net.parameters(), lr=cfg["optimiser"]["lr"],
                                      weight_decay=cfg["optimiser"]["weight_decay"])
         self.gen = torch.Generator().manual_seed(seed)
         self.tot_step_time, self.steps_since_frame, self.optim_frames, self.last_is_keyframe = 0.0, 0, 0, False
         self.frame_id, self.depth, self.T, self.normals = [], None, None, None
-        self.fal = torch.zeros(0)
+        self.fal = torch.zeros(0, device=self.device)
         self.frozen = None
+        self.n_steps_done = 0
 
     def get_latest_frame_id(self):
         return int(self.tot_step_time * self.fps)
@@ -173,6 +177,7 @@ class PortTrainer:
         if self.last_is_keyframe:
             self.frozen = copy.deepcopy(self.net)
         fid, d, T, n = frame
+        d, T, n = d.to(self.device), T.to(self.device), n.to(self.device)
         replace = self.last_is_keyframe is False and len(self.frame_id) > 0
         if replace:
             self.frame_id[-1] = fid; self.depth[-1] = d; self.T[-1] = T; self.normals[-1] = n; self.fal[-1] = 0.0
@@ -180,7 +185,7 @@ class PortTrainer:
             cat = lambda a, b: b[None] if a is None else torch.cat((a, b[None]))
             self.frame_id.append(fid)
             self.depth, self.T, self.normals = cat(self.depth, d), cat(self.T, T), cat(self.normals, n)
-            self.fal = torch.cat((self.fal, torch.zeros(1)))
+            self.fal = torch.cat((self.fal, torch.zeros(1, device=self.device)))
         self.steps_since_frame, self.last_is_keyframe = 0, False
         self.optim_frames, self.noise_std = self.iters_per_frame, self.noise_frame
 
@@ -189,9 +194,10 @@ class PortTrainer:
         sc = dict(self.sc, n_rays=self.n_rays_is_kf, dist_behind_surf=0.8)
         s = sample_step(self.depth[-1:], self.T[-1:], self.normals[-1:], self.cam, sc, self.gen)
         with torch.no_grad():
-            noise = None if self.noise_std is None else torch.randn(s["pc"].shape[:-1], generator=self.gen) * self.noise_std
+            noise = None if self.noise_std is None else \
+                (torch.randn(s["pc"].shape[:-1], generator=self.gen) * self.noise_std).to(self.device)
             sdf = self.frozen(s["pc"], noise)
-        ratio, _ = keyframe_ratio(s["z"].numpy(), sdf.numpy(), s["depth"].numpy(), self.kf_dist_th)
+        ratio, _ = keyframe_ratio(s["z"].cpu().numpy(), sdf.cpu().numpy(), s["depth"].cpu().numpy(), self.kf_dist_th)
         return ratio < self.kf_pixel_ratio
 
     def check_keyframe_latest(self):
@@ -209,9 +215,15 @@ class PortTrainer:
         return add_new_frame
 
     def step(self):
+        import time
+        native = self.virtual_step_ms is None
+        if native:                     # metrics.start_timing: device-synchronised wall clock
+            if self.device.type == "cuda":
+                torch.cuda.synchronize(self.device)
+            t0 = time.perf_counter()
         K = len(self.frame_id)
         if K > self.window_size:       # select_keyframes, trainer.py:652-674
-            p = (self.fal[:-2] / self.fal[:-2].sum()).numpy()
+            p = (self.fal[:-2] / self.fal[:-2].sum()).cpu().numpy()
             idxs = [*np.random.choice(np.arange(0, K - 2), size=self.window_size - 2, replace=False, p=p), K - 2, K - 1]
         else:
             idxs = list(range(K))
@@ -219,6 +231,13 @@ class PortTrainer:
         losses, fa = train_step(self.net, self.opt, self.depth[idxs], self.T[idxs], self.normals[:len(idxs)], self.cam,
                                 self.sc, self.lc, self.noise_std, self.gen)
         self.fal[idxs] = fa
-        self.tot_step_time += (1 / self.frac_time_perception) * self.virtual_step_ms / 1000.0
+        if native:
+            if self.device.type == "cuda":
+                torch.cuda.synchronize(self.device)
+            step_ms = (time.perf_counter() - t0) * 1000.0
+        else:
+            step_ms = self.virtual_step_ms
+        self.tot_step_time += (1 / self.frac_time_perception) * step_ms / 1000.0
         self.steps_since_frame += 1
-        return losses, self.virtual_step_ms
+        self.n_steps_done += 1
+        return losses, step_ms

@@ -324,6 +324,145 @@ def run_step_case(mods, name, net, lossc, samplec, K, cam, seed, noise_std, n_st
     print("wrote", path)
 
 
+
+def _trained_setup(mods, seed):
+    import oracle.isdf_oracle as orc
+    from isdf_amd import synthetic
+    cam = dict(H=480, W=640, fx=577.87, fy=577.87, cx=319.5, cy=239.5)
+    net = dict(H=256, B=2, n_freqs=6, scale_input=0.05937489, scale_output=0.14)
+    samplec = dict(SAMPLE_DEFAULT, n_rays=200)
+    frames_np = synthetic.keyframes(5, cam, seed=seed, stride=48, noise_std=0.01)
+    params_np = orc.init_params(net["H"], net["B"], net["n_freqs"], np.random.RandomState(seed + 100))
+    Tb = synthetic.bounds_transform()
+    tr = build_trainer(mods, cam, net, LOSS_DEFAULT, samplec, frames_np, params_np, Tb, 0.08)
+    return tr, cam, net, samplec, Tb
+
+
+def trained_warmup(mods, seed, pre_steps, path):
+    """child process of run_trained_case: `pre_steps` unmodified Trainer.step calls with flush-to-zero on"""
+    tr, cam, net, samplec, Tb = _trained_setup(mods, seed)
+    np.random.seed(seed); torch.manual_seed(seed)
+    for s in range(pre_steps):
+        losses, _ = tr.step()
+        if s % 20 == 0 or s == pre_steps - 1:
+            print("warm-up step", s, "total", float(losses["total_loss"]), flush=True)
+    torch.save(dict(model=tr.sdf_map.state_dict(), optim=tr.optimiser.state_dict(), frame_avg_losses=tr.frames.frame_avg_losses,
+                    np_rng=np.random.get_state(), torch_rng=torch.get_rng_state()), path)
+
+
+def bf16_round(x):
+    """round-to-nearest-even to bfloat16, returned as float32"""
+    u = np.ascontiguousarray(x, np.float32).view(np.uint32)
+    r = ((u + 0x7fff + ((u >> 16) & 1)) & 0xffff0000).astype(np.uint32)
+    return r.view(np.float32)
+
+
+def run_trained_case(mods, name, seed=61, pre_steps=300, traj_steps=20, traj_rays=40):
+    """Round 4: the default 6x256 network at TRAINED weights -- every gradient test before this one ran
+    at random-initialised weights, where almost no unit of a Softplus(beta=100) layer is saturated.
+
+    1. the UNMODIFIED reference `Trainer.step` x `pre_steps` on 5 keyframes of the analytic room (isdf_amd/synthetic.py, 480x640,
+       replicaCAD.json loss / sample / optimiser settings).  Flush-to-zero is on for this warm-up only (9x faster on x86, SURVEY 6.1;
+       it only decides WHICH trained state the fixture holds).
+    2. eval batch at that state: `sample_points` + `sdf_eval_and_loss` + `backward()`; stored: the sampler's outputs (so the test needs
+       no keyframes), the noise draw, sdf, d sdf/dx, loss terms, ALL gradients in full (signed-projection tests need them).
+    3. trajectory: AdamW moments rounded to bfloat16 and loaded back (the fixture then holds the exact start state in half the
+       bytes), `traj_steps` further unmodified `Trainer.step`s at `traj_rays` rays per keyframe; stored per step: the sampler outputs,
+       the noise, the losses; at the end: the accumulated parameter update (float16) and digests of the moments."""
+    import subprocess
+    import tempfile
+    trainer, sample, embedding, fc_map, loss, transform, FrameData = mods
+    tr, cam, net, samplec, Tb = _trained_setup(mods, seed)
+    # warm-up in a CHILD process with flush-to-zero set before its first torch op (worker threads inherit the mode of the thread
+    # that creates them, so it cannot be switched off again inside one process); this process never enables it
+    tmp = os.path.join(tempfile.gettempdir(), "isdf_trained_warmup_%d_%d.pt" % (seed, pre_steps))
+    if not os.path.exists(tmp):
+        subprocess.check_call([sys.executable, os.path.abspath(__file__), "_trained_warmup", str(seed), str(pre_steps), tmp])
+    ck = torch.load(tmp, weights_only=False)
+    tr.sdf_map.load_state_dict(ck["model"])
+    tr.optimiser.load_state_dict(ck["optim"])
+    tr.frames.frame_avg_losses = ck["frame_avg_losses"]
+    np.random.set_state(ck["np_rng"]); torch.set_rng_state(ck["torch_rng"])
+    names = [k for k, _ in tr.sdf_map.named_parameters()]
+    out = dict(cam=np.array([cam["H"], cam["W"], cam["fx"], cam["fy"], cam["cx"], cam["cy"]], np.float64),
+               net=np.array([net["H"], net["B"], net["n_freqs"], net["scale_input"], net["scale_output"]], np.float64),
+               seed=np.array([seed]), noise_std=np.array([0.08], np.float64), has_transform=np.array([1]), bounds_T=Tb,
+               pre_steps=np.array([pre_steps]), traj_steps=np.array([traj_steps]), n_frames=np.array([5]),
+               T_WC_batch=t2n(tr.frames.T_WC_batch))      # T_WC_sample = T_WC_batch[indices_b] (sample.py:63)
+    for k, v in LOSS_DEFAULT.items():
+        out["loss_" + k] = np.array([v]) if not isinstance(v, str) else np.array(v)
+    for k, v in samplec.items():
+        out["sample_" + k] = np.array([v], np.float64)
+    for k, p in tr.sdf_map.named_parameters():
+        out["param/" + k] = t2n(p)
+
+    def sampler_outputs(prefix, sp, noise):
+        _, dirs_W = transform.origin_dirs_W(sp["T_WC_sample"], sp["dirs_C_sample"])
+        out[prefix + "pc"] = t2n(sp["pc"]); out[prefix + "z_vals"] = t2n(sp["z_vals"])
+        out[prefix + "depth_sample"] = t2n(sp["depth_sample"]); out[prefix + "dirs_C_sample"] = t2n(sp["dirs_C_sample"])
+        out[prefix + "dirs_W_sample"] = t2n(dirs_W); out[prefix + "norm_sample"] = t2n(sp["norm_sample"])
+        for k in ("indices_b", "indices_h", "indices_w"):
+            out[prefix + k] = t2n(sp[k]).astype(np.int16)
+        out[prefix + "noise"] = (noise * np.float32(0.08)).astype(np.float32)     # as added to raw: randn * noise_std (fc_map.py:106-108)
+
+    # ---- 2. eval batch
+    with DrawRecorder() as rec:
+        sp = tr.sample_points(tr.frames.depth_batch, tr.frames.T_WC_batch, norm_batch=tr.frames.normal_batch)
+        pc_in = sp["pc"].clone()
+        total, losses, loss_approx, frame_avg_loss = tr.sdf_eval_and_loss(sp, do_avg_loss=True)
+        ih, iw, U, N_off, noise = rec.pop_step(with_noise=True)
+    sampler_outputs("eval/", sp, noise)
+    pc = pc_in.clone().requires_grad_()
+    raw_sdf = tr.sdf_map(pc, noise_std=None)
+    out["eval/sdf_nonoise"] = t2n(raw_sdf)
+    out["eval/sdf_grad"] = t2n(mods[3].gradient(pc, raw_sdf))
+    total.backward()
+    for k, p in tr.sdf_map.named_parameters():
+        out["eval/grad/" + k] = t2n(p.grad)
+        p.grad = None
+    out["eval/total_loss"] = np.array([float(total)]); out["eval/sdf_loss"] = np.array([losses["sdf_loss"]])
+    out["eval/grad_loss"] = np.array([losses["grad_loss"]]); out["eval/eikonal_loss"] = np.array([losses["eikonal_loss"]])
+    out["eval/frame_avg_loss"] = t2n(frame_avg_loss)
+    print(name, "eval batch R =", sp["pc"].shape[0], "total", float(total), losses, flush=True)
+
+    # ---- 3. trajectory from a bf16-representable AdamW state
+    st = tr.optimiser.state
+    for k, p in tr.sdf_map.named_parameters():
+        for mom in ("exp_avg", "exp_avg_sq"):
+            q = bf16_round(t2n(st[p][mom]))
+            st[p][mom].copy_(torch.from_numpy(q))
+            out["adam/%s/%s" % (mom, k)] = (q.view(np.uint32) >> 16).astype(np.uint16)
+    out["adam/step"] = np.array([float(st[next(iter(tr.sdf_map.parameters()))]["step"])])
+    theta0 = {k: t2n(p) for k, p in tr.sdf_map.named_parameters()}
+    tr.n_rays = traj_rays
+    captured = []
+    orig_sample_points = tr.sample_points
+
+    def observing_sample_points(*a, **kw):       # the reference method runs unmodified; its return value is recorded
+        o = orig_sample_points(*a, **kw)
+        captured.append(o)
+        return o
+    tr.sample_points = observing_sample_points
+    out["traj/frame_avg_losses0"] = t2n(tr.frames.frame_avg_losses)
+    with DrawRecorder() as rec:
+        for s in range(traj_steps):
+            losses, _ = tr.step()
+            ih, iw, U, N_off, noise = rec.pop_step(with_noise=True)
+            sampler_outputs("traj/s%d/" % s, captured.pop(0), noise)
+            out["traj/s%d/losses" % s] = np.array([losses["sdf_loss"], losses["grad_loss"], losses["eikonal_loss"],
+                                                   float(losses["total_loss"])], np.float64)
+            out["traj/s%d/frame_avg_losses" % s] = t2n(tr.frames.frame_avg_losses)
+            print(name, "trajectory step", s, "total", float(losses["total_loss"]), flush=True)
+    prng = np.random.RandomState(4321)
+    for k, p in tr.sdf_map.named_parameters():
+        out["traj/update/" + k] = (t2n(p) - theta0[k]).astype(np.float16)
+        _digest(out, "traj/exp_avg_", k, t2n(st[p]["exp_avg"]), prng)
+        _digest(out, "traj/exp_avg_sq_", k, t2n(st[p]["exp_avg_sq"]), prng)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path) / 1e6, "MB")
+
+
 def run_ingest_case(mods, name, seed):
     """reference per-frame ingest (normals) and keyframe depth render on small seeded inputs"""
     trainer, sample, embedding, fc_map, loss, transform, FrameData = mods
@@ -351,9 +490,14 @@ def run_ingest_case(mods, name, seed):
 
 
 def main():
+    only = sys.argv[1] if len(sys.argv) > 1 else None
+    if only == "_trained_warmup":
+        torch.set_flush_denormal(True)           # before the first torch op of this (child) process
+        torch.set_num_threads(8)
+        trained_warmup(import_reference(), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4])
+        return
     torch.set_num_threads(4)
     mods = import_reference()
-    only = sys.argv[1] if len(sys.argv) > 1 else None
     if only == "ingest":
         run_ingest_case(mods, "ingest_small", 31)
         return
@@ -425,6 +569,20 @@ def main():
     if only in round3:
         round3[only]()
         return
+    # ---- round 4: the paper's 4-hidden-layer net (hidden_layers_block = 1, fc_map.py:77-90) at width 256, and the default net
+    # at TRAINED weights with a 20-step reference trajectory
+    round4 = {
+        "eval_b1_256": lambda: run_eval_case(mods, "eval_b1_256", dict(H=256, B=1, n_freqs=6, scale_input=0.05937489, scale_output=0.14),
+                                             LOSS_DEFAULT, dict(SAMPLE_DEFAULT, n_rays=24), 5, cam_s, 58, 0.08, False),
+        "trained_default": lambda: run_trained_case(mods, "trained_default"),
+    }
+    if only == "round4":
+        for fn in round4.values():
+            fn()
+        return
+    if only in round4:
+        round4[only]()
+        return
     cam_s = dict(H=48, W=64, fx=60.0, fy=60.0, cx=31.5, cy=23.5)
     small = dict(H=64, B=1, n_freqs=6, scale_input=0.05937489, scale_output=0.14)
     full = dict(H=256, B=2, n_freqs=6, scale_input=0.05937489, scale_output=0.14)
@@ -452,6 +610,8 @@ def main():
     for fn in round2.values():
         fn()
     for fn in round3.values():
+        fn()
+    for fn in round4.values():
         fn()
 
 

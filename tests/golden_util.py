@@ -152,3 +152,30 @@ def params_of(g, prefix="param/"):
 def rel_err(a, b):
     a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
     return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
+# ---- `trained_default` (round 4): the default net at trained weights, sampler outputs stored instead of keyframes ----------
+def trained_batch(g, prefix):
+    """One batch of the `trained_default` fixture (prefix "eval/" or "traj/s<k>/"): the reference sampler's outputs in the
+    oracle's argument order + the scaled noise it added."""
+    ib = g[prefix + "indices_b"].astype(np.int64)
+    return dict(pc=g[prefix + "pc"], z_vals=g[prefix + "z_vals"], depth_sample=g[prefix + "depth_sample"],
+                dirs_C_sample=g[prefix + "dirs_C_sample"], dirs_W_sample=g[prefix + "dirs_W_sample"],
+                T_WC_sample=g["T_WC_batch"][ib], norm_sample=g[prefix + "norm_sample"], noise=g[prefix + "noise"],
+                indices_b=ib, indices_h=g[prefix + "indices_h"].astype(np.int64), indices_w=g[prefix + "indices_w"].astype(np.int64))
+
+
+def trained_adam_state(g, names):
+    """the trajectory's start state: AdamW moments stored as bfloat16 bit patterns (they ARE the exact start state: the
+    reference run loaded these rounded values, make_golden.run_trained_case)"""
+    up = lambda u: (u.astype(np.uint32) << 16).view(np.float32)
+    return {"step": int(g["adam/step"][0]),
+            "exp_avg": {k: up(g["adam/exp_avg/" + k]) for k in names},
+            "exp_avg_sq": {k: up(g["adam/exp_avg_sq/" + k]) for k in names}}
+
+
+def signed_projection(got, ref):
+    """<got - ref, ref> / |ref|^2: the part of the error that is ALONG the reference (a scale bias); a rel-L2 bound cannot
+    tell it from noise, and unlike noise it does not average out over optimisation steps"""
+    a, b = np.asarray(got, np.float64).ravel(), np.asarray(ref, np.float64).ravel()
+    return float((a - b) @ b / max(b @ b, 1e-300))

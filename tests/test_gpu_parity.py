@@ -1169,3 +1169,110 @@ def test_other_network_shapes_vs_reference(case):
     print("%s: worst gradient deviation (reference norm / probe digests, oracle rel-L2) %.3e" % (case, worst))
     _check_grads_vs_reference_digest(eng, N, g, tol=SHAPE_DW_TOL[case])
     _check_grads_vs_oracle(eng, N, grads, tol=SHAPE_DW_TOL[case])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Round 4: the default net at TRAINED weights (fixture `trained_default`, produced by the REAL reference: 300 unmodified
+# Trainer.step calls on the analytic room, then an eval batch with all gradients in full and a 20-step trajectory from a
+# bf16-representable AdamW state).  Every gradient test above runs at random-initialised weights, where almost no unit of
+# a Softplus(beta=100) layer is saturated, and bounds rel-L2 / cosine only -- a small error of CONSTANT SIGN passes those
+# and accumulates over thousands of AdamW steps (round 3, commit d490710: all 75 tests green, trained L1 4.07 -> 5.63 cm).
+# These tests bound the SIGNED projection <g_hip - g_ref, g_ref> / |g_ref|^2 per tensor and of the accumulated update.
+TOL_SIGNED = 6e-3          # per-tensor signed projection of a gradient (measured on MI355X: see DESIGN 5)
+TOL_SIGNED_ALL = 5e-3      # ... of all parameters together
+TOL_UPDATE_SIGNED = 3e-2   # signed projection of the 20-step parameter update
+
+
+def _smp_from_batch(b, n_frames):
+    R, S = b["z_vals"].shape
+    return dict(n_valid=torch.tensor([R], dtype=torch.int32, device="cuda"), pc=_dev(b["pc"]), z_vals=_dev(b["z_vals"]),
+                depth_sample=_dev(b["depth_sample"]), dirs_C_sample=_dev(b["dirs_C_sample"]),
+                dirs_W_sample=_dev(b["dirs_W_sample"]), norm_sample=_dev(b["norm_sample"]),
+                indices_b=_dev(b["indices_b"]), indices_h=_dev(b["indices_h"]), indices_w=_dev(b["indices_w"]),
+                max_rays=R, S=S, n_frames=n_frames)
+
+
+def trained_eval_metrics(fwd_operand="fp16x2"):
+    """HIP step on the fixture's eval batch at trained weights -> dict of error measures vs the REFERENCE"""
+    g = gu.load("trained_default")
+    eng = _engine(g, fwd_operand)
+    lc, sc = _cfgs(g)
+    b = gu.trained_batch(g, "eval/")
+    smp = _smp_from_batch(b, int(g["n_frames"][0]))
+    sdf, grad = eng.sdf_eval(_dev(b["pc"].reshape(-1, 3)), want_grad=True)
+    eng.train_step(smp, lc, sc, noise=_dev(b["noise"]))
+    torch.cuda.synchronize()
+    ls = eng.loss_sums().cpu().numpy().astype(np.float64)
+    N = ls[4]
+    m = dict(sdf=gu.rel_err(sdf.cpu().numpy(), g["eval/sdf_nonoise"].reshape(-1)),
+             sdf_grad=gu.rel_err(grad.cpu().numpy(), g["eval/sdf_grad"].reshape(-1, 3)), N=N,
+             losses={k: abs(ls[i] / N - g["eval/" + k][0]) / abs(g["eval/" + k][0])
+                     for i, k in enumerate(("sdf_loss", "grad_loss", "eikonal_loss", "total_loss"))}, tensors={})
+    allg, allr = [], []
+    for k in gu.params_of(g):
+        got = (eng.grad_view(k).cpu().numpy().astype(np.float64) / N).reshape(-1)
+        ref = g["eval/grad/" + k].astype(np.float64).reshape(-1)
+        m["tensors"][k] = dict(rel_l2=gu.rel_err(got, ref), cos=float(got @ ref / (np.linalg.norm(got) * np.linalg.norm(ref))),
+                               signed=gu.signed_projection(got, ref))
+        allg.append(got); allr.append(ref)
+    allg, allr = np.concatenate(allg), np.concatenate(allr)
+    m["all"] = dict(rel_l2=gu.rel_err(allg, allr), signed=gu.signed_projection(allg, allr))
+    return m
+
+
+def trained_trajectory_metrics(fwd_operand="fp16x2"):
+    """20 fused HIP steps from the fixture's trained state (weights + AdamW moments) on the reference's own sampler outputs
+    and noise -> per-step loss errors and the error of the accumulated parameter update vs the REFERENCE's"""
+    g = gu.load("trained_default")
+    eng = _engine(g, fwd_operand)
+    lc, sc = _cfgs(g)
+    names = list(gu.params_of(g))
+    st = gu.trained_adam_state(g, names)
+    for k in names:
+        off, shp = eng.slices[k]
+        n = int(np.prod(shp))
+        eng.exp_avg[off:off + n].copy_(_dev(st["exp_avg"][k].reshape(-1)))
+        eng.exp_avg_sq[off:off + n].copy_(_dev(st["exp_avg_sq"][k].reshape(-1)))
+    eng.opt_step = st["step"]
+    theta0 = eng.params.clone()
+    F = int(g["n_frames"][0])
+    loss_err = []
+    for s in range(int(g["traj_steps"][0])):
+        b = gu.trained_batch(g, "traj/s%d/" % s)
+        eng.train_step(_smp_from_batch(b, F), lc, sc, noise=_dev(b["noise"]), optim=dict(lr=0.0013, weight_decay=0.012))
+        ls = eng.loss_sums().cpu().numpy().astype(np.float64)
+        ref = g["traj/s%d/losses" % s]
+        loss_err.append([abs(ls[i] / ls[4] - ref[i]) / abs(ref[i]) for i in range(4)])
+    upd = (eng.params - theta0).cpu().numpy().astype(np.float64)
+    ref = np.concatenate([g["traj/update/" + k].astype(np.float64).ravel() for k in names])
+    return dict(loss_err_total_per_step=[e[3] for e in loss_err],
+                loss_err_max=np.max(loss_err, axis=0).tolist(), loss_err_mean=np.mean(loss_err, axis=0).tolist(),
+                update_rel_l2=gu.rel_err(upd, ref), update_signed=gu.signed_projection(upd, ref),
+                update_cos=float(upd @ ref / (np.linalg.norm(upd) * np.linalg.norm(ref))))
+
+
+def test_trained_weights_step_vs_reference():
+    m = trained_eval_metrics()
+    print("trained-weights eval batch:", {k: v for k, v in m.items() if k != "tensors"})
+    print("  worst tensor rel-L2:", max((v["rel_l2"], k) for k, v in m["tensors"].items()),
+          " worst |signed|:", max((abs(v["signed"]), k) for k, v in m["tensors"].items()))
+    assert m["sdf"] < TOL_SDF and m["sdf_grad"] < TOL_SDF_GRAD, (m["sdf"], m["sdf_grad"])
+    for k, e in m["losses"].items():
+        assert e < TOL_LOSS, (k, e)
+    for k, v in m["tensors"].items():
+        assert v["cos"] > 0.999 and v["rel_l2"] < TOL_DW, (k, v)
+        assert abs(v["signed"]) < TOL_SIGNED, (k, v)
+    assert abs(m["all"]["signed"]) < TOL_SIGNED_ALL, m["all"]
+
+
+def test_trained_trajectory_vs_reference():
+    m = trained_trajectory_metrics()
+    print("trained-state 20-step trajectory:", m)
+    # The loss is piecewise linear and the trained net nearly so: two correct implementations part ways as soon as the sign of
+    # one near-zero residual differs (fp32 oracle vs fp32 reference on this fixture: 1e-7 through step 12, 4e-3 at step 19,
+    # tests/test_oracle_golden.py) -- a 16-bit-operand implementation does so from the first step.  The early steps bound the
+    # arithmetic, the whole trajectory bounds the drift of the accumulated update (direction and scale).
+    assert max(m["loss_err_total_per_step"][:5]) < 5e-3, m
+    assert max(m["loss_err_total_per_step"]) < 0.15, m
+    assert m["update_cos"] > 0.98 and m["update_rel_l2"] < 0.25, m
+    assert abs(m["update_signed"]) < TOL_UPDATE_SIGNED, m

@@ -1,0 +1,59 @@
+#!/bin/bash
+# Round-4 GPU sessions (one gpurun call each):  tools/r04_session.sh <stage>
+#   ab1        GPU tests (new trained-state tests print their measures), same-box A/B of variants/lib_*.so, step-time
+#              distribution of a native-clock run, 30 more seeds of the accuracy control
+#   accuracy   fp32 eager-GPU control vs the HIP path (HEAD and the reverted d490710 variant) on 10 shared seeds, the
+#              trained-weights gradient-bias probe for both libraries, reference-driver schedule and native-clock runs
+# Outputs land in gpurun_out/r04/ (scratch); what is judged is copied to profiles/ by hand.
+set -u
+cd "$(dirname "$0")/.."
+export TMPDIR=/tmp
+O=gpurun_out/r04
+mkdir -p $O
+SEEDS10="1 2 3 4 5 6 7 8 9 10"
+SEEDS5="1 2 3 4 5"
+VAR=variants/lib_pl_from_a.so
+stage=${1:-accuracy}
+t0=$(date +%s)
+lap() { echo "[$(( $(date +%s) - t0 )) s] $*"; }
+
+if [ "$stage" = accuracy ]; then
+  python tests/accuracy_experiment.py --backend port --device cuda --seeds $SEEDS10 --keyframes 24 --steps-per-kf 100 \
+      --out $O/acc_control_fp32_gpu_24x100.json > $O/acc_control_fp32_gpu_24x100.log 2>&1; lap control 24x100
+  python tests/accuracy_experiment.py --backend hip --seeds $SEEDS10 --keyframes 24 --steps-per-kf 100 \
+      --out $O/acc_hip_24x100.json > $O/acc_hip_24x100.log 2>&1; lap hip 24x100
+  ISDF_HIP_LIB=$VAR python tests/accuracy_experiment.py --backend hip --seeds $SEEDS10 --keyframes 24 --steps-per-kf 100 \
+      --out $O/acc_hip_pl_from_a_24x100.json > $O/acc_hip_pl_from_a_24x100.log 2>&1; lap variant 24x100
+  python tests/grad_bias_probe.py --make-weights /tmp/probe_w.pt > $O/probe_make.log 2>&1; lap probe weights
+  python tests/grad_bias_probe.py --weights /tmp/probe_w.pt --out $O/probe_head.json > $O/probe_head.log 2>&1; lap probe head
+  ISDF_HIP_LIB=$VAR python tests/grad_bias_probe.py --weights /tmp/probe_w.pt --out $O/probe_pl_from_a.json > $O/probe_pl_from_a.log 2>&1; lap probe variant
+  python tests/accuracy_experiment.py --native-clock --backend hip --seeds $SEEDS5 --out $O/native_clock_hip.json > $O/native_clock_hip.log 2>&1; lap native hip
+  python tests/accuracy_experiment.py --native-clock --backend port --device cuda --seeds $SEEDS5 --out $O/native_clock_port_cuda.json > $O/native_clock_port_cuda.log 2>&1; lap native port
+  python tests/accuracy_experiment.py --native-clock --backend hip --seeds $SEEDS5 --max-steps 20000 --out $O/native_clock_hip_cap20000.json > $O/native_clock_hip_cap20000.log 2>&1; lap native hip capped
+  python tests/accuracy_experiment.py --reference-schedule --steps 1000 --backend hip --seeds $SEEDS10 --out $O/refsched_hip.json > $O/refsched_hip.log 2>&1; lap refsched hip
+  python tests/accuracy_experiment.py --reference-schedule --steps 1000 --backend port --device cuda --seeds $SEEDS10 --out $O/refsched_port_cuda.json > $O/refsched_port_cuda.log 2>&1; lap refsched port
+  tail -n 3 $O/*.log
+fi
+
+if [ "$stage" = ab1 ]; then
+  python -m pytest tests/test_gpu_parity.py -q -s -m gpu -k "trained" > $O/pytest_trained.log 2>&1; lap pytest trained
+  python -m pytest tests -q -m gpu > $O/pytest_gpu.log 2>&1; lap pytest gpu
+  for rep in 1 2; do for f in variants/lib_*.so; do
+    ISDF_HIP_LIB=$PWD/$f python bench.py --steps 300 --warmup 50 --no-cpu-baseline > $O/ab1_$(basename $f .so)_$rep.json 2> /dev/null; lap bench $f $rep
+  done; done
+  python tests/accuracy_experiment.py --native-clock --backend hip --seeds 1 2 --out $O/native_clock_hip_diag.json > $O/native_clock_hip_diag.log 2>&1; lap native diag
+  python tests/accuracy_experiment.py --backend hip --seeds $(seq 11 40) --keyframes 24 --steps-per-kf 100 \
+      --out $O/acc_hip_24x100_seeds11_40.json > $O/acc_hip_24x100_seeds11_40.log 2>&1; lap hip 30 seeds
+  python tests/accuracy_experiment.py --backend port --device cuda --seeds $(seq 11 20) --keyframes 24 --steps-per-kf 100 \
+      --out $O/acc_control_fp32_gpu_24x100_seeds11_20.json > $O/acc_control_seeds11_20.log 2>&1; lap control 10 seeds
+  tail -n 25 $O/pytest_trained.log; tail -n 8 $O/pytest_gpu.log
+  for f in $O/ab1_*.json; do python - "$f" <<'PY'
+import json, sys
+j = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); fm = j.get("fast_mode_fp16") or {}
+print("%-28s %8.1f steps/s %.4f ms chain %.4f dw %.4f tail %.4f sync %.4f | fp16 %8.1f chain %.4f | loss %.5f" % (
+    sys.argv[1].split("ab1_")[1][:-5], j["value"], j["ms_per_step"], *list(j["kernel_ms"].values())[:3], j["trainer_step_sync_ms"],
+    fm.get("steps_per_s", 0), fm.get("chain_ms", 0), j["final_total_loss"]))
+PY
+  done
+  tail -n 3 $O/native_clock_hip_diag.log $O/acc_hip_24x100_seeds11_40.log $O/acc_control_seeds11_20.log
+fi
