@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define ISDF_ABI_VERSION 4
+#define ISDF_ABI_VERSION 5
 
 enum {
   ISDF_OK = 0,
@@ -86,6 +86,12 @@ int64_t isdf_workspace_bytes(const isdf_net_cfg* net, int64_t max_points, int32_
 /* number of floats in the flat reduction buffer written by isdf_train_step:
  *   [ grad(n_params) | loss_sums(8) | block_loss(F*64) | block_cnt(F*64) ]    */
 int64_t isdf_reduce_floats(const isdf_net_cfg* net, int32_t n_frames);
+/* first float of the reduction buffer that is complete when isdf_step_out.split_event is recorded: the message's SUFFIX
+ * [isdf_reduce_split_floats, isdf_reduce_floats + extra_floats) = weight gradients of the layers from the cat layer up, the out
+ * layer, loss sums, bins and the caller's tail; the PREFIX [0, isdf_reduce_split_floats) = layers below the cat layer
+ * follows with the call's last launch.  (New: the reference has no collective, README.md:102; SURVEY 8e "overlap the
+ * all-reduce of early-finished layers' dW".)                                                                       */
+int64_t isdf_reduce_split_floats(const isdf_net_cfg* net);
 
 /* Rebuild the packed operand copies from the fp32 parameters (after loading a
  * checkpoint; isdf_adamw does it itself after every update).                  */
@@ -222,6 +228,10 @@ typedef struct isdf_step_out {
                            `losses` of Trainer.step (trainer.py:1016; loss.py:187-200)
                            need no device->host copy command -- they are valid after the
                            caller's closing stream synchronisation (metrics.py:27-30)   */
+  void* split_event;    /* optional hipEvent_t, isdf_train_step only (data parallel): the closing reduction runs as TWO
+                           launches and this event is recorded on `stream` between them -- the suffix of reduce_buf
+                           (isdf_reduce_split_floats) is final at the event, so its all-reduce can run on a second stream
+                           beside the second launch.  Same arithmetic, same values as the one-launch form.            */
 } isdf_step_out;
 
 /* layout of loss_sums inside reduce_buf (after the n_params gradient floats) */

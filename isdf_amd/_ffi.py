@@ -11,12 +11,13 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # ISDF_HIP_LIB: development override (A/B variants and the instrumented build of tools/build_variants.py)
 LIB_PATH = os.environ.get("ISDF_HIP_LIB") or os.path.join(HERE, "libisdf_hip.so")
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 # every symbol include/isdf_hip.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
     "isdf_abi_version", "isdf_error_string", "isdf_check_net", "isdf_param_count", "isdf_shadow_bytes",
-    "isdf_workspace_bytes", "isdf_reduce_floats", "isdf_sample_scan_bytes", "isdf_pack_weights", "isdf_sample_rays",
+    "isdf_workspace_bytes", "isdf_reduce_floats", "isdf_reduce_split_floats", "isdf_sample_scan_bytes", "isdf_pack_weights",
+    "isdf_sample_rays",
     "isdf_sdf_eval", "isdf_train_step", "isdf_train_step_adamw", "isdf_train_step_finish", "isdf_bounds_pc",
     "isdf_frame_avg", "isdf_adamw", "isdf_estimate_normals", "isdf_render_depth",
 ]
@@ -70,7 +71,8 @@ class StepArgs(C.Structure):
 
 class StepOut(C.Structure):
     _fields_ = [("reduce_buf", C.c_void_p), ("sdf", C.c_void_p), ("sdf_grad", C.c_void_p),
-                ("tot_loss_mat", C.c_void_p), ("prof_events", C.POINTER(C.c_void_p)), ("host_mailbox", C.c_void_p)]
+                ("tot_loss_mat", C.c_void_p), ("prof_events", C.POINTER(C.c_void_p)), ("host_mailbox", C.c_void_p),
+                ("split_event", C.c_void_p)]
 
 
 class OptimArgs(C.Structure):
@@ -103,7 +105,7 @@ def lib():
     L.isdf_error_string.argtypes = [C.c_int]
     L.isdf_check_net.restype = C.c_int
     L.isdf_check_net.argtypes = [P(NetCfg)]
-    for n in ("isdf_param_count", "isdf_shadow_bytes"):
+    for n in ("isdf_param_count", "isdf_shadow_bytes", "isdf_reduce_split_floats"):
         getattr(L, n).restype = i64
         getattr(L, n).argtypes = [P(NetCfg)]
     L.isdf_workspace_bytes.restype = i64
@@ -123,7 +125,7 @@ def lib():
     L.isdf_adamw.argtypes = [P(NetCfg), vp, vp, vp, vp, vp, f32, f32, f32, f32, f32, f32, i32, vp, vp]
     L.isdf_estimate_normals.argtypes = [vp, i32, i32, f32, f32, f32, f32, vp, vp]
     L.isdf_render_depth.argtypes = [vp, i64, i64, i32, vp, vp, vp, f32, vp, vp, vp]
-    for n in SYMBOLS[8:]:
+    for n in SYMBOLS[SYMBOLS.index("isdf_pack_weights"):]:
         getattr(L, n).restype = C.c_int
     if L.isdf_abi_version() != ABI_VERSION:
         raise IsdfError("libisdf_hip.so ABI %d != binding ABI %d" % (L.isdf_abi_version(), ABI_VERSION))

@@ -25,7 +25,7 @@ int launch_step_tail(int phase, const NetLayout& L, const float* dwPart, const f
                      float eps, float wd, int step, const float* wg_loss, int64_t maxTiles, const int32_t* n_valid, int S,
                      const float* tot_ws, const int64_t* ib, const int64_t* ih, const int64_t* iw, int F, int H, int W,
                      float* loss_sums, float* bl, float* bc, float* la_out, float* fa_out, const int32_t* fa_index,
-                     hipStream_t st, float* mailbox, float* extra, int n_extra, int extra_slot, float extra_value);
+                     hipStream_t st, float* mailbox, float* extra, int n_extra, int extra_slot, float extra_value, int part = 0);
 int launch_frame_avg(const float* bl, const float* bc, int F, float* la, float* fa, const int32_t* fa_index,
                      hipStream_t st);
 int launch_bounds_pc(const int32_t* n_valid, int max_rays, int S, const float* pc, const float* z, const float* depth,
@@ -86,6 +86,12 @@ int64_t isdf_reduce_floats(const isdf_net_cfg* net, int32_t n_frames) {
   NetLayout l; int rc = make_layout(net, &l);
   if (rc) return rc;
   return l.n_params + 8 + 2 * (int64_t)n_frames * 64;
+}
+
+int64_t isdf_reduce_split_floats(const isdf_net_cfg* net) {
+  NetLayout l; int rc = make_layout(net, &l);
+  if (rc) return rc;
+  return l.offW[l.cat];    // cat_layer.0.weight: everything from here on is final at isdf_step_out.split_event
 }
 
 int isdf_pack_weights(const isdf_net_cfg* net, const float* params, void* shadow, void* stream) {
@@ -204,12 +210,17 @@ static int train_step_impl(const isdf_net_cfg* net, const isdf_loss_cfg* loss, c
     return ISDF_OK;
   }
   // two-call / data-parallel form: slab + partial reduction and loss/bin finalisation in ONE launch; the summed
-  // gradient then goes to the all-reduce and isdf_adamw
-  rc = launch_step_tail(1, l, dwPart, vecPart, w.vecStride, o->reduce_buf, nullptr, nullptr, nullptr, nullptr, 1.f, 0.f,
-                        0.f, 0.f, 0.f, 0.f, 1, wgLoss, w.nTiles, a->n_valid, a->S, totLoss, a->indices_b, a->indices_h,
-                        a->indices_w, a->n_frames, a->H, a->W, lossSums, blockLoss, blockCnt, nullptr, nullptr, nullptr,
-                        st, o->host_mailbox, extra, a->extra_floats, a->extra_slot, a->extra_value);
-  if (rc) return rc;
+  // gradient then goes to the all-reduce and isdf_adamw.  With o->split_event: TWO launches, the event between them -- the
+  // message's suffix (layers from the cat layer up, out layer, loss sums, bins) is final at the event.
+  const int parts = o->split_event ? 2 : 1;
+  for (int part = 1; part <= parts; ++part) {
+    rc = launch_step_tail(1, l, dwPart, vecPart, w.vecStride, o->reduce_buf, nullptr, nullptr, nullptr, nullptr, 1.f, 0.f,
+                          0.f, 0.f, 0.f, 0.f, 1, wgLoss, w.nTiles, a->n_valid, a->S, totLoss, a->indices_b, a->indices_h,
+                          a->indices_w, a->n_frames, a->H, a->W, lossSums, blockLoss, blockCnt, nullptr, nullptr, nullptr,
+                          st, o->host_mailbox, extra, a->extra_floats, a->extra_slot, a->extra_value, parts == 1 ? 0 : part);
+    if (rc) return rc;
+    if (parts == 2 && part == 1 && hipEventRecord((hipEvent_t)o->split_event, st) != hipSuccess) return ISDF_EHIP;
+  }
   if (ev && hipEventRecord(ev[3], st) != hipSuccess) return ISDF_EHIP;
   return ISDF_OK;
 }
@@ -225,6 +236,7 @@ int isdf_train_step_adamw(const isdf_net_cfg* net, const isdf_loss_cfg* loss, co
                           int64_t workspace_bytes, void* stream) {
   if (!opt || !opt->params || !opt->exp_avg || !opt->exp_avg_sq || !opt->shadow || opt->step < 1) return ISDF_EINVAL;
   if ((opt->loss_approx == nullptr) != (opt->frame_avg == nullptr)) return ISDF_EINVAL;   // both or neither
+  if (o && o->split_event) return ISDF_EINVAL;   // the fused form has no message to split
   return train_step_impl(net, loss, opt->params, opt->shadow, a, o, workspace, workspace_bytes, stream, opt);
 }
 

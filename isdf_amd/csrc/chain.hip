@@ -235,25 +235,6 @@ __global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 && EP == HD && !oper_x2_a
 #pragma unroll
     for (int e = 0; e < 4; ++e) { o[e] = __uint_as_float(a[e]); o[4 + e] = __uint_as_float(b[e]); }
   };
-  // The forward epilogues' biases come from LDS: the hidden layers' bias vectors (all but the top one) are parked in part[],
-  // the top one in gbs[] -- both idle until the end of the forward sweep -- by one coalesced load per thread here, instead of
-  // two 16-byte buffer loads per accumulator block and layer in the epilogues (224 vector-memory instructions per tile on the
-  // kernel's busiest unit).  Nets whose bias vectors do not fit (HD = 512, more than 9 layers) keep the loads.
-  const bool biasLds = HD == BM * 4 && (L.L - 1) * HD <= T::NPART * BM * 4;
-  if (biasLds) {
-    for (int i = tid; i < (L.L - 1) * HD; i += T::NW * 64) part[i] = p.params[L.offB[i / HD] + i % HD];
-    if (tid < HD) gbs[tid] = p.params[L.offB[L.L - 1] + tid];
-  }
-  // bias of hidden layer li for the block's 8 features (staged in LDS above, or straight from the parameter buffer)
-  auto ld_bias8 = [&](int li, int ub, float (&o)[8]) {
-    if (biasLds) {
-      const float* src = (li == L.L - 1 ? gbs : part + li * HD) + ub + 4 * hi;
-      const float4 a = *(const float4*)src, b = *(const float4*)(src + 8);
-      o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
-    } else {
-      ld_params8(L.offB[li] + ub, o);
-    }
-  };
   // per-workgroup partial of a bias / out-layer gradient entry: sum over the half-wave's 32 points
   // The 8 values of an accumulator block (features elemUniform + 4*hi + {0..3, 8..11}) go out in ONE store: after the butterflies
   // every lane holds all eight sums, lane j < 8 of each half keeps sum j and writes it to its feature.  (One store per VALUE made
@@ -474,7 +455,7 @@ __global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 && EP == HD && !oper_x2_a
     if (!last) {
       float bv[8];
       for_blocks([&](int fb, int pb, int qp, int row) {
-        if (pb == 0) ld_bias8(li, ubase(fb, qp), bv);
+        if (pb == 0) ld_params8(L.offB[li] + ubase(fb, qp), bv);
         float a[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) a[e] = softplus_f(acc[fb][pb][8 * qp + e] + bv[e]);
@@ -486,7 +467,7 @@ __global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 && EP == HD && !oper_x2_a
       float bv[8], wv[8];
       for_blocks([&](int fb, int pb, int qp, int row) {
         if (pb == 0) {
-          ld_bias8(li, ubase(fb, qp), bv);
+          ld_params8(L.offB[li] + ubase(fb, qp), bv);
           ld_params8(L.offWout + ubase(fb, qp), wv);
         }
         float a[8], pl[8];

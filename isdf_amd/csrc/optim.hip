@@ -230,6 +230,7 @@ struct TailParams {
   const float* count_ptr;            // PHASE 2: gradient = grad[] * grad_scale / *count_ptr (reduced count)
   FinalizeArgs fin;
   int nW, nV;                        // blocks of the weight and the vector sections
+  int wBlock0;                       // first weight block of this launch (a split tail runs the weight section in two launches)
 };
 
 __device__ __forceinline__ void shadow_put(const NetLayout& L, uint16_t* sh, bool fwdSet, int64_t elem, float val,
@@ -286,7 +287,7 @@ __global__ __launch_bounds__(1024) void step_tail_kernel(const TailParams p) {
   const bool emptyBatch = (PHASE == 0 && P == 0) || (PHASE == 2 && p.count_ptr && *p.count_ptr == 0.f);
   if (b < p.nW) {
     // ---- weights (dw_reduce_kernel's mapping: one thread per element of a 256x256 dW unit)
-    const int64_t idx = (int64_t)b * 1024 + threadIdx.x;
+    const int64_t idx = (int64_t)(b + p.wBlock0) * 1024 + threadIdx.x;
     constexpr int64_t perUnit = (int64_t)DW_BLK * DW_BLK;
     const int unit = (int)(idx / perUnit);
     if (unit >= dw_units(L)) return;
@@ -455,7 +456,9 @@ int launch_step_tail(int phase, const NetLayout& L, const float* dwPart, const f
                      float eps, float wd, int step, const float* wg_loss, int64_t maxTiles, const int32_t* n_valid, int S,
                      const float* tot_ws, const int64_t* ib, const int64_t* ih, const int64_t* iw, int F, int H, int W,
                      float* loss_sums, float* bl, float* bc, float* la_out, float* fa_out, const int32_t* fa_index,
-                     hipStream_t st, float* mailbox, float* extra, int n_extra, int extra_slot, float extra_value) {
+                     hipStream_t st, float* mailbox, float* extra, int n_extra, int extra_slot, float extra_value, int part) {
+  // part 0: everything in one launch.  Split tail (phase 1 only): part 1 = weight blocks of the dW units from the cat layer up +
+  // vector section + finalisation (the message's suffix, isdf_reduce_split_floats), part 2 = the weight blocks below.
   TailParams p = {};
   p.lay = L; p.dwPart = dwPart; p.vecPart = vecPart; p.vecStride = vecStride; p.grad = grad;
   p.params = params; p.m = m; p.v = v; p.shadow = shadow; p.grad_scale = grad_scale;
@@ -467,7 +470,17 @@ int launch_step_tail(int phase, const NetLayout& L, const float* dwPart, const f
   const int64_t total = (int64_t)dw_units(L) * DW_BLK * DW_BLK;
   p.nW = (int)((total + 1023) / 1024);
   p.nV = (L.L * L.HD + L.HD + 1 + 63) / 64;
-  const dim3 grid((unsigned)(p.nW + p.nV + 1 + F));
+  int tailBlocks = p.nV + 1 + F;
+  if (part != 0) {
+    if (phase != 1) return ISDF_EINVAL;
+    int unitsBelow = 0;                     // dW units of the layers below the cat layer (units are numbered layer by layer)
+    for (int li = 0; li < L.cat; ++li) unitsBelow += (L.HD / DW_BLK) * (dw_kpad(L, li) / DW_BLK);
+    const int split = unitsBelow * (DW_BLK * DW_BLK / 1024);
+    if (part == 1) { p.wBlock0 = split; p.nW -= split; }
+    else { p.nW = split; p.nV = 0; tailBlocks = 0; }
+  }
+  const dim3 grid((unsigned)(p.nW + tailBlocks));
+  if (grid.x == 0) return ISDF_OK;
   if (phase == 0) hipLaunchKernelGGL(step_tail_kernel<0>, grid, dim3(1024), 0, st, p);
   else hipLaunchKernelGGL(step_tail_kernel<1>, grid, dim3(1024), 0, st, p);
   return isdf_launch_status();

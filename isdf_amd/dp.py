@@ -39,6 +39,32 @@ def allreduce_(buf, group=None):
     return buf
 
 
+def new_split_event(device):
+    """an event whose native handle exists (torch creates it at the first record)"""
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(device))
+    return ev
+
+
+def allreduce_split_(buf, cut, split_event, side_stream, group=None):
+    """The step's collective in TWO parts ("overlap the all-reduce of early-finished layers' dW"): the suffix
+    buf[cut:] -- final at `split_event`, which isdf_train_step recorded between its two closing launches -- is reduced on
+    `side_stream` while the second launch still fills the prefix buf[:cut]; the prefix follows in stream order.  Element-wise
+    sums over the same ranks: at world size 2 the result equals the one-message all-reduce bit for bit (a + b); with more
+    ranks RCCL's ring order depends on the message layout, so the two forms may differ by fp32 re-association, each of them
+    identical on every rank.  The caller's stream waits for both parts before this returns."""
+    if group is None and not (torch.distributed.is_available() and torch.distributed.is_initialized()):
+        return buf
+    side_stream.wait_event(split_event)
+    with torch.cuda.stream(side_stream):
+        w1 = torch.distributed.all_reduce(buf[cut:], op=torch.distributed.ReduceOp.SUM, group=group, async_op=True)
+    w2 = torch.distributed.all_reduce(buf[:cut], op=torch.distributed.ReduceOp.SUM, group=group, async_op=True)
+    w1.wait()
+    w2.wait()
+    torch.cuda.current_stream(buf.device).wait_stream(side_stream)
+    return buf
+
+
 def finish(buf, n_params, n_frames):
     """What the step does with the reduced buffer: mean gradient, mean losses,
     block averages (loss.py:208-240).  Used by the CPU protocol tests; on the GPU

@@ -179,6 +179,7 @@ class Engine:
         self.mailbox = None           # pinned host mirror of [loss sums (8) | reduced tail (reduce_extra)]
         self._step_plans = {}
         self.opt_step = 0
+        self.reduce_split = int(self.lib.isdf_reduce_split_floats(C.byref(self.cnet)))   # first float of the message's early-final suffix
         self.slices = {}
         off = 0
         for k, shp in net.param_shapes():
@@ -322,7 +323,8 @@ class Engine:
 
     # ---- training step ----------------------------------------------------------
     def train_step(self, smp, lc: LossConfig, sc: SampleConfig, noise=None, debug=False, prof_events=None,
-                   noise_std=0.0, noise_seed=0, noise_offset=0, optim=None, surf_group=None, extra_slot=0, extra_value=0.0):
+                   noise_std=0.0, noise_seed=0, noise_offset=0, optim=None, surf_group=None, extra_slot=0, extra_value=0.0,
+                   split_event=None):
         """Everything between sampling and the optimiser.  Fills self.reduce_buf with
         [grad sums | loss sums(8) | block_loss | block_cnt]; returns debug tensors.
 
@@ -332,6 +334,9 @@ class Engine:
         all-gathered surface samples of every rank.
         extra_slot / extra_value: with `self.reduce_extra` caller-owned floats behind the reduction message, the step writes
         extra_value into slot extra_slot and 0 into the others (data parallel: this rank's previous step time).
+        split_event: torch.cuda.Event (two-call form only): the closing reduction runs as two launches with this event recorded
+        between them; `self.reduce_buf[self.reduce_split:]` is final at the event (dp.allreduce_split_ overlaps its all-reduce
+        with the second launch).
         The loss sums also land in `self.mailbox[:8]` (pinned host memory), valid after the next stream synchronisation."""
         dev = self.device
         F, R0, S = smp["n_frames"], smp["max_rays"], smp["S"]
@@ -348,6 +353,7 @@ class Engine:
                         R0, S, F, sc.H, sc.W, lc.loss_type, lc.trunc_weight, lc.trunc_distance,
                         lc.eik_weight, lc.eik_apply_dist, lc.grad_weight, lc.orien_loss, optim is None,
                         0 if fo is None else fo.data_ptr(), 0 if fi is None else fi.data_ptr(), self.reduce_extra,
+                        0 if split_event is None else split_event.cuda_event,
                         None if self.reduce_buf is None else self.reduce_buf.data_ptr(), None if self._ws is None else self._ws.data_ptr())
             plan = self._step_plans.get(smp["_slot"])
             if plan is not None and plan[0] == plan_key:
@@ -420,6 +426,10 @@ class Engine:
         o.host_mailbox = self.mailbox.data_ptr()
         if prof_events is not None:   # ctypes array of 4 hipEvent_t (bench.py)
             o.prof_events = prof_events
+        if split_event is not None:
+            if optim is not None:
+                raise ValueError("split_event belongs to the two-call (data-parallel) form")
+            o.split_event = split_event.cuda_event
         dbg = {}
         if debug:
             dbg = dict(sdf=torch.zeros(R0, S, device=dev), sdf_grad=torch.zeros(R0, S, 3, device=dev),

@@ -277,8 +277,15 @@ class HotPath:
             kw["surf_group"] = hip.dist_group
         if hip.clock_slots:              # this rank's previous step time rides in the message's tail (one slot per rank)
             kw.update(extra_slot=hip.rank, extra_value=hip.prev_step_ms)
+        split = hip.dist_group is not None and hip.overlap_allreduce and not fused_optim
+        if split:
+            if hip.split_event is None:
+                hip.split_event, hip.comm_stream = dp.new_split_event(hip.device), torch.cuda.Stream(hip.device)
+            kw["split_event"] = hip.split_event
         dbg = eng.train_step(s, self._loss_cfg(), sc, noise=noise, **kw)
-        if hip.dist_group is not None:   # sums over ranks; AdamW divides by the reduced count
+        if split:                        # the message in two parts, the first one beside the closing reduction's second launch
+            dp.allreduce_split_(eng.reduce_buf, eng.reduce_split, hip.split_event, hip.comm_stream, hip.dist_group)
+        elif hip.dist_group is not None:   # sums over ranks; AdamW divides by the reduced count
             dp.allreduce_(eng.reduce_buf, hip.dist_group)   # THE collective of the step
         return dbg
 
@@ -550,7 +557,7 @@ UNSUPPORTED_HINT = ("isdf_amd hot path: %s (the reference's own Python path is t
 
 
 def graft(trainer, rng="philox", seed=1, dist_group=None, fix_normal_window=False, fwd_operand="fp16x2",
-          fuse_optimiser=True, virtual_step_ms=None, engine_factory=None):
+          fuse_optimiser=True, virtual_step_ms=None, engine_factory=None, overlap_allreduce=False):
     """Re-bind the hot path of `trainer` (an `isdf.modules.trainer.Trainer` or a `StandinTrainer`) to the HIP
     kernels, IN PLACE, and return it.
 
@@ -560,6 +567,8 @@ def graft(trainer, rng="philox", seed=1, dist_group=None, fix_normal_window=Fals
          weights are broadcast from rank 0 here so every rank starts from the same network.
     virtual_step_ms: if set, the virtual clock advances by this much per step instead of the measured step time
          (the frame schedule is a function of measured time, trainer.py:100-101,1011-1013; pin it to compare runs).
+    overlap_allreduce: data parallel only -- the closing reduction in two launches and the all-reduce in two parts, the first
+         one on a side stream beside the second launch (dp.allreduce_split_); two collectives per step instead of one.
     engine_factory: tests only (a stand-in engine for hosts without a GPU)."""
     if isinstance(trainer, HotPath) and getattr(trainer, "_hip", None) is not None:
         return trainer
@@ -604,6 +613,8 @@ def graft(trainer, rng="philox", seed=1, dist_group=None, fix_normal_window=Fals
     hip = types.SimpleNamespace(rng=rng, seed=int(seed), dist_group=dist_group, fix_normal_window=bool(fix_normal_window),
                                 fuse_optimiser=bool(fuse_optimiser), device=dev, draw_count=0, noise_count=0,
                                 step_count=0, idx_cache=None, timing_events=None,
+                                overlap_allreduce=bool(overlap_allreduce) and dist_group is not None, split_event=None,
+                                comm_stream=None,
                                 virtual_step_ms=None if virtual_step_ms is None else float(virtual_step_ms),
                                 loss_host=torch.zeros(8, dtype=torch.float32,
                                                       pin_memory=(dev.type == "cuda")))

@@ -21,7 +21,7 @@ from .standin import FrameData, StandinTrainer                   # noqa: F401
 class HipTrainer(HotPath, StandinTrainer):
     def __init__(self, device, config, incremental=True, inv_bounds_transform=None, rng="philox",
                  seed=1, dist_group=None, fix_normal_window=False, fwd_operand="fp16x2", virtual_step_ms=None,
-                 engine_factory=None):
+                 engine_factory=None, overlap_allreduce=False):
         """config: path to / dict with the reference's JSON schema (replicaCAD.json).
         rng: "philox" (in-kernel, no host sync) or "torch" (draw with torch in the
         reference's order and shapes -- parity mode, one host sync per step)."""
@@ -29,7 +29,8 @@ class HipTrainer(HotPath, StandinTrainer):
         StandinTrainer.__init__(self, device, config, None, incremental, inv_bounds_transform=inv_bounds_transform,
                                 fwd_operand=fwd_operand, engine_factory=engine_factory)
         graft(self, rng=rng, seed=seed, dist_group=dist_group, fix_normal_window=fix_normal_window,
-              fwd_operand=fwd_operand, virtual_step_ms=virtual_step_ms, engine_factory=engine_factory)
+              fwd_operand=fwd_operand, virtual_step_ms=virtual_step_ms, engine_factory=engine_factory,
+              overlap_allreduce=overlap_allreduce)
 
     # aliases kept for checkpoint files / callers of round 1
     def state_dict(self):

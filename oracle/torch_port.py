@@ -60,12 +60,19 @@ class PortNet(torch.nn.Module):
 def sample_step(depth, T_WC, normals, cam, sc, gen):
     """sample_pixels + get_batch_data + sample_along_rays (`sample.py:11-178`).  The draws come from the (CPU)
     generator `gen` and are moved to the data's device -- what the reference itself does for the surface offsets
-    (sample.py:160-162); on "cuda" the rest of the chain then runs as eager device ops like upstream."""
+    (sample.py:160-162); on "cuda" the rest of the chain then runs as eager device ops like upstream.
+    gen None: draw exactly as the reference does -- torch's GLOBAL generators, pixel indices and stratified offsets on the data's
+    device (sample.py:15-16,123), the surface offsets on the CPU (sample.py:160-162) -- so that a run seeded with
+    torch.manual_seed consumes the same random stream as `HipTrainer(rng="torch")` (paired accuracy runs)."""
     F, H, W = depth.shape
     n = sc["n_rays"]
     dev = depth.device
-    ih = torch.randint(0, H, (F * n,), generator=gen).to(dev)
-    iw = torch.randint(0, W, (F * n,), generator=gen).to(dev)
+    if gen is None:
+        ih = torch.randint(0, H, (F * n,), device=dev)
+        iw = torch.randint(0, W, (F * n,), device=dev)
+    else:
+        ih = torch.randint(0, H, (F * n,), generator=gen).to(dev)
+        iw = torch.randint(0, W, (F * n,), generator=gen).to(dev)
     ib = torch.arange(F, device=dev).repeat_interleave(n)
     d = depth[ib, ih, iw]
     nm = normals[ib, ih, iw]
@@ -79,7 +86,8 @@ def sample_step(depth, T_WC, normals, cam, sc, gen):
     maxd = d + sc["dist_behind_surf"]
     rng = (maxd - sc["min_depth"])[:, None]
     lim = torch.linspace(0, 1, sc["n_strat"] + 1, device=dev)[None, :].repeat(R, 1) * rng + sc["min_depth"]
-    z = lim[:, :-1] + torch.rand(R, sc["n_strat"], generator=gen).to(dev) * (rng / sc["n_strat"])
+    U = torch.rand(R, sc["n_strat"], device=dev) if gen is None else torch.rand(R, sc["n_strat"], generator=gen).to(dev)
+    z = lim[:, :-1] + U * (rng / sc["n_strat"])
     off = torch.normal(torch.zeros(R, sc["n_surf"] - 1), 0.1, generator=gen).to(dev)
     near = torch.clamp(d[:, None] + off, torch.full((R, 1), sc["min_depth"], device=dev), maxd[:, None])
     z = torch.cat((d[:, None], near, z), 1)
@@ -92,7 +100,8 @@ def loss_step(net, s, lc, noise_std, gen, noise=None):
     noise: optional pre-drawn, pre-scaled noise (parity tests)."""
     pc = s["pc"].clone().requires_grad_()
     if noise is None and noise_std is not None:
-        noise = torch.randn(pc.shape[:-1], generator=gen).to(pc.device) * noise_std
+        noise = (torch.randn(pc.shape[:-1], device=pc.device) if gen is None else
+                 torch.randn(pc.shape[:-1], generator=gen).to(pc.device)) * noise_std
     sdf = net(pc, noise)
     g = torch.autograd.grad(sdf, pc, torch.ones_like(sdf), create_graph=True, retain_graph=True)[0]
     bounds = s["dC"].norm(dim=-1)[:, None] * (s["depth"][:, None] - s["z"])

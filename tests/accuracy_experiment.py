@@ -98,15 +98,21 @@ def prepare_keyframes(seeds, n):
 
 
 FWD_OPERAND = "fp16x2"   # --fwd-operand: the HIP path's operand mode for the pinned-schedule runs
+PAIRED = False           # --paired-draws: both backends draw from torch's global generators in the reference's order
 DEVICE = "cpu"           # --device: where the port backend runs ("cuda" = PyTorch-ROCm eager, the fp32 control on the same GPU)
 
 
 def run_hip(seed, depth, normal, T, cam, steps_per_kf):
     from isdf_amd.trainer import HipTrainer, FrameData
     np.random.seed(seed); torch.manual_seed(seed)
-    tr = HipTrainer("cuda", config(cam), inv_bounds_transform=synthetic.bounds_transform(), rng="philox", seed=seed,
-                    fwd_operand=FWD_OPERAND)
+    tr = HipTrainer("cuda", config(cam), inv_bounds_transform=synthetic.bounds_transform(), rng="torch" if PAIRED else "philox",
+                    seed=seed, fwd_operand=FWD_OPERAND)
     dev = tr.device
+    if PAIRED:      # the same initial network as the control: torch's xavier draw under the same seed (PortNet's constructor order)
+        from oracle import torch_port as tp
+        torch.manual_seed(seed)
+        net0 = tp.PortNet(256, 2, 6, 0.05937489, 0.14, synthetic.bounds_transform())
+        tr.sdf_map.load_state_dict(net0.state_dict())
     t_train = 0.0
     for k in range(depth.shape[0]):
         fd = FrameData(frame_id=np.array([k]), depth_batch=torch.from_numpy(depth[k:k + 1]).to(dev),
@@ -191,7 +197,7 @@ def run_port(seed, depth, normal, T, cam, steps_per_kf):
     dev = torch.device(DEVICE)
     net = tp.PortNet(256, 2, 6, 0.05937489, 0.14, synthetic.bounds_transform()).to(dev)
     opt = torch.optim.AdamW(net.parameters(), lr=0.0013, weight_decay=0.012)
-    gen = torch.Generator().manual_seed(seed)
+    gen = None if PAIRED else torch.Generator().manual_seed(seed)
     c = config(cam)
     sc = dict(n_rays=200, n_strat=19, n_surf=8, min_depth=0.07, dist_behind_surf=0.1)
     lc = dict(trunc_distance=c["loss"]["trunc_distance"], loss_type="L1", trunc_weight=c["loss"]["trunc_weight"],
@@ -394,14 +400,18 @@ def main():
     ap.add_argument("--virtual-step-ms", type=float, default=20.0)
     ap.add_argument("--fwd-operand", default="fp16x2", choices=["fp16x2", "fp16", "bf16", "fp16x2_full"])
     ap.add_argument("--device", default="cpu", help="device of the port backend (cuda = PyTorch-ROCm eager fp32: the control)")
+    ap.add_argument("--paired-draws", action="store_true",
+                    help="pinned schedule: both backends start from the SAME initial network and draw pixels / offsets / noise from "
+                         "torch's global generators in the reference's order (HipTrainer rng='torch'; port gen=None): identical "
+                         "random streams, so what differs between the two runs is the arithmetic")
     ap.add_argument("--native-clock", action="store_true",
                     help="reference driver loop with the MEASURED step time as the virtual clock over the whole stream")
     ap.add_argument("--frames", type=int, default=600, help="length of the 30 fps stream (native-clock mode)")
     ap.add_argument("--max-steps", type=int, default=1000000,
                     help="native-clock mode: optimisation-step cap (replicaCAD.json trainer.steps is 20000)")
     a = ap.parse_args()
-    global FWD_OPERAND, DEVICE
-    FWD_OPERAND, DEVICE = a.fwd_operand, a.device
+    global FWD_OPERAND, DEVICE, PAIRED
+    FWD_OPERAND, DEVICE, PAIRED = a.fwd_operand, a.device, a.paired_draws
     cam = dict(synthetic.SCANNET_CAM)
     res = []
     if a.native_clock or a.reference_schedule:

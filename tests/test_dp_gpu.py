@@ -60,7 +60,7 @@ def _batch(depth, normal, draws, st, ranks):
                 U=cat("U"), N_off=cat("N"), noise=cat("noise"))
 
 
-def _run_engine(bounds, ranks, group, out):
+def _run_engine(bounds, ranks, group, out, overlap=False):
     from isdf_amd.engine import Engine, NetConfig, LossConfig, SampleConfig
     from isdf_amd import synthetic, dp
     import oracle.isdf_oracle as orc
@@ -73,11 +73,14 @@ def _run_engine(bounds, ranks, group, out):
     sc = SampleConfig(n_rays=NR * len(ranks), **CAM)
     lc = LossConfig(bounds_method=bounds)
     fal = torch.zeros(F, device="cuda")
+    split_ev, side = (dp.new_split_event(eng.device), torch.cuda.Stream(eng.device)) if overlap else (None, None)
     for st in range(N_STEPS):
         b = _batch(depth, normal, draws, st, ranks)
         s = eng.sample(d, Tt, n, idx, idx, sc, draws={k: dev(v) for k, v in b.items() if k != "noise"})
-        eng.train_step(s, lc, sc, noise=dev(b["noise"]), surf_group=group if bounds == "pc" else None)
-        if group is not None:
+        eng.train_step(s, lc, sc, noise=dev(b["noise"]), surf_group=group if bounds == "pc" else None, split_event=split_ev)
+        if overlap:      # closing reduction in two launches, all-reduce in two parts (the suffix beside the second launch)
+            dp.allreduce_split_(eng.reduce_buf, eng.reduce_split, split_ev, side, group)
+        elif group is not None:
             dp.allreduce_(eng.reduce_buf, group)
         if st == 0:
             out.update(g1=eng.reduce_buf[:eng.n_params].cpu().numpy())      # first-step gradient SUMS
@@ -137,6 +140,42 @@ def _run_trainer(rank, group, out):
                t_kf=bool(tr.last_is_keyframe), t_fal=tr.frames.frame_avg_losses.cpu().numpy(), t_K=len(tr.frames))
 
 
+def _run_trainer_overlap(rank, group, out):
+    """HipTrainer(overlap_allreduce=True): the same steps as a twin with the one-message all-reduce, collectives counted"""
+    import contextlib, io
+    from isdf_amd.trainer import HipTrainer
+    from isdf_amd import synthetic
+    from tests.accuracy_experiment import config
+    cfg = config(CAM)
+    cfg["sample"].update(n_rays=64, n_rays_is_kf=128)
+    traj = synthetic.trajectory(20)
+    res = {}
+    for overlap in (False, True):
+        np.random.seed(5); torch.manual_seed(5)
+        tr = HipTrainer("cuda:0", cfg, inv_bounds_transform=synthetic.bounds_transform(), rng="philox", seed=6,
+                        dist_group=group, overlap_allreduce=overlap, virtual_step_ms=10.0)
+        rng = np.random.RandomState(3)
+        counts = {"n": 0}
+        orig = torch.distributed.all_reduce
+
+        def counted(*a, **k):
+            counts["n"] += 1
+            return orig(*a, **k)
+        with contextlib.redirect_stdout(io.StringIO()):
+            for k in range(3):
+                fr = tr.make_frame(k * 5, synthetic.render_depth(traj[k * 5], CAM, rng, noise_std=0.01), traj[k * 5])
+                tr.last_is_keyframe = True
+                tr.add_frame(fr)
+                tr.noise_std = tr.noise_kf
+                torch.distributed.all_reduce = counted
+                for _ in range(3):
+                    tr.step()
+                torch.distributed.all_reduce = orig
+        torch.cuda.synchronize()
+        res[overlap] = (tr.engine.params.cpu().numpy(), counts["n"] / 9.0)
+    out.update(to_params_one=res[False][0], to_params_two=res[True][0], to_coll_one=res[False][1], to_coll_two=res[True][1])
+
+
 def _worker(rank, world, port, path):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -148,7 +187,11 @@ def _worker(rank, world, port, path):
         o = {}
         _run_engine(bounds, [rank], group, o)
         out.update({"%s_%s" % (bounds, k): v for k, v in o.items()})
+    o = {}
+    _run_engine("ray", [rank], group, o, overlap=True)         # the two-part all-reduce: same parameters bit for bit
+    out.update({"ray_overlap_%s" % k: v for k, v in o.items()})
     _run_trainer(rank, group, out)
+    _run_trainer_overlap(rank, group, out)
     np.savez(path % rank, **out)
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
@@ -183,6 +226,13 @@ def test_two_ranks_on_one_gpu_match_the_single_process_union_batch():
         diff = np.abs(r0[bounds + "_params"] - single["params"])
         assert diff.max() <= 2 * N_STEPS * 0.0013 + 1e-7 and rel(r0[bounds + "_params"], single["params"]) < 1e-3, \
             (bounds, diff.max(), rel(r0[bounds + "_params"], single["params"]))
+    # the two-part all-reduce (closing reduction in two launches, suffix reduced on a side stream): at world size 2 the SAME
+    # parameters, moments and losses bit for bit as the one-message form, on both ranks; two collectives per step
+    for k in ("params", "m", "v", "fal", "ls", "g1"):
+        assert np.array_equal(r0["ray_overlap_" + k], r0["ray_" + k]), k
+        assert np.array_equal(r0["ray_overlap_" + k], r1["ray_overlap_" + k]), k
+    assert np.array_equal(r0["to_params_one"], r0["to_params_two"]) and np.array_equal(r0["to_params_two"], r1["to_params_two"])
+    assert float(r0["to_coll_one"]) == 1.0 and float(r0["to_coll_two"]) == 2.0
     # trainer level: both ranks hold the same network, keyframes (rank 0's frames), clock, window and decisions
     for k in ("t_params", "t_depth_sum", "t_clock", "t_idxs", "t_add_new", "t_kf", "t_fal", "t_K"):
         assert np.array_equal(r0[k], r1[k]), k

@@ -2,6 +2,8 @@
 # Round-4 GPU sessions (one gpurun call each):  tools/r04_session.sh <stage>
 #   ab1        GPU tests (new trained-state tests print their measures), same-box A/B of variants/lib_*.so, step-time
 #              distribution of a native-clock run, 30 more seeds of the accuracy control
+#   ab2        full GPU suite on the ABI-5 tree, the fixed bias-LDS variant (parity subset + same-box A/B), PAIRED accuracy runs
+#              (identical random streams and initial network, HIP vs fp32 eager), data-parallel bench modes on one GPU
 #   accuracy   fp32 eager-GPU control vs the HIP path (HEAD and the reverted d490710 variant) on 10 shared seeds, the
 #              trained-weights gradient-bias probe for both libraries, reference-driver schedule and native-clock runs
 # Outputs land in gpurun_out/r04/ (scratch); what is judged is copied to profiles/ by hand.
@@ -56,4 +58,39 @@ print("%-28s %8.1f steps/s %.4f ms chain %.4f dw %.4f tail %.4f sync %.4f | fp16
 PY
   done
   tail -n 3 $O/native_clock_hip_diag.log $O/acc_hip_24x100_seeds11_40.log $O/acc_control_seeds11_20.log
+fi
+
+if [ "$stage" = ab2 ]; then
+  python -m pytest tests -q -m gpu -s > $O/pytest_gpu2.log 2>&1; lap pytest gpu
+  ISDF_HIP_LIB=$PWD/variants/lib_biaslds2.so python -m pytest tests/test_gpu_parity.py -q -m gpu \
+      -k "ragged or base_size_forward or public_seams or determinism or checkpoint or trained" > $O/pytest_biaslds2.log 2>&1; lap pytest biaslds2
+  for rep in 1 2; do for f in variants/lib_*.so; do
+    ISDF_HIP_LIB=$PWD/$f python bench.py --steps 300 --warmup 50 --no-cpu-baseline > $O/ab2_$(basename $f .so)_$rep.json 2> /dev/null; lap bench $f $rep
+  done; done
+  S20="$(seq 1 20)"
+  python tests/accuracy_experiment.py --paired-draws --backend hip --seeds $S20 --keyframes 24 --steps-per-kf 100 \
+      --out $O/acc_paired_hip.json > $O/acc_paired_hip.log 2>&1; lap paired hip
+  python tests/accuracy_experiment.py --paired-draws --backend port --device cuda --seeds $S20 --keyframes 24 --steps-per-kf 100 \
+      --out $O/acc_paired_control.json > $O/acc_paired_control.log 2>&1; lap paired control
+  ISDF_BENCH_FORCE_DP=1 python bench.py --steps 300 --warmup 50 --no-cpu-baseline > $O/bench_forced_dp_world1.json 2> $O/bench_forced_dp_world1.err; lap dp1
+  ISDF_BENCH_FORCE_DP=1 python bench.py --steps 300 --warmup 50 --no-cpu-baseline --overlap-allreduce > $O/bench_forced_dp_world1_overlap.json 2> $O/bench_forced_dp_world1_overlap.err; lap dp1 overlap
+  for mode in "--scaling weak" "--scaling strong" "--scaling weak --overlap-allreduce"; do
+    tag=$(echo $mode | tr -d ' -')
+    ISDF_BENCH_BACKEND=gloo python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29611 \
+        bench.py --gpus 2 --steps 100 --warmup 20 --no-cpu-baseline $mode > $O/bench_dp2_gloo_$tag.json 2> $O/bench_dp2_gloo_$tag.err; lap dp2 $tag
+  done
+  tail -n 12 $O/pytest_gpu2.log; tail -n 6 $O/pytest_biaslds2.log
+  grep -h "trained-weights eval\|worst tensor\|trained-state" $O/pytest_gpu2.log | cut -c1-900
+  for f in $O/ab2_*.json $O/bench_forced_dp_world1*.json $O/bench_dp2_gloo_*.json; do python - "$f" <<'PY'
+import json, sys
+try:
+    j = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); fm = j.get("fast_mode_fp16") or {}
+    print("%-40s %8.1f /s %.4f ms chain %.4f dw %.4f tail %.4f sync %.4f | %s | loss %.5f" % (
+        sys.argv[1].split("/")[-1][:-5], j["value"], j["ms_per_step"], *list(j["kernel_ms"].values())[:3], j["trainer_step_sync_ms"],
+        json.dumps(j.get("distributed")), j["final_total_loss"]))
+except Exception as e:
+    print(sys.argv[1], "unreadable:", e)
+PY
+  done
+  tail -n 2 $O/acc_paired_hip.log $O/acc_paired_control.log
 fi
