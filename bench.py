@@ -371,7 +371,7 @@ def main():
 
     import __graft_entry__
     __graft_entry__.build(verbose=False)
-    from isdf_amd.trainer import HipTrainer, FrameData
+    from tests.standin_trainer import HipTrainer, FrameData
     from isdf_amd import synthetic, dp
 
     cfg = reference_config()
@@ -405,7 +405,7 @@ def main():
     sc = tr._sample_cfg()
     lc = tr._loss_cfg()
     S = sc.S
-    fidx = torch.arange(F, dtype=torch.int32, device=dev)
+    fidx = tuple(range(F))      # the window inline (kernel arguments), as HipTrainer.step passes it
     max_rays = F * sc.n_rays
     K, W = args.steps, args.warmup
     # per-kernel HIP events ride on every PROF_EVERY-th timed step: four event records between the launches cost ~2 us of
@@ -495,6 +495,24 @@ def main():
         per_step[i] = time.perf_counter() - t_a
     sync_step_ms = (time.perf_counter() - ts) / n_sync * 1e3      # the MEAN; median / p90 show host hiccups
 
+    # ---- the same synchronised step() once the keyframe set has outgrown the window (K = 8 > window_size = 5): the regime
+    # every real run is in after the first few seconds -- `select_keyframes` (trainer.py:652-674, the reference's own code: two
+    # device ops + a .cpu()) draws a new window on the host EVERY step; the window travels inline as kernel arguments
+    windowed_ms = None
+    if group is None and not args.wide:
+        K8 = 8
+        d8, n8, T8 = (torch.cat([t, t[:K8 - F]]) for t in (tr.frames.depth_batch, tr.frames.normal_batch, tr.frames.T_WC_batch))
+        saved = tr.frames
+        tr.frames = FrameData(frame_id=np.arange(K8), depth_batch=d8, T_WC_batch=T8, normal_batch=n8,
+                              frame_avg_losses=torch.full((K8,), 0.1, device=dev))
+        for _ in range(60):
+            tr.step()
+        t_w8 = time.perf_counter()
+        for _ in range(n_sync):
+            tr.step()
+        windowed_ms = (time.perf_counter() - t_w8) / n_sync * 1e3
+        tr.frames = saved
+
     # ---- per-kernel timing from the HIP events recorded inside the timed region
     chain_us = np.array([events.ms(4 * i, 4 * i + 1) for i in range(KP)]) * 1e3
     t_chain = np.mean([events.ms(4 * i, 4 * i + 1) for i in range(KP)]) * 1e-3
@@ -575,6 +593,10 @@ def main():
                                   "what": "HipTrainer.step(): sync + event, sampler, step kernels (AdamW, frame averages and the "
                                   "loss sums' host copy inside the last launch), sync -- per step, as Trainer.step is timed upstream"},
             "trainer_step_sync_ms": round(sync_step_ms, 4),
+            "synchronised_step_windowed": None if windowed_ms is None else {
+                "ms_per_step": round(windowed_ms, 4), "steps_per_s": round(1e3 / windowed_ms, 2), "keyframes": 8, "window": F,
+                "what": "HipTrainer.step() with K = 8 keyframes > window_size: the reference's select_keyframes draws a new window "
+                        "on the host every step (two device ops + a device->host copy), the window goes to the kernels inline"},
             "clock_ramp": {"untimed_steps_before_warmup": ramp_steps, "seconds": args.ramp_seconds},
             "chain_us_per_step": {"first5": [round(float(v), 1) for v in chain_us[:5]], "min": round(float(chain_us.min()), 1),
                                   "median": round(float(np.median(chain_us)), 1), "max": round(float(chain_us.max()), 1),

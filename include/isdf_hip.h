@@ -136,7 +136,16 @@ typedef struct isdf_sample_args {
   const float* draw_u;
   const float* draw_n;
   uint64_t seed, offset;
+  /* ABI 5 -- the window INLINE: with n_inline == n_frames (1..ISDF_MAX_INLINE_FRAMES) the kernel takes the window's keyframe
+   * indices from these kernel arguments and ignores frame_idx / normal_idx (which may then be NULL): no device copy of a window
+   * that select_keyframes (trainer.py:652-674) re-draws on the host every step, and no dependent index load in front of the
+   * depth gather.  0 = use the device arrays.                                                                            */
+  int32_t n_inline;
+  int32_t frame_idx_inline[8];
+  int32_t normal_idx_inline[8];
+  int32_t reserved_inline;
 } isdf_sample_args;
+#define ISDF_MAX_INLINE_FRAMES 8
 
 typedef struct isdf_sample_out {
   int32_t* n_valid;      /* [1]  R = rays kept (depth != 0, normal not NaN)    */
@@ -267,6 +276,11 @@ typedef struct isdf_optim_args {
   float* loss_approx;
   float* frame_avg;
   const int32_t* frame_avg_index;
+  /* ABI 5: the same index list inline (frame_avg_inline_n == n_frames, 1..ISDF_MAX_INLINE_FRAMES; frame_avg_index is then
+   * ignored and may be NULL), for the host-drawn window of every step (see isdf_sample_args.n_inline)                       */
+  int32_t frame_avg_inline_n;
+  int32_t frame_avg_index_inline[8];
+  int32_t reserved_inline;
 } isdf_optim_args;
 
 int isdf_train_step_adamw(const isdf_net_cfg* net, const isdf_loss_cfg* loss, const isdf_step_args* a,

@@ -40,7 +40,9 @@ class SampleArgs(C.Structure):
                 ("n_strat", C.c_int32), ("n_surf", C.c_int32), ("min_depth", C.c_float),
                 ("dist_behind_surf", C.c_float), ("rng_mode", C.c_int32),
                 ("draw_h", C.c_void_p), ("draw_w", C.c_void_p), ("draw_u", C.c_void_p),
-                ("draw_n", C.c_void_p), ("seed", C.c_uint64), ("offset", C.c_uint64)]
+                ("draw_n", C.c_void_p), ("seed", C.c_uint64), ("offset", C.c_uint64),
+                ("n_inline", C.c_int32), ("frame_idx_inline", C.c_int32 * 8), ("normal_idx_inline", C.c_int32 * 8),
+                ("reserved_inline", C.c_int32)]
 
 
 class SampleOut(C.Structure):
@@ -79,7 +81,9 @@ class OptimArgs(C.Structure):
     _fields_ = [("params", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p), ("shadow", C.c_void_p),
                 ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
                 ("weight_decay", C.c_float), ("grad_scale", C.c_float), ("step", C.c_int32), ("reserved", C.c_int32),
-                ("loss_approx", C.c_void_p), ("frame_avg", C.c_void_p), ("frame_avg_index", C.c_void_p)]
+                ("loss_approx", C.c_void_p), ("frame_avg", C.c_void_p), ("frame_avg_index", C.c_void_p),
+                ("frame_avg_inline_n", C.c_int32), ("frame_avg_index_inline", C.c_int32 * 8), ("reserved_inline", C.c_int32)]
+MAX_INLINE_FRAMES = 8
 
 
 

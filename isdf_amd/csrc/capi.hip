@@ -19,13 +19,15 @@ int launch_adamw_pack(const NetLayout& L, float* params, float* m, float* v, uin
                       const float* count_ptr, float grad_scale, float lr, float b1, float b2, float eps, float wd,
                       int step, hipStream_t st, int n_frames = 0, const float* bl = nullptr, const float* bc = nullptr,
                       float* la = nullptr, float* fa = nullptr, const int32_t* fa_index = nullptr,
-                      const float* loss_sums = nullptr, const float* extra = nullptr, int n_extra = 0, float* mailbox = nullptr);
+                      const float* loss_sums = nullptr, const float* extra = nullptr, int n_extra = 0, float* mailbox = nullptr,
+                      int fa_inline_n = 0, const int32_t* fa_inline = nullptr);
 int launch_step_tail(int phase, const NetLayout& L, const float* dwPart, const float* vecPart, int vecStride, float* grad,
                      float* params, float* m, float* v, uint16_t* shadow, float grad_scale, float lr, float b1, float b2,
                      float eps, float wd, int step, const float* wg_loss, int64_t maxTiles, const int32_t* n_valid, int S,
                      const float* tot_ws, const int64_t* ib, const int64_t* ih, const int64_t* iw, int F, int H, int W,
                      float* loss_sums, float* bl, float* bc, float* la_out, float* fa_out, const int32_t* fa_index,
-                     hipStream_t st, float* mailbox, float* extra, int n_extra, int extra_slot, float extra_value, int part = 0);
+                     hipStream_t st, float* mailbox, float* extra, int n_extra, int extra_slot, float extra_value, int part = 0,
+                     int fa_inline_n = 0, const int32_t* fa_inline = nullptr);
 int launch_frame_avg(const float* bl, const float* bc, int F, float* la, float* fa, const int32_t* fa_index,
                      hipStream_t st);
 int launch_bounds_pc(const int32_t* n_valid, int max_rays, int S, const float* pc, const float* z, const float* depth,
@@ -107,11 +109,12 @@ int64_t isdf_sample_scan_bytes(int64_t max_rays) { return max_rays < 1 ? ISDF_EI
 int isdf_sample_rays(const isdf_sample_args* a, const isdf_sample_out* o, void* scan_ws, int64_t scan_ws_bytes,
                      void* stream) {
   isdf_clear_stale_hip_error();
-  if (!a || !o || !a->depth_batch || !a->T_WC_batch || !a->frame_idx || !o->n_valid || !o->indices_b ||
+  if (!a || !o || !a->depth_batch || !a->T_WC_batch || !o->n_valid || !o->indices_b ||
       !o->indices_h || !o->indices_w || !o->depth_sample || !o->dirs_C_sample || !o->dirs_W_sample || !o->z_vals ||
       !o->pc)
     return ISDF_EINVAL;
-  if (a->normal_batch && !a->normal_idx) return ISDF_EINVAL;
+  if (a->n_inline != 0 && (a->n_inline != a->n_frames || a->n_inline > ISDF_MAX_INLINE_FRAMES)) return ISDF_EINVAL;
+  if (a->n_inline == 0 && (!a->frame_idx || (a->normal_batch && !a->normal_idx))) return ISDF_EINVAL;
   if (a->n_frames < 1 || a->n_rays < 1 || a->H < 1 || a->W < 1 || a->n_strat < 1 || a->n_surf < 0) return ISDF_EINVAL;
   if ((int64_t)a->n_frames * a->n_rays > 0x7fffffff / 64) return ISDF_EINVAL;
   if (a->rng_mode == 0 && (!a->draw_h || !a->draw_w || !a->draw_u || (a->n_surf > 1 && !a->draw_n))) return ISDF_EINVAL;
@@ -204,7 +207,7 @@ static int train_step_impl(const isdf_net_cfg* net, const isdf_loss_cfg* loss, c
                           opt->weight_decay, opt->step, wgLoss, w.nTiles, a->n_valid, a->S, totLoss, a->indices_b,
                           a->indices_h, a->indices_w, a->n_frames, a->H, a->W, lossSums, blockLoss, blockCnt,
                           opt->loss_approx, opt->frame_avg, opt->frame_avg_index, st, o->host_mailbox, extra, a->extra_floats,
-                          a->extra_slot, a->extra_value);
+                          a->extra_slot, a->extra_value, 0, opt->frame_avg_inline_n, opt->frame_avg_index_inline);
     if (rc) return rc;
     if (ev && hipEventRecord(ev[3], st) != hipSuccess) return ISDF_EHIP;
     return ISDF_OK;
@@ -236,6 +239,8 @@ int isdf_train_step_adamw(const isdf_net_cfg* net, const isdf_loss_cfg* loss, co
                           int64_t workspace_bytes, void* stream) {
   if (!opt || !opt->params || !opt->exp_avg || !opt->exp_avg_sq || !opt->shadow || opt->step < 1) return ISDF_EINVAL;
   if ((opt->loss_approx == nullptr) != (opt->frame_avg == nullptr)) return ISDF_EINVAL;   // both or neither
+  if (opt->frame_avg_inline_n != 0 && (opt->frame_avg_inline_n != a->n_frames || opt->frame_avg_inline_n > ISDF_MAX_INLINE_FRAMES))
+    return ISDF_EINVAL;
   if (o && o->split_event) return ISDF_EINVAL;   // the fused form has no message to split
   return train_step_impl(net, loss, opt->params, opt->shadow, a, o, workspace, workspace_bytes, stream, opt);
 }
@@ -249,6 +254,8 @@ int isdf_train_step_finish(const isdf_net_cfg* net, const isdf_optim_args* opt, 
   if (!opt || !opt->params || !opt->exp_avg || !opt->exp_avg_sq || !opt->shadow || opt->step < 1 || !reduce_buf) return ISDF_EINVAL;
   if ((opt->loss_approx == nullptr) != (opt->frame_avg == nullptr)) return ISDF_EINVAL;   // both or neither
   if (opt->loss_approx && n_frames < 1) return ISDF_EINVAL;
+  if (opt->frame_avg_inline_n != 0 && (opt->frame_avg_inline_n != n_frames || opt->frame_avg_inline_n > ISDF_MAX_INLINE_FRAMES))
+    return ISDF_EINVAL;
   if (extra_floats < 0 || extra_floats > 1016 || n_frames < 0) return ISDF_EINVAL;
   if (extra_floats > 0 && !host_mailbox) return ISDF_EINVAL;   // the reduced tail has nowhere to go: say so instead of dropping it
   const float* lossSums = reduce_buf + l.n_params;
@@ -258,7 +265,7 @@ int isdf_train_step_finish(const isdf_net_cfg* net, const isdf_optim_args* opt, 
                            lossSums + ISDF_LS_COUNT, opt->grad_scale, opt->lr, opt->beta1, opt->beta2, opt->eps,
                            opt->weight_decay, opt->step, (hipStream_t)stream, F, bl, bl + (int64_t)n_frames * 64,
                            opt->loss_approx, opt->frame_avg, opt->frame_avg_index, lossSums, bl + (int64_t)n_frames * 128,
-                           extra_floats, host_mailbox);
+                           extra_floats, host_mailbox, opt->frame_avg_inline_n, opt->frame_avg_index_inline);
 }
 
 int isdf_bounds_pc(const int32_t* n_valid, int32_t max_rays, int32_t S, const float* pc, const float* z_vals,

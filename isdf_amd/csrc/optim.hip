@@ -119,6 +119,7 @@ struct FinalizeArgs {
   // optional (single-GPU tail only): the per-frame averages of loss.frame_avg written straight away --
   // loss_approx [F,8,8] and frame_avg[fa_index ? fa_index[f] : f] (the keyframe store's frame_avg_losses)
   float *la_out, *fa_out; const int32_t* fa_index;
+  int fa_inline_n; int32_t fa_inline[8];     // the same index list as kernel arguments (isdf_optim_args.frame_avg_index_inline)
   // optional: loss sums mirrored into pinned host memory; caller-owned tail of the reduction message
   float* mailbox; float* extra; int n_extra, extra_slot; float extra_value;
 };
@@ -209,7 +210,7 @@ __device__ __forceinline__ void finalize_block(int block, const FinalizeArgs& a,
       a.la_out[f * 64 + tid] = v;
 #pragma unroll
       for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-      if (tid == 0) a.fa_out[a.fa_index ? a.fa_index[f] : f] = v / 64.f;
+      if (tid == 0) a.fa_out[a.fa_inline_n ? a.fa_inline[f] : (a.fa_index ? a.fa_index[f] : f)] = v / 64.f;
     }
   }
 }
@@ -252,7 +253,8 @@ __device__ __forceinline__ int64_t packed_elem(int row, int k, int Kp) {
 // loss.frame_avg (loss.py:208-240) of frame f from the (all-reduced) bins: 64 threads, one per 8x8 block
 __device__ __forceinline__ void frame_avg_block(int f, int t, const float* __restrict__ block_loss,
                                                 const float* __restrict__ block_cnt, float* __restrict__ loss_approx,
-                                                float* __restrict__ frame_avg, const int32_t* __restrict__ fa_index) {
+                                                float* __restrict__ frame_avg, const int32_t* __restrict__ fa_index,
+                                                int dst_inline = -1) {
   if (t >= 64) return;
   float c = block_cnt[f * 64 + t];
   c = c == 0.f ? 1.f : c;                      // loss.py:215
@@ -260,7 +262,7 @@ __device__ __forceinline__ void frame_avg_block(int f, int t, const float* __res
   loss_approx[f * 64 + t] = v;
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-  if (t == 0) frame_avg[fa_index ? fa_index[f] : f] = v / 64.f;         // loss.py:236-238
+  if (t == 0) frame_avg[dst_inline >= 0 ? dst_inline : (fa_index ? fa_index[f] : f)] = v / 64.f;         // loss.py:236-238
 }
 
 template <int PHASE>
@@ -272,7 +274,8 @@ __global__ __launch_bounds__(1024) void step_tail_kernel(const TailParams p) {
   if (b >= p.nW + p.nV) {
     if (PHASE != 2) finalize_block(b - p.nW - p.nV, p.fin, lds);
     else if (b - p.nW - p.nV < p.fin.n_frames)
-      frame_avg_block(b - p.nW - p.nV, threadIdx.x, p.fin.block_loss, p.fin.block_cnt, p.fin.la_out, p.fin.fa_out, p.fin.fa_index);
+      frame_avg_block(b - p.nW - p.nV, threadIdx.x, p.fin.block_loss, p.fin.block_cnt, p.fin.la_out, p.fin.fa_out, p.fin.fa_index,
+                      p.fin.fa_inline_n ? p.fin.fa_inline[b - p.nW - p.nV] : -1);
     else if ((int)threadIdx.x < 8 + p.fin.n_extra)   // last block of isdf_train_step_finish: the host's view of the reduced message
       p.fin.mailbox[threadIdx.x] = threadIdx.x < 8 ? p.fin.loss_sums[threadIdx.x] : p.fin.extra[threadIdx.x - 8];
     return;
@@ -445,8 +448,9 @@ int launch_pack(const NetLayout& L, const float* params, uint16_t* shadow, hipSt
 static FinalizeArgs finalize_args(const float* wg_loss, int64_t maxTiles, const int32_t* n_valid, int S, const float* tot_ws,
                                   const int64_t* ib, const int64_t* ih, const int64_t* iw, int F, int H, int W,
                                   float* loss_sums, float* bl, float* bc) {
-  FinalizeArgs a = {wg_loss, maxTiles, n_valid, S, tot_ws, ib, ih, iw, F, H, W, loss_sums, bl, bc, nullptr, nullptr, nullptr,
-                    nullptr, nullptr, 0, 0, 0.f};
+  FinalizeArgs a = {};
+  a.wg_loss = wg_loss; a.maxTiles = maxTiles; a.n_valid = n_valid; a.S = S; a.tot_ws = tot_ws; a.ib = ib; a.ih = ih; a.iw = iw;
+  a.n_frames = F; a.H = H; a.W = W; a.loss_sums = loss_sums; a.block_loss = bl; a.block_cnt = bc;
   return a;
 }
 // phase 0: params/m/v/shadow + optim scalars + finalize args; phase 1: grad + finalize args only;
@@ -456,7 +460,8 @@ int launch_step_tail(int phase, const NetLayout& L, const float* dwPart, const f
                      float eps, float wd, int step, const float* wg_loss, int64_t maxTiles, const int32_t* n_valid, int S,
                      const float* tot_ws, const int64_t* ib, const int64_t* ih, const int64_t* iw, int F, int H, int W,
                      float* loss_sums, float* bl, float* bc, float* la_out, float* fa_out, const int32_t* fa_index,
-                     hipStream_t st, float* mailbox, float* extra, int n_extra, int extra_slot, float extra_value, int part) {
+                     hipStream_t st, float* mailbox, float* extra, int n_extra, int extra_slot, float extra_value, int part,
+                     int fa_inline_n, const int32_t* fa_inline) {
   // part 0: everything in one launch.  Split tail (phase 1 only): part 1 = weight blocks of the dW units from the cat layer up +
   // vector section + finalisation (the message's suffix, isdf_reduce_split_floats), part 2 = the weight blocks below.
   TailParams p = {};
@@ -465,7 +470,11 @@ int launch_step_tail(int phase, const NetLayout& L, const float* dwPart, const f
   if (phase == 0)
     p.c = AdamwCoef{lr, b1, b2, eps, wd, 1.f - powf(b1, (float)step), sqrtf(1.f - powf(b2, (float)step))};
   p.fin = finalize_args(wg_loss, maxTiles, n_valid, S, tot_ws, ib, ih, iw, F, H, W, loss_sums, bl, bc);
-  if (la_out && fa_out) { p.fin.la_out = la_out; p.fin.fa_out = fa_out; p.fin.fa_index = fa_index; }
+  if (la_out && fa_out) {
+    p.fin.la_out = la_out; p.fin.fa_out = fa_out; p.fin.fa_index = fa_index;
+    p.fin.fa_inline_n = fa_inline_n;
+    for (int k = 0; k < fa_inline_n && k < 8; ++k) p.fin.fa_inline[k] = fa_inline[k];
+  }
   p.fin.mailbox = mailbox; p.fin.extra = extra; p.fin.n_extra = n_extra; p.fin.extra_slot = extra_slot; p.fin.extra_value = extra_value;
   const int64_t total = (int64_t)dw_units(L) * DW_BLK * DW_BLK;
   p.nW = (int)((total + 1023) / 1024);
@@ -491,8 +500,11 @@ int launch_adamw_pack(const NetLayout& L, float* params, float* m, float* v, uin
                       const float* count_ptr, float grad_scale, float lr, float b1, float b2, float eps, float wd,
                       int step, hipStream_t st, int n_frames = 0, const float* bl = nullptr, const float* bc = nullptr,
                       float* la = nullptr, float* fa = nullptr, const int32_t* fa_index = nullptr,
-                      const float* loss_sums = nullptr, const float* extra = nullptr, int n_extra = 0, float* mailbox = nullptr) {
+                      const float* loss_sums = nullptr, const float* extra = nullptr, int n_extra = 0, float* mailbox = nullptr,
+                      int fa_inline_n = 0, const int32_t* fa_inline = nullptr) {
   TailParams p = {};
+  p.fin.fa_inline_n = fa_inline_n;
+  for (int k = 0; k < fa_inline_n && k < 8; ++k) p.fin.fa_inline[k] = fa_inline[k];
   p.fin.block_loss = const_cast<float*>(bl); p.fin.block_cnt = const_cast<float*>(bc);
   p.fin.la_out = la; p.fin.fa_out = fa; p.fin.fa_index = fa_index; p.fin.n_frames = n_frames;
   p.fin.loss_sums = const_cast<float*>(loss_sums); p.fin.extra = const_cast<float*>(extra); p.fin.n_extra = n_extra;

@@ -43,6 +43,17 @@ __device__ __forceinline__ unsigned long long st_pack(uint32_t epoch, unsigned l
   return ((unsigned long long)(epoch & 0x3fffffffu) << 34) | (flag << 32) | v;
 }
 
+// window entry b of an index list: from the kernel arguments (a select chain over <= 8 values -- a per-lane index into a
+// kernel-argument array would compile to vector loads of the kernarg segment) or from the device array
+__device__ __forceinline__ int pick8(const int32_t (&v)[8], int b) {
+  int r = v[0];
+#pragma unroll
+  for (int k = 1; k < 8; ++k) r = b == k ? v[k] : r;
+  return r;
+}
+__device__ __forceinline__ int window_frame(const isdf_sample_args& a, int b) { return a.n_inline ? pick8(a.frame_idx_inline, b) : a.frame_idx[b]; }
+__device__ __forceinline__ int window_normal(const isdf_sample_args& a, int b) { return a.n_inline ? pick8(a.normal_idx_inline, b) : a.normal_idx[b]; }
+
 // validity of drawn ray r (the pixel draw and the two gathers of sample.py:11-55) -- what decides the compaction
 __device__ __forceinline__ bool ray_valid(const isdf_sample_args& a, int r) {
   const int b = r / a.n_rays;
@@ -50,10 +61,10 @@ __device__ __forceinline__ bool ray_valid(const isdf_sample_args& a, int r) {
   if (a.rng_mode == 0) { h = (int)a.draw_h[r]; wq = (int)a.draw_w[r]; }
   else { const uint4 u = ray_random(a, (uint32_t)r, 0u); h = (int)(u.x % (uint32_t)a.H); wq = (int)(u.y % (uint32_t)a.W); }
   const int64_t pix = (int64_t)h * a.W + wq;
-  const float d = a.depth_batch[(int64_t)a.frame_idx[b] * a.H * a.W + pix];
+  const float d = a.depth_batch[(int64_t)window_frame(a, b) * a.H * a.W + pix];
   bool valid = d != 0.f;
   if (a.normal_batch) {
-    const float n0 = a.normal_batch[((int64_t)a.normal_idx[b] * a.H * a.W + pix) * 3];
+    const float n0 = a.normal_batch[((int64_t)window_normal(a, b) * a.H * a.W + pix) * 3];
     valid = valid && !(n0 != n0);
   }
   return valid;
@@ -74,10 +85,11 @@ __global__ __launch_bounds__(SMP_NT) void sample_rays_kernel(const isdf_sample_a
   __shared__ int sChunk, sBase;
   __shared__ uint32_t sEpoch;
   __shared__ int sPre[NW], sWaveCnt[NW];
-  // (the pad keeps the streaming instantiation at 82 KB of LDS = ONE 16-wave workgroup per CU; seven floats per ray fit two, which
+  // (the pad keeps the streaming instantiation above 80 KB of LDS = ONE 16-wave workgroup per CU; seven floats per ray fit two, which
   //  measured SLOWER: 1e6 rays 0.203 vs 0.198 ms, 1e7 rays 1.78 vs 1.61 ms -- more gathers and look-back polls in flight, same HBM)
   __shared__ float sRay[CHUNK][8];   // depth, origin xyz, dirs_W xyz, pad  (compacted order within the chunk)
   __shared__ __attribute__((aligned(16))) float sPc[NW][768];   // a wave's 256 world points, staged for 16-byte stores
+  __shared__ __attribute__((aligned(16))) float sZ[NW][256];    // ... and their 256 z values
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   unsigned long long* state = (unsigned long long*)(ws + 4);
   const int total = a.n_frames * a.n_rays;
@@ -108,8 +120,8 @@ __global__ __launch_bounds__(SMP_NT) void sample_rays_kernel(const isdf_sample_a
       if (a.rng_mode == 0) { h = (int)a.draw_h[r]; wq = (int)a.draw_w[r]; }
       else { const uint4 u = ray_random(a, (uint32_t)r, 0u); h = (int)(u.x % (uint32_t)a.H); wq = (int)(u.y % (uint32_t)a.W); }
       const int64_t pix = (int64_t)h * a.W + wq;
-      const int fi = a.frame_idx[b];
-      const float* np = a.normal_batch ? a.normal_batch + ((int64_t)a.normal_idx[b] * a.H * a.W + pix) * 3 : nullptr;
+      const int fi = window_frame(a, b);
+      const float* np = a.normal_batch ? a.normal_batch + ((int64_t)window_normal(a, b) * a.H * a.W + pix) * 3 : nullptr;
       d = a.depth_batch[(int64_t)fi * a.H * a.W + pix];       // both gathers in flight together ...
       if (np) { n0 = np[0]; n1 = np[1]; n2 = np[2]; }
       T += (int64_t)fi * 16;
@@ -262,7 +274,8 @@ __global__ __launch_bounds__(SMP_NT) void sample_rays_kernel(const isdf_sample_a
       z = __fadd_rn(lim, __fmul_rn(U, blen));                       // sample.py:123-126
     }
     const int64_t n = r * S + s;
-    o.z_vals[n] = z;
+    if (fullGroup) sZ[wv][m * 64 + lane] = z;
+    else o.z_vals[n] = z;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {  // pc = origins + dirs_W * z, sample.py:176
       const float v = __fadd_rn(sr[1 + i], __fmul_rn(sr[4 + i], z));
@@ -280,6 +293,8 @@ __global__ __launch_bounds__(SMP_NT) void sample_rays_kernel(const isdf_sample_a
         const float4 v = *(const float4*)&sPc[wv][(k * 64 + lane) * 4];
         *(f4u*)(dst + (k * 64 + lane) * 4) = f4u{v.x, v.y, v.z, v.w};
       }
+      const float4 zv = *(const float4*)&sZ[wv][lane * 4];     // the group's z values: one 16-byte store per lane instead of four
+      *(f4u*)(o.z_vals + (int64_t)base * S + (int64_t)G * 256 + lane * 4) = f4u{zv.x, zv.y, zv.z, zv.w};   // 4-byte ones
       __builtin_amdgcn_wave_barrier();   // the next group of this wave overwrites sPc
     }
   }

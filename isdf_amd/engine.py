@@ -218,9 +218,16 @@ class Engine:
     def sample(self, depth_batch, T_WC_batch, normal_batch, frame_idx, normal_idx, sc: SampleConfig,
                draws=None, seed=0, offset=0, want_T=False, reuse=False):
         """The sampler (one launch).  draws: dict(indices_h, indices_w, U, N_off)
-        of device tensors in the reference's shapes (parity mode) or None (Philox)."""
+        of device tensors in the reference's shapes (parity mode) or None (Philox).
+        frame_idx / normal_idx: int32 device tensors [F], or -- the step loop's form -- tuples of <= 8 Python ints, which
+        travel as kernel arguments (isdf_sample_args.n_inline): a window that `select_keyframes` re-draws on the host every
+        step then costs no device copy and no new call plan."""
         dev = self.device
-        F = int(frame_idx.numel())
+        inline = isinstance(frame_idx, (tuple, list))
+        if inline and (len(frame_idx) > _ffi.MAX_INLINE_FRAMES or
+                       (normal_batch is not None and (normal_idx is None or len(normal_idx) != len(frame_idx)))):
+            raise ValueError("inline windows hold up to %d keyframes (with one normal index each)" % _ffi.MAX_INLINE_FRAMES)
+        F = len(frame_idx) if inline else int(frame_idx.numel())
         R0 = F * sc.n_rays
         S = sc.S
         key = (R0, S, bool(want_T), normal_batch is not None)
@@ -239,19 +246,30 @@ class Engine:
             # per step was a third of it.  Valid while the same input tensors / configuration come back.
             plan = ring[3][slot]
             pkey = (depth_batch.data_ptr(), T_WC_batch.data_ptr(), 0 if normal_batch is None else normal_batch.data_ptr(),
-                    frame_idx.data_ptr(), 0 if normal_idx is None else normal_idx.data_ptr(), sc.n_rays, sc.H, sc.W,
+                    -1 if inline else frame_idx.data_ptr(),
+                    -1 if inline else (0 if normal_idx is None else normal_idx.data_ptr()), sc.n_rays, sc.H, sc.W,
                     sc.fx, sc.fy, sc.cx, sc.cy, sc.n_strat, sc.n_surf, sc.min_depth, sc.dist_behind_surf)
             if draws is None and plan is not None and plan[0] == pkey:
                 _, a, o, out = plan
                 a.seed, a.offset = int(seed), int(offset)
+                if inline:
+                    a.frame_idx_inline[:F] = frame_idx
+                    if normal_idx is not None:
+                        a.normal_idx_inline[:F] = normal_idx
                 _ffi.check(self.lib.isdf_sample_rays(C.byref(a), C.byref(o), self._scan_ptr, self._scan_ws.numel(),
                                                      _stream(self.device)), "isdf_sample_rays")
                 return dict(out)
         a = _ffi.SampleArgs()
         a.depth_batch, a.T_WC_batch = depth_batch.data_ptr(), T_WC_batch.data_ptr()
         a.normal_batch = None if normal_batch is None else normal_batch.data_ptr()
-        a.frame_idx = frame_idx.data_ptr()
-        a.normal_idx = None if normal_idx is None else normal_idx.data_ptr()
+        if inline:
+            a.n_inline = F
+            a.frame_idx_inline[:F] = [int(v) for v in frame_idx]
+            if normal_idx is not None:
+                a.normal_idx_inline[:F] = [int(v) for v in normal_idx]
+        else:
+            a.frame_idx = frame_idx.data_ptr()
+            a.normal_idx = None if normal_idx is None else normal_idx.data_ptr()
         a.n_frames, a.n_rays, a.H, a.W = F, sc.n_rays, sc.H, sc.W
         a.fx, a.fy, a.cx, a.cy = sc.fx, sc.fy, sc.cx, sc.cy
         a.n_strat, a.n_surf = sc.n_strat, sc.n_surf
@@ -347,12 +365,13 @@ class Engine:
                 and lc.bounds_method == "ray"):
             fo = None if optim is None else optim.get("frame_avg_out")
             fi = None if optim is None else optim.get("frame_avg_index")
+            fi_inline = isinstance(fi, (tuple, list))
             ns = smp.get("norm_sample")
             plan_key = (smp["_slot"], smp["pc"].data_ptr(), smp["n_valid"].data_ptr(), smp["indices_b"].data_ptr(),
                         smp["z_vals"].data_ptr(), 0 if ns is None else ns.data_ptr(),
                         R0, S, F, sc.H, sc.W, lc.loss_type, lc.trunc_weight, lc.trunc_distance,
                         lc.eik_weight, lc.eik_apply_dist, lc.grad_weight, lc.orien_loss, optim is None,
-                        0 if fo is None else fo.data_ptr(), 0 if fi is None else fi.data_ptr(), self.reduce_extra,
+                        0 if fo is None else fo.data_ptr(), 0 if fi is None else (-1 if fi_inline else fi.data_ptr()), self.reduce_extra,
                         0 if split_event is None else split_event.cuda_event,
                         None if self.reduce_buf is None else self.reduce_buf.data_ptr(), None if self._ws is None else self._ws.data_ptr())
             plan = self._step_plans.get(smp["_slot"])
@@ -366,6 +385,8 @@ class Engine:
                     q.lr, q.weight_decay = float(optim.get("lr", 0.0013)), float(optim.get("weight_decay", 0.012))
                     q.beta1, q.beta2, q.eps = float(betas[0]), float(betas[1]), float(optim.get("eps", 1e-8))
                     q.grad_scale, q.step = float(optim.get("grad_scale", 1.0)), int(self.opt_step)
+                    if fi_inline:
+                        q.frame_avg_index_inline[:F] = fi
                     _ffi.check(self.lib.isdf_train_step_adamw(C.byref(self.cnet), C.byref(closs), C.byref(a), C.byref(o),
                                                               C.byref(q), self._ws_ptr, ws.numel(), _stream(self.device)),
                                "isdf_train_step_adamw")
@@ -469,9 +490,14 @@ class Engine:
             la = torch.empty(F, 8, 8, dtype=torch.float32, device=self.device)
             fa_out, fa_idx = optim["frame_avg_out"], optim.get("frame_avg_index")
             assert fa_out.dtype == torch.float32 and fa_out.is_contiguous()
-            assert fa_idx is None or (fa_idx.dtype == torch.int32 and fa_idx.numel() == F)
             q.loss_approx, q.frame_avg = la.data_ptr(), fa_out.data_ptr()
-            q.frame_avg_index = None if fa_idx is None else fa_idx.data_ptr()
+            if isinstance(fa_idx, (tuple, list)):     # the window as kernel arguments (isdf_optim_args.frame_avg_index_inline)
+                assert len(fa_idx) == F <= _ffi.MAX_INLINE_FRAMES
+                q.frame_avg_inline_n = F
+                q.frame_avg_index_inline[:F] = [int(v) for v in fa_idx]
+            else:
+                assert fa_idx is None or (fa_idx.dtype == torch.int32 and fa_idx.numel() == F)
+                q.frame_avg_index = None if fa_idx is None else fa_idx.data_ptr()
             dbg["loss_approx"] = la
             keep += [fa_out, fa_idx]
         return q
@@ -481,8 +507,9 @@ class Engine:
         operand repack and -- with optim["frame_avg_out"] -- loss.frame_avg from the reduced bins, ONE launch."""
         dbg, keep = {}, []
         fo, fi = optim.get("frame_avg_out"), optim.get("frame_avg_index")
-        fkey = (n_frames, 0 if fo is None else fo.data_ptr(), 0 if fi is None else fi.data_ptr(), self.reduce_buf.data_ptr(),
-                self.mailbox.data_ptr(), self.reduce_extra)
+        fi_inline = isinstance(fi, (tuple, list))
+        fkey = (n_frames, 0 if fo is None else fo.data_ptr(), 0 if fi is None else (-1 if fi_inline else fi.data_ptr()),
+                self.reduce_buf.data_ptr(), self.mailbox.data_ptr(), self.reduce_extra)
         plan = self._step_plans.get("finish")
         if plan is not None and plan[0] == fkey:      # same buffers as the last call: reuse the struct, bump the scalars
             _, q, dbg = plan
@@ -491,6 +518,8 @@ class Engine:
             q.lr, q.weight_decay = float(optim.get("lr", 0.0013)), float(optim.get("weight_decay", 0.012))
             q.beta1, q.beta2, q.eps = float(betas[0]), float(betas[1]), float(optim.get("eps", 1e-8))
             q.grad_scale, q.step = float(optim.get("grad_scale", 1.0)), int(self.opt_step)
+            if fi_inline:
+                q.frame_avg_index_inline[:n_frames] = fi
         else:
             q = self._optim_args(optim, n_frames, dbg, keep)
             dbg["_keep"] = keep
@@ -509,6 +538,8 @@ class Engine:
         return self.reduce_buf[self.n_params:self.n_params + 8]
 
     def frame_avg(self, n_frames, out=None, index=None):
+        if isinstance(index, (tuple, list)):
+            index = torch.as_tensor([int(v) for v in index], dtype=torch.int32, device=self.device)
         """loss.frame_avg from the (reduced) bins.  out/index: write frame f's average to out[index[f]] (the
         keyframe store's frame_avg_losses and the window's keyframe ids) instead of a fresh [F] tensor."""
         la = torch.empty(n_frames, 8, 8, dtype=torch.float32, device=self.device)

@@ -17,8 +17,8 @@ with the `torch.optim.AdamW` surface.  Everything else (`get_data`, `add_frame`,
 `check_keyframe_latest`, `select_keyframes`, evaluation, visualisation) keeps running as the
 reference's own code on the same object.
 
-Where the reference is not importable (the GPU box, bench.py), `isdf_amd.standin.StandinTrainer` provides
-the driver-side methods and `isdf_amd.trainer.HipTrainer` is `graft()` applied to it -- the same code path.
+Where the reference is not importable (the GPU box, bench.py), `tests/standin_trainer.py` (test / bench infrastructure, outside
+this package) restates the driver-side methods; its `HipTrainer` is `graft()` applied to that stand-in -- the same code path.
 
 There is no CPU fallback: without the HIP library or a HIP device `graft` raises.
 """
@@ -193,14 +193,17 @@ class HotPath:
         must reach the same decision)."""
         eng, hip = self.engine, self._hip
         if hip.rng == "torch":
+            as_t = lambda ix: torch.as_tensor(list(ix), dtype=torch.long, device=hip.device) if isinstance(ix, (tuple, list)) else ix.long()
+            fi_t, ni_t = as_t(frame_idx), (None if normal_idx is None else as_t(normal_idx))
+
             def n_valid(ih, iw):   # the reference learns R from its boolean-mask compaction (a sync)
-                ib = torch.arange(frame_idx.numel(), device=ih.device).repeat_interleave(sc.n_rays)
-                d = depth_batch[frame_idx.long()[ib], ih, iw]
+                ib = torch.arange(fi_t.numel(), device=ih.device).repeat_interleave(sc.n_rays)
+                d = depth_batch[fi_t[ib], ih, iw]
                 ok = d != 0
                 if norm_batch is not None:
-                    ok &= ~torch.isnan(norm_batch[normal_idx.long()[ib], ih, iw, 0])
+                    ok &= ~torch.isnan(norm_batch[ni_t[ib], ih, iw, 0])
                 return int(ok.sum().item())
-            draws = self._draws_torch(frame_idx.numel(), sc, n_valid)
+            draws = self._draws_torch(fi_t.numel(), sc, n_valid)
             return eng.sample(depth_batch, T_WC_batch, norm_batch, frame_idx, normal_idx, sc, draws=draws,
                               want_T=want_T, reuse=reuse)
         hip.draw_count += 1
@@ -350,15 +353,21 @@ class HotPath:
         else:
             idxs = np.arange(K)
         self.active_idxs = idxs
-        # device copies of the window indices are cached while the window does not change
-        key = (tuple(int(i) for i in idxs), bool(hip.fix_normal_window))
-        if hip.idx_cache is None or hip.idx_cache[0] != key:
-            fidx = torch.as_tensor(np.asarray(idxs), dtype=torch.int32, device=hip.device)
+        # The window: up to 8 keyframes travel INLINE as kernel arguments (sampler, step tail) -- select_keyframes re-draws it on
+        # the host every step once K > window_size, and a device copy per step (two H2D copies + new call plans) cost ~80 us of
+        # the synchronised step in that regime.  Longer windows (non-incremental runs over many frames) use cached device tensors.
+        if len(idxs) <= _ffi.MAX_INLINE_FRAMES:
+            fidx = tuple(int(i) for i in idxs)
             # reference quirk q4: normals are read from the UN-windowed normal_batch with
             # window-local indices (trainer.py:956,969); fix_normal_window=True uses idxs.
-            nidx = fidx if hip.fix_normal_window else torch.arange(len(idxs), dtype=torch.int32, device=hip.device)
-            hip.idx_cache = (key, fidx, nidx)
-        _, fidx, nidx = hip.idx_cache
+            nidx = fidx if hip.fix_normal_window else tuple(range(len(fidx)))
+        else:
+            key = (tuple(int(i) for i in idxs), bool(hip.fix_normal_window))
+            if hip.idx_cache is None or hip.idx_cache[0] != key:
+                fidx = torch.as_tensor(np.asarray(idxs), dtype=torch.int32, device=hip.device)
+                nidx = fidx if hip.fix_normal_window else torch.arange(len(idxs), dtype=torch.int32, device=hip.device)
+                hip.idx_cache = (key, fidx, nidx)
+            _, fidx, nidx = hip.idx_cache
         norm_batch = self.frames.normal_batch if self.do_normal else None
         sc = self._sample_cfg()
         # no depth_batch[idxs] copy (trainer.py:965: 16 MB at 680x1200x5): the sampler takes the window indices
@@ -383,7 +392,7 @@ class HotPath:
                     eng.frame_avg(len(idxs), out=fal, index=fidx)
                 else:
                     _, fa = eng.frame_avg(len(idxs))
-                    self.frames.frame_avg_losses[fidx.long()] = fa      # trainer.py:979
+                    self.frames.frame_avg_losses[[int(i) for i in idxs]] = fa      # trainer.py:979
             if not fused:
                 self.optimiser.step()                  # AdamW on the (all-reduced) gradient sums
         # `losses`: the step's last launch stored the (reduced) loss sums -- and, data parallel, the ranks' step times -- in

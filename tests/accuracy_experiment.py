@@ -103,7 +103,7 @@ DEVICE = "cpu"           # --device: where the port backend runs ("cuda" = PyTor
 
 
 def run_hip(seed, depth, normal, T, cam, steps_per_kf):
-    from isdf_amd.trainer import HipTrainer, FrameData
+    from tests.standin_trainer import HipTrainer, FrameData
     np.random.seed(seed); torch.manual_seed(seed)
     tr = HipTrainer("cuda", config(cam), inv_bounds_transform=synthetic.bounds_transform(), rng="torch" if PAIRED else "philox",
                     seed=seed, fwd_operand=FWD_OPERAND)
@@ -135,7 +135,7 @@ def run_hip_reference_schedule(seed, cam, n_steps=1200, virtual_step_ms=20.0, n_
     int(tot_step_time * fps) (trainer.py:100).  The virtual clock advances by `virtual_step_ms` per step
     (pinned) instead of the measured step time so the schedule is reproducible."""
     import contextlib, io
-    from isdf_amd.trainer import HipTrainer
+    from tests.standin_trainer import HipTrainer
     from tests.driver_loop import run_train_loop
     np.random.seed(seed); torch.manual_seed(seed)
     tr = HipTrainer("cuda", config(cam), inv_bounds_transform=synthetic.bounds_transform(), rng="philox", seed=seed,
@@ -333,7 +333,7 @@ def run_native_clock(backend, seed, stream, max_steps, extra_opt_steps=400, eval
     cam = stream.cam
     np.random.seed(seed); torch.manual_seed(seed)
     if backend == "hip":
-        from isdf_amd.trainer import HipTrainer
+        from tests.standin_trainer import HipTrainer
         tr = HipTrainer("cuda", config(cam), inv_bounds_transform=synthetic.bounds_transform(), rng="philox", seed=seed,
                         fwd_operand=FWD_OPERAND, virtual_step_ms=virtual_step_ms)
         sdf_fn = lambda p: tr.sdf_map(p)

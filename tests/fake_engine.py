@@ -9,6 +9,10 @@ import torch
 import oracle.isdf_oracle as orc
 
 
+def _as_index(ix):
+    return [int(v) for v in ix] if isinstance(ix, (tuple, list)) else ix.long()
+
+
 class FakeEngine:
     def __init__(self, net, device="cpu"):
         self.net, self.device = net, torch.device("cpu")
@@ -49,6 +53,9 @@ class FakeEngine:
     # ---- sampler (capacity-sized outputs, rows >= n_valid undefined)
     def sample(self, depth_batch, T_WC_batch, normal_batch, frame_idx, normal_idx, sc, draws=None, seed=0, offset=0,
                want_T=False, reuse=False):
+        if isinstance(frame_idx, (tuple, list)):       # the step loop passes the window inline (engine.Engine.sample)
+            frame_idx = torch.as_tensor(list(frame_idx), dtype=torch.int32)
+            normal_idx = None if normal_idx is None else torch.as_tensor(list(normal_idx), dtype=torch.int32)
         F = int(frame_idx.numel())
         R0, S = F * sc.n_rays, sc.S
         fi = frame_idx.long().numpy()
@@ -132,7 +139,7 @@ class FakeEngine:
         dbg = {}
         if optim is not None:
             if optim.get("frame_avg_out") is not None:
-                optim["frame_avg_out"][optim["frame_avg_index"].long()] = self._fa
+                optim["frame_avg_out"][_as_index(optim["frame_avg_index"])] = self._fa
                 dbg["loss_approx"] = self._la
             self.adamw(lr=optim.get("lr", 0.0013), weight_decay=optim.get("weight_decay", 0.012),
                        betas=optim.get("betas", (0.9, 0.999)), eps=optim.get("eps", 1e-8))
@@ -146,7 +153,7 @@ class FakeEngine:
         bc[bc == 0] = 1.0
         la = bl / bc
         if optim.get("frame_avg_out") is not None:
-            optim["frame_avg_out"][optim["frame_avg_index"].long()] = la.sum(1) / 64.0
+            optim["frame_avg_out"][_as_index(optim["frame_avg_index"])] = la.sum(1) / 64.0
         self.adamw(lr=optim.get("lr", 0.0013), weight_decay=optim.get("weight_decay", 0.012),
                    betas=optim.get("betas", (0.9, 0.999)), eps=optim.get("eps", 1e-8))
         self.calls.append("train_step_finish")

@@ -1,19 +1,21 @@
-"""Stand-in for the DRIVER side of the reference `Trainer` (`isdf/modules/trainer.py`) on hosts where the
-reference itself is not importable (the GPU box has no /root/reference; bench.py and the `-m gpu` tests run
-there).  It holds exactly the methods of the reference class that the hot path does NOT replace but that the
-drivers' frame-scheduling loop calls (train.py:102-136):
+"""TEST / BENCH INFRASTRUCTURE -- not part of the product package.
+
+Stand-in for the DRIVER side of the reference `Trainer` (`isdf/modules/trainer.py`) on hosts where the reference itself is not
+importable (the GPU box has no /root/reference; bench.py and the `-m gpu` tests run there).  It restates exactly the methods of
+the reference class that the hot path does NOT replace but that the drivers' frame-scheduling loop calls (train.py:102-136):
 
     __init__ / set_params      trainer.py:35-96,157-333   (hot-path subset of the JSON schema)
     get_latest_frame_id        trainer.py:100-101
     add_data / add_frame       trainer.py:564-582
     check_keyframe_latest      trainer.py:622-650
     select_keyframes           trainer.py:652-674
-    FrameData                  isdf/datasets/data_util.py:11-102
 
-with the reference's attribute names, so that `isdf_amd.hot_path.graft()` -- the product's only binding --
-treats it exactly like a reference `Trainer` instance.  Where the reference IS importable, graft the real
-`Trainer` instead; nothing here is needed then.  `step`, `sample_points`,
-`sdf_eval_and_loss`, `is_keyframe` are deliberately absent: they exist only as HIP kernels (hot_path.HotPath).
+with the reference's attribute names, so that `isdf_amd.hot_path.graft()` -- the product's only binding -- treats it exactly like
+a reference `Trainer` instance.  Where the reference IS importable, graft the real `Trainer` instead (INTEGRATION.md,
+tests/test_graft_reference.py); nothing here is needed then.  `step`, `sample_points`, `sdf_eval_and_loss`, `is_keyframe` are
+deliberately absent: they exist only as HIP kernels (hot_path.HotPath).
+
+    HipTrainer(device, config, ...)  ==  graft(StandinTrainer(device, config, ...), ...)
 """
 import copy
 import json
@@ -21,82 +23,9 @@ import json
 import numpy as np
 import torch
 
-from .hot_path import FlatAdamW
-from .modules import PositionalEncodingHIP, SDFMapHIP
-
-_FIELDS = ("frame_id", "im_batch", "im_batch_np", "depth_batch", "depth_batch_np", "T_WC_batch", "T_WC_batch_np",
-           "normal_batch", "frame_avg_losses", "T_WC_track", "T_WC_gt")
-
-
-class FrameData:
-    """Keyframe store (`data_util.FrameData`, isdf/datasets/data_util.py:11-81): same fields and the same
-    `add_frame_data(data, replace)` contract (append, or overwrite the last slot when the previous frame was
-    not promoted to a keyframe), but the device batches live in pre-allocated buffers that grow
-    geometrically instead of being re-built with `torch.cat` on every frame (data_util.py:84-102 copies the
-    whole keyframe set -- ~13 MB per keyframe at 680x1200 -- each time a frame arrives).
-    The public attributes stay plain tensors: views of the first len(self) rows of the backing buffers.
-    Accepts the reference's own FrameData objects as `data` (same attribute names)."""
-
-    def __init__(self, frame_id=None, im_batch=None, im_batch_np=None, depth_batch=None, depth_batch_np=None,
-                 T_WC_batch=None, T_WC_batch_np=None, normal_batch=None, frame_avg_losses=None, T_WC_track=None,
-                 T_WC_gt=None):
-        self.frame_id = frame_id
-        self.im_batch, self.im_batch_np = im_batch, im_batch_np
-        self.depth_batch, self.depth_batch_np = depth_batch, depth_batch_np
-        self.T_WC_batch, self.T_WC_batch_np = T_WC_batch, T_WC_batch_np
-        self.normal_batch = normal_batch
-        self.frame_avg_losses = frame_avg_losses
-        self.T_WC_track, self.T_WC_gt = T_WC_track, T_WC_gt
-        self._back = {}          # field name -> backing tensor (capacity >= len)
-
-    def __len__(self):
-        return 0 if self.frame_id is None else len(self.frame_id)
-
-    def __deepcopy__(self, memo):   # snapshots carry only the live rows
-        out = FrameData()
-        for k in _FIELDS:
-            v = getattr(self, k, None)
-            setattr(out, k, None if v is None else (v.copy() if isinstance(v, np.ndarray) else v.clone()))
-        return out
-
-    def _expand(self, name, batch, data, replace):
-        if data is None:
-            return batch
-        if batch is None:
-            if isinstance(data, np.ndarray):
-                return data
-            batch = data[:0]
-        elif replace:
-            batch[-1] = data[0]
-            return batch
-        if isinstance(data, np.ndarray):     # host twins / frame ids
-            return np.concatenate((batch, data))
-        n, k = batch.shape[0], data.shape[0]
-        back = getattr(self, "_back", None)
-        if back is None:
-            back = self._back = {}
-        buf = back.get(name)
-        if (buf is None or buf.data_ptr() != batch.data_ptr() or buf.shape[0] < n + k or buf.dtype != data.dtype
-                or buf.device != data.device or buf.shape[1:] != data.shape[1:]):
-            cap = max(2 * (n + k), 8)        # geometric growth: amortised O(1) copies per keyframe
-            buf = torch.empty((cap,) + tuple(data.shape[1:]), dtype=data.dtype, device=data.device)
-            if n:
-                buf[:n] = batch
-            back[name] = buf
-        buf[n:n + k] = data
-        return buf[:n + k]
-
-    def add_frame_data(self, data, replace):
-        """data_util.py:45-78"""
-        n_new = len(data)
-        for k in _FIELDS:
-            if k == "frame_avg_losses":
-                continue
-            if k == "T_WC_gt" and getattr(data, k, None) is None:
-                continue
-            setattr(self, k, self._expand(k, getattr(self, k, None), getattr(data, k, None), replace))
-        empty = torch.zeros([n_new], device=data.depth_batch.device)
-        self.frame_avg_losses = self._expand("frame_avg_losses", self.frame_avg_losses, empty, replace)
+from isdf_amd.frame_store import FrameData
+from isdf_amd.hot_path import FlatAdamW, HotPath, StepLosses, graft      # noqa: F401
+from isdf_amd.modules import PositionalEncodingHIP, SDFMapHIP
 
 
 class StandinTrainer:
@@ -241,3 +170,25 @@ class StandinTrainer:
         rand_ints = np.random.choice(np.arange(0, limit), size=self.window_size - 2, replace=False, p=loss_dist)
         last = n_frames - 1
         return [*rand_ints, last - 1, last]
+
+
+class HipTrainer(HotPath, StandinTrainer):
+    def __init__(self, device, config, incremental=True, inv_bounds_transform=None, rng="philox",
+                 seed=1, dist_group=None, fix_normal_window=False, fwd_operand="fp16x2", virtual_step_ms=None,
+                 engine_factory=None, overlap_allreduce=False):
+        """config: path to / dict with the reference's JSON schema (replicaCAD.json).
+        rng: "philox" (in-kernel, no host sync) or "torch" (draw with torch in the
+        reference's order and shapes -- parity mode, one host sync per step)."""
+        self._hip = None
+        StandinTrainer.__init__(self, device, config, None, incremental, inv_bounds_transform=inv_bounds_transform,
+                                fwd_operand=fwd_operand, engine_factory=engine_factory)
+        graft(self, rng=rng, seed=seed, dist_group=dist_group, fix_normal_window=fix_normal_window,
+              fwd_operand=fwd_operand, virtual_step_ms=virtual_step_ms, engine_factory=engine_factory,
+              overlap_allreduce=overlap_allreduce)
+
+    # aliases kept for checkpoint files / callers of round 1
+    def state_dict(self):
+        return self.hip_state_dict()
+
+    def load_state_dict(self, sd):
+        return self.load_hip_state_dict(sd)

@@ -80,3 +80,28 @@ def test_engine_refuses_cpu():
     from isdf_amd.engine import Engine, NetConfig
     with pytest.raises(_ffi.IsdfError):
         Engine(NetConfig(), "cpu")
+
+
+def test_ctypes_structs_match_the_header_layout(tmp_path):
+    """sizeof / offsetof of every struct that crosses the boundary, as gcc lays out include/isdf_hip.h, against the ctypes
+    mirrors in isdf_amd/_ffi.py (a silent mismatch would hand the kernels shifted pointers)"""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    structs = {"isdf_net_cfg": _ffi.NetCfg, "isdf_sample_args": _ffi.SampleArgs, "isdf_sample_out": _ffi.SampleOut,
+               "isdf_loss_cfg": _ffi.LossCfg, "isdf_step_args": _ffi.StepArgs, "isdf_step_out": _ffi.StepOut,
+               "isdf_optim_args": _ffi.OptimArgs}
+    last = {"isdf_net_cfg": "fwd_operand", "isdf_sample_args": "n_inline", "isdf_sample_out": "pc", "isdf_loss_cfg": "orien_loss",
+            "isdf_step_args": "extra_value", "isdf_step_out": "split_event", "isdf_optim_args": "frame_avg_inline_n"}
+    src = ['#include <stdio.h>', '#include <stddef.h>', '#include "isdf_hip.h"', 'int main(void) {']
+    for name in structs:
+        src.append('  printf("%s %%zu %%zu\\n", sizeof(%s), offsetof(%s, %s));' % (name, name, name, last[name]))
+    src += ['  return 0;', '}']
+    c = tmp_path / "sizes.c"
+    c.write_text("\n".join(src))
+    exe = tmp_path / "sizes"
+    subprocess.check_call(["gcc", "-I", os.path.join(root, "include"), str(c), "-o", str(exe)])
+    for line in subprocess.check_output([str(exe)], text=True).splitlines():
+        name, size, off = line.split()
+        ct = structs[name]
+        assert C.sizeof(ct) == int(size), (name, C.sizeof(ct), size)
+        assert getattr(ct, last[name]).offset == int(off), (name, last[name])

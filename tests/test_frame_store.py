@@ -5,7 +5,7 @@ import copy
 import numpy as np
 import torch
 
-from isdf_amd.trainer import FrameData
+from isdf_amd.frame_store import FrameData
 
 
 def _frame(i, H=6, W=8):

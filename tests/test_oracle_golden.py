@@ -298,7 +298,13 @@ def test_oracle_trajectory_from_trained_state():
         for a, r in zip(got, ref):
             assert abs(a - r) < (1e-4 if s < 12 else 2e-2) * abs(r), (s, got, ref)
         orc.adamw_step(params, grads, state)
-    upd = np.concatenate([(params[k] - theta0[k]).ravel() for k in params]).astype(np.float64)
-    ref = np.concatenate([g["traj/update/" + k].astype(np.float64).ravel() for k in params])
-    assert gu.rel_err(upd, ref) < 2e-2, gu.rel_err(upd, ref)
-    assert abs(gu.signed_projection(upd, ref)) < 2e-3, gu.signed_projection(upd, ref)
+        if s + 1 == 5:
+            upd = np.concatenate([(params[k] - theta0[k]).ravel() for k in params]).astype(np.float64)
+            ref5 = np.concatenate([g["traj/update5/" + k].astype(np.float64).ravel() for k in params])
+            assert gu.rel_err(upd, ref5) < 2e-3, gu.rel_err(upd, ref5)          # (the fixture stores the update as float16: 3e-4)
+            assert abs(gu.signed_projection(upd, ref5)) < 2e-4, gu.signed_projection(upd, ref5)
+    # after all 20 steps only the size of the update is compared: the direction is chaos-dominated by then
+    prng = np.random.RandomState(4321)
+    for k in params:
+        nrm = g["traj/update_dig/" + k][0]
+        assert abs(np.linalg.norm((params[k] - theta0[k]).astype(np.float64)) - nrm) < 5e-2 * nrm, k

@@ -4,6 +4,8 @@
 #              distribution of a native-clock run, 30 more seeds of the accuracy control
 #   ab2        full GPU suite on the ABI-5 tree, the fixed bias-LDS variant (parity subset + same-box A/B), PAIRED accuracy runs
 #              (identical random streams and initial network, HIP vs fp32 eager), data-parallel bench modes on one GPU
+#   final      full GPU suite, end-of-round records (tools/round_records.sh 04), native-clock run of the final host path,
+#              accuracy by forward operand mode (40 seeds each)
 #   accuracy   fp32 eager-GPU control vs the HIP path (HEAD and the reverted d490710 variant) on 10 shared seeds, the
 #              trained-weights gradient-bias probe for both libraries, reference-driver schedule and native-clock runs
 # Outputs land in gpurun_out/r04/ (scratch); what is judged is copied to profiles/ by hand.
@@ -93,4 +95,19 @@ except Exception as e:
 PY
   done
   tail -n 2 $O/acc_paired_hip.log $O/acc_paired_control.log
+fi
+
+if [ "$stage" = final ]; then
+  python -m pytest tests -q -m gpu -s > $O/pytest_gpu_final.log 2>&1; lap pytest gpu
+  bash tools/round_records.sh 04 > $O/round_records.log 2>&1; lap records
+  cd $GRAFT_REPO_ROOT
+  python tests/accuracy_experiment.py --native-clock --backend hip --seeds $SEEDS5 --out $O/native_clock_hip_final.json > $O/native_clock_hip_final.log 2>&1; lap native hip
+  for m in fp16x2_full bf16; do
+    python tests/accuracy_experiment.py --backend hip --seeds $(seq 1 40) --keyframes 24 --steps-per-kf 100 --fwd-operand $m \
+        --out $O/acc_hip_24x100_$m.json > $O/acc_hip_24x100_$m.log 2>&1; lap accuracy $m
+  done
+  tail -n 8 $O/pytest_gpu_final.log
+  grep -h "trained-weights eval\|worst tensor\|trained-state" $O/pytest_gpu_final.log | cut -c1-1100
+  tail -n 40 $O/round_records.log
+  tail -n 2 $O/native_clock_hip_final.log $O/acc_hip_24x100_fp16x2_full.log $O/acc_hip_24x100_bf16.log
 fi
