@@ -136,7 +136,7 @@ def cpu_baseline(cfg, threads_list=None, budget_s=24.0):
     runs in its own process (see _cpu_baseline_child)."""
     import subprocess
     cores = os.cpu_count() or 1
-    cands = sorted({t for t in (threads_list or [16, 32, 64, 128, cores]) if 1 <= t <= cores}) or [cores]
+    cands = sorted({t for t in (threads_list or [8, 16, 32, 64, 128, cores]) if 1 <= t <= cores}) or [cores]
     per = max(2.5, 0.6 * budget_s / len(cands))
 
     def child(th, ftz, b):
@@ -328,8 +328,10 @@ def main():
                     help="N > 1: the step tail in two launches and the all-reduce in two parts, the first on a side stream while the "
                          "second launch runs (hot_path.graft(overlap_allreduce=True)); same parameters bit for bit at world size 2")
     ap.add_argument("--cpu-threads", type=int, nargs="*", default=None,
-                    help="thread counts of the CPU-baseline sweep (default: 16 32 64 128 and all logical CPUs, capped at the box)")
+                    help="thread counts of the CPU-baseline sweep (default: 8 16 32 64 128 and all logical CPUs, capped at the box)")
     ap.add_argument("--fwd-operand", default="fp16x2", choices=["fp16x2", "fp16", "bf16", "fp16x2_full"])
+    ap.add_argument("--bwd-operand", default=None, choices=["fp16", "bf16"],
+                    help="operand / spill type of the second-order sweeps and the dW contraction (default: fp16 with an fp16-family forward)")
     ap.add_argument("--ramp-seconds", type=float, default=0.4,
                     help="untimed clock-ramp phase before the W warm-up steps (a fresh box runs the first ~100 ms at idle "
                          "clocks: 25 cold steps measured 13 %% slower than steady state in round 1); reported in the JSON line")
@@ -395,7 +397,7 @@ def main():
     torch.manual_seed(1)
     np.random.seed(1)
     tr = HipTrainer("cuda:%d" % local, cfg, incremental=True, inv_bounds_transform=synthetic.bounds_transform(),
-                    rng="philox", seed=1, dist_group=group, fwd_operand=args.fwd_operand,
+                    rng="philox", seed=1, dist_group=group, fwd_operand=args.fwd_operand, bwd_operand=args.bwd_operand,
                     overlap_allreduce=args.overlap_allreduce)
     dev = tr.device       # (replicated weights: graft() broadcasts rank 0's at construction)
     tr.frames = FrameData(frame_id=np.arange(F), depth_batch=torch.from_numpy(depth).to(dev),
@@ -498,20 +500,31 @@ def main():
     # ---- the same synchronised step() once the keyframe set has outgrown the window (K = 8 > window_size = 5): the regime
     # every real run is in after the first few seconds -- `select_keyframes` (trainer.py:652-674, the reference's own code: two
     # device ops + a .cpu()) draws a new window on the host EVERY step; the window travels inline as kernel arguments
-    windowed_ms = None
+    windowed_ms, transport_ab = None, None
     if group is None and not args.wide:
         K8 = 8
         d8, n8, T8 = (torch.cat([t, t[:K8 - F]]) for t in (tr.frames.depth_batch, tr.frames.normal_batch, tr.frames.T_WC_batch))
         saved = tr.frames
-        tr.frames = FrameData(frame_id=np.arange(K8), depth_batch=d8, T_WC_batch=T8, normal_batch=n8,
-                              frame_avg_losses=torch.full((K8,), 0.1, device=dev))
-        for _ in range(60):
-            tr.step()
-        t_w8 = time.perf_counter()
-        for _ in range(n_sync):
-            tr.step()
-        windowed_ms = (time.perf_counter() - t_w8) / n_sync * 1e3
+        frames8 = FrameData(frame_id=np.arange(K8), depth_batch=d8, T_WC_batch=T8, normal_batch=n8,
+                            frame_avg_losses=torch.full((K8,), 0.1, device=dev))
+
+        def timed_steps(n=n_sync, warm=60):
+            for _ in range(warm):
+                tr.step()
+            t_a = time.perf_counter()
+            for _ in range(n):
+                tr.step()
+            return (time.perf_counter() - t_a) / n * 1e3
+        transport_ab = {}
+        for label, inline in (("inline_kernel_arguments", True), ("device_tensors", False)):   # A/B of the window's transport
+            tr._hip.inline_window = inline
+            tr.frames = saved
+            fixed = timed_steps()
+            tr.frames = frames8
+            transport_ab[label] = {"sync_step_ms_K5": round(fixed, 4), "sync_step_ms_K8_windowed": round(timed_steps(), 4)}
+        tr._hip.inline_window = True
         tr.frames = saved
+        windowed_ms = transport_ab["inline_kernel_arguments"]["sync_step_ms_K8_windowed"]
 
     # ---- per-kernel timing from the HIP events recorded inside the timed region
     chain_us = np.array([events.ms(4 * i, 4 * i + 1) for i in range(KP)]) * 1e3
@@ -559,10 +572,11 @@ def main():
                             "collectives_per_step": 0 if group is None else (2 if overlap else 1),
                             "overlap_allreduce": bool(overlap), "per_rank_chain_us": per_rank_chain_us,
                             "per_rank_elapsed_s": per_rank_elapsed},
-            "dtype": {"fp16x2": "f16 (compensated forward: hi+lo operands past the cat layer) / bf16 MFMA operands, f32 accumulate",
-                      "fp16x2_full": "f16 (exact-forward instrument: hi+lo operands in every forward layer) / bf16 MFMA operands, f32 accumulate",
-                      "fp16": "f16/bf16 MFMA operands, f32 accumulate", "bf16": "bf16 MFMA operands, f32 accumulate"}[args.fwd_operand],
-            "fwd_operand": args.fwd_operand,
+            "dtype": {"fp16x2": "f16 MFMA operands (compensated forward: hi+lo operands past the cat layer), f32 accumulate; ",
+                      "fp16x2_full": "f16 MFMA operands (exact-forward instrument: hi+lo operands in every forward layer), f32 accumulate; ",
+                      "fp16": "f16 MFMA operands, f32 accumulate; ", "bf16": "bf16 MFMA operands, f32 accumulate; "}[args.fwd_operand]
+                     + "second-order sweeps and dW operands %s" % (eng.net.bwd_operand or ("bf16" if args.fwd_operand == "bf16" else "fp16")),
+            "fwd_operand": args.fwd_operand, "bwd_operand": eng.net.bwd_operand or ("bf16" if args.fwd_operand == "bf16" else "fp16"),
             "data": "synthetic",
             "config": {"workload": ("replicaCAD.json defaults: 5 keyframes x %d rays x 27 samples = %d points per "
                                     "rank-step, 680x1200 synthetic room depth, 6x256 Softplus MLP + 255-wide "
@@ -596,7 +610,8 @@ def main():
             "synchronised_step_windowed": None if windowed_ms is None else {
                 "ms_per_step": round(windowed_ms, 4), "steps_per_s": round(1e3 / windowed_ms, 2), "keyframes": 8, "window": F,
                 "what": "HipTrainer.step() with K = 8 keyframes > window_size: the reference's select_keyframes draws a new window "
-                        "on the host every step (two device ops + a device->host copy), the window goes to the kernels inline"},
+                        "on the host every step (two device ops + a device->host copy), the window goes to the kernels inline",
+                "window_transport_ab": transport_ab},
             "clock_ramp": {"untimed_steps_before_warmup": ramp_steps, "seconds": args.ramp_seconds},
             "chain_us_per_step": {"first5": [round(float(v), 1) for v in chain_us[:5]], "min": round(float(chain_us.min()), 1),
                                   "median": round(float(np.median(chain_us)), 1), "max": round(float(chain_us.max()), 1),

@@ -54,7 +54,7 @@ typedef struct isdf_net_cfg {
   float scale_output;    /* model.scale_output (fc_map.py:109)                 */
   float bounds_T[12];    /* rows of inv_bounds_transform[:3,:4] (row-major)    */
   int32_t fwd_operand;   /* MFMA operands of the forward and first-backward
-                            GEMMs (second-order passes are always bf16):
+                            GEMMs (the second-order passes: bwd_operand):
                             0 bf16; 1 fp16; 2 "fp16x2" = fp16 with a compensated
                             forward -- layers >= cat_layer also multiply the
                             fp16 residual of their weights, the layers past it
@@ -67,7 +67,12 @@ typedef struct isdf_net_cfg {
                             hidden 256 with a padded embedding of 256 only,
                             other shapes ISDF_EUNSUPPORTED).  isdf_shadow_bytes
                             grows by one forward set for modes 2 and 3.        */
-  int32_t reserved;
+  int32_t bwd_operand;   /* ABI 5: MFMA operands of the SECOND-order passes (adjoint of the input-gradient sweep, reverse sweep
+                            with the injected term, the dW contraction) and storage type of the tensors spilled between them:
+                            0 bf16 (range-safe for any loss-adjoint magnitude; rounds 1-3), 1 fp16 (needs fwd_operand >= 1;
+                            11 instead of 8 significand bits in every weight-gradient operand: total_loss.backward(),
+                            trainer.py:981, to ~1e-3 instead of ~4e-3; the adjoints of the shipped configs sit well inside
+                            fp16's range)                                                                    */
 } isdf_net_cfg;
 
 int isdf_abi_version(void);

@@ -29,7 +29,7 @@ class NetCfg(C.Structure):
     _fields_ = [("hidden", C.c_int32), ("blocks", C.c_int32), ("n_freqs", C.c_int32),
                 ("has_transform", C.c_int32), ("scale_input", C.c_float),
                 ("scale_output", C.c_float), ("bounds_T", C.c_float * 12),
-                ("fwd_operand", C.c_int32), ("reserved", C.c_int32)]
+                ("fwd_operand", C.c_int32), ("bwd_operand", C.c_int32)]
 
 
 class SampleArgs(C.Structure):

@@ -161,10 +161,15 @@ __device__ __forceinline__ int frag16_off(int w, int fb, int pb, int qp, int lan
   return ((((w * FBN + fb) * PBN + pb) * 2 + qp) * 64 + lane) * 8;
 }
 
-template <int HD, int EP, int OPER, int MODE>
+// BW: operand type of the SECOND-order sweeps (adjoint, reverse) and of every spilled tensor (the dW kernel's operands) in train mode:
+// false = bf16 (rounds 1-3: range-safe whatever the loss adjoints' magnitude), true = fp16 (NetLayout::bwd_f16: the same packed weight
+// copies as the forward / first reverse sweeps, 11 instead of 8 significand bits in every dW operand -- DESIGN 5, round 4).
+template <int HD, int EP, int OPER, int MODE, bool BW = false>
 __global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 && EP == HD && !oper_x2_all(OPER) ? 4 : 2)) void chain_kernel(const ChainParams p) {
   typedef Tile<HD, EP, oper_x2_all(OPER)> T;
   constexpr bool F16 = oper_f16(OPER), X2 = oper_x2(OPER), X2ALL = oper_x2_all(OPER);
+  static_assert(!BW || (F16 && MODE == 2), "fp16 second-order sweeps go with fp16 forward operands, train mode only");
+  typedef typename Op<BW>::e spillT;   // element type of the spilled tensors
   static_assert(!X2ALL || (HD == 256 && EP == 256), "fp16x2_full: four operand regions only fit the <256, 256> tile");
   constexpr int LO = X2ALL ? (HD + EP) : HD;   // first column of the residual of the running activation (a_lo)
   static_assert(EP == HD || EP == 2 * HD, "padded embedding width is one or two hidden widths");
@@ -269,7 +274,7 @@ __global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 && EP == HD && !oper_x2_a
     auto put = [&](int feat, float v) {
       *(opT*)(row + swz(pt, (HD + feat) * 2)) = (opT)v;
       if (X2ALL) *(opT*)(row + swz(pt, (LO + HD + feat) * 2)) = (opT)(v - (float)(opT)v);   // emb_lo
-      if (MODE == 2 && !WIDE_E) *(__bf16*)(row + swz(pt, feat * 2)) = (__bf16)v;   // bf16 copy staged for the spill
+      if (MODE == 2 && !WIDE_E) *(spillT*)(row + swz(pt, feat * 2)) = (spillT)v;   // copy in the spill type, staged for the spill
     };
     if (prt == 0) {
       xs[pt * 4] = y0; xs[pt * 4 + 1] = y1; xs[pt * 4 + 2] = y2;
@@ -290,7 +295,7 @@ __global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 && EP == HD && !oper_x2_a
   lds_barrier();
   auto spill_region = [&](int colElemBase, int64_t tensorOff, auto cvt) {
     // copy a [BM][HD] 16-bit region of X to global in frag16 order (16 B per lane); cvt: the region holds fp16
-    // operands and the spill tensors are bf16 (dW operand type)
+    // operands and the spill tensors are bf16 (dW operand type of the BW = false instantiations)
 #pragma unroll
     for (int fb = 0; fb < FB; ++fb)
 #pragma unroll
@@ -314,8 +319,8 @@ __global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 && EP == HD && !oper_x2_a
       spill_region(0, p.sp.A[0], std::false_type{});
       lds_barrier();
     } else {   // no room for a staged copy: spill the embedding halves straight from region 2
-      spill_region(HD, p.sp.A[0], std::integral_constant<bool, F16>{});
-      spill_region(2 * HD, p.sp.A[0] + p.sp.tensorElems, std::integral_constant<bool, F16>{});
+      spill_region(HD, p.sp.A[0], std::integral_constant<bool, F16 && !BW>{});
+      spill_region(2 * HD, p.sp.A[0] + p.sp.tensorElems, std::integral_constant<bool, F16 && !BW>{});
     }
   }
 
@@ -358,19 +363,25 @@ __global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 && EP == HD && !oper_x2_a
   };
   auto load_tile8 = [&](const Pre& pr, int fb, int pb, int qp, float (&o)[8]) {
     const uint4 u = pr.v[fb][qp][pb];
-    float a[4], b[4];
-    unpack4_bf16(make_uint2(u.x, u.y), a); unpack4_bf16(make_uint2(u.z, u.w), b);
+    if constexpr (BW) {
+      const f16x4 a = __builtin_bit_cast(f16x4, make_uint2(u.x, u.y)), b = __builtin_bit_cast(f16x4, make_uint2(u.z, u.w));
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { o[e] = a[e]; o[4 + e] = b[e]; }
+      for (int e = 0; e < 4; ++e) { o[e] = (float)a[e]; o[4 + e] = (float)b[e]; }
+    } else {
+      float a[4], b[4];
+      unpack4_bf16(make_uint2(u.x, u.y), a); unpack4_bf16(make_uint2(u.z, u.w), b);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { o[e] = a[e]; o[4 + e] = b[e]; }
+    }
   };
   auto store_tile8 = [&](int64_t tensorOff, int fb, int pb, int qp, const float (&v)[8]) {
-    const uint2 a = pack4<false>(v[0], v[1], v[2], v[3]), b = pack4<false>(v[4], v[5], v[6], v[7]);
+    const uint2 a = pack4<BW>(v[0], v[1], v[2], v[3]), b = pack4<BW>(v[4], v[5], v[6], v[7]);
     bstore16_nt<true>(make_uint4(a.x, a.y, b.x, b.y), srdS, lane16, sbase(tensorOff), cidx(fb, pb, qp));
   };
   // tensors that only the dW kernel re-reads (GB, ZB) are stored with the default cache policy (chain -2.3 %, dW unchanged);
   // A and P, which the chain kernel itself re-reads most, stay non-temporal
   auto store_tile8_dw = [&](int64_t tensorOff, int fb, int pb, int qp, const float (&v)[8]) {
-    const uint2 a = pack4<false>(v[0], v[1], v[2], v[3]), b = pack4<false>(v[4], v[5], v[6], v[7]);
+    const uint2 a = pack4<BW>(v[0], v[1], v[2], v[3]), b = pack4<BW>(v[4], v[5], v[6], v[7]);
     bstore16_nt<false>(make_uint4(a.x, a.y, b.x, b.y), srdS, lane16, sbase(tensorOff), cidx(fb, pb, qp));
   };
   // sigma'(z) of a layer for the backward epilogues, re-derived from the bf16 activation tile (no sigma' tensor is stored)
@@ -398,7 +409,7 @@ __global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 && EP == HD && !oper_x2_a
   };
   static_assert(FB * PB * 2 * 1024 <= (BM / T::NW) * T::R2 * 2, "a wave's pieces of one tensor fit its rows of region 2");
   auto park_tile8 = [&](int fb, int pb, int qp, const float (&v)[8]) {
-    const uint2 a = pack4<false>(v[0], v[1], v[2], v[3]), b = pack4<false>(v[4], v[5], v[6], v[7]);
+    const uint2 a = pack4<BW>(v[0], v[1], v[2], v[3]), b = pack4<BW>(v[4], v[5], v[6], v[7]);
     *(uint4*)(X + park_addr(cidx(fb, pb, qp))) = make_uint4(a.x, a.y, b.x, b.y);
   };
   float rawp[PB];
@@ -785,7 +796,7 @@ __global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 && EP == HD && !oper_x2_a
     const float y0 = xs[pt * 4], y1 = xs[pt * 4 + 1], y2 = xs[pt * 4 + 2];
     const float b0 = gbs[pt * 4], b1 = gbs[pt * 4 + 1], b2 = gbs[pt * 4 + 2];
     char* row = X + pt * ROWB;
-    auto put = [&](int feat, float v) { *(__bf16*)(row + swz(pt, (HD + feat) * 2)) = (__bf16)v; };
+    auto put = [&](int feat, float v) { *(spillT*)(row + swz(pt, (HD + feat) * 2)) = (spillT)v; };
     if (prt == 0) {
       put(0, b0); put(1, b1); put(2, b2);
       for (int f = L.E; f < EP; ++f) put(f, 0.f);
@@ -817,11 +828,11 @@ __global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 && EP == HD && !oper_x2_a
   auto adj_gemm = [&](int li, auto&& pf) {
     refresh();
     if (li == 0)
-      gemm<false, EP / 16, FB, PB, ROWB, T::CKF, true>(acc, wq, rsW, fwdW(setFwdB, li), X, HD * 2, lane, pf);
+      gemm<BW, EP / 16, FB, PB, ROWB, T::CKF, true>(acc, wq, rsW, fwdW(BW ? setFwdA : setFwdB, li), X, HD * 2, lane, pf);
     else if (li == L.cat)
-      gemm<false, (HD + EP) / 16, FB, PB, ROWB, T::CKF, true>(acc, wq, rsW, fwdW(setFwdB, li), X, 0, lane, pf);
+      gemm<BW, (HD + EP) / 16, FB, PB, ROWB, T::CKF, true>(acc, wq, rsW, fwdW(BW ? setFwdA : setFwdB, li), X, 0, lane, pf);
     else
-      gemm<false, HD / 16, FB, PB, ROWB, T::CKF, true>(acc, wq, rsW, fwdW(setFwdB, li), X, 0, lane, pf);
+      gemm<BW, HD / 16, FB, PB, ROWB, T::CKF, true>(acc, wq, rsW, fwdW(BW ? setFwdA : setFwdB, li), X, 0, lane, pf);
   };
   // The injected second-order term of layer li, u q sigma''(z) = beta (u sigma') (q sigma') (1 - sigma') / sigma', is NOT spilled:
   // the reverse sweep rebuilds it from GB[li+1] = u sigma' and P[li] = q sigma', which the dW kernel needs in memory anyway --
@@ -838,7 +849,7 @@ __global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 && EP == HD && !oper_x2_a
       load_s1(preA, fb, pb, qp, a);   // a[] = sigma'
 #pragma unroll
       for (int e = 0; e < 8; ++e) qb[e] = acc[fb][pb][8 * qp + e] * a[e];
-      put_x(false, fb, pb, qp, qb, 0);
+      put_x(BW, fb, pb, qp, qb, 0);
       store_tile8_dw(p.sp.GB[li + 1], fb, pb, qp, qb);
       if (li == L.L - 2) park_tile8(fb, pb, qp, qb);   // the reverse sweep's FIRST unit needs it back three units from here
     });
@@ -877,7 +888,7 @@ __global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 && EP == HD && !oper_x2_a
         wsum[e] += sb * a[e];
       }
       store_tile8_dw(p.sp.ZB[li], fb, pb, qp, zb);
-      if (li > 0) put_x(false, fb, pb, qp, zb, 0);
+      if (li > 0) put_x(BW, fb, pb, qp, zb, 0);
     }, [&](int fb, int qp) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) qsum[e] *= so;
@@ -897,7 +908,7 @@ __global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 && EP == HD && !oper_x2_a
   for (int li = L.L - 2; li >= 0; --li) {
     Pre preA, preG, preP;
     refresh();
-    gemm<false, HD / 16, FB, PB, ROWB, T::CKF, true>(acc, wq, rsW, wptr(setBwdB, L.bwdMat[li + 1], HD), X, 0, lane,
+    gemm<BW, HD / 16, FB, PB, ROWB, T::CKF, true>(acc, wq, rsW, wptr(BW ? setBwdA : setBwdB, L.bwdMat[li + 1], HD), X, 0, lane,
                                                [&] {
                                                  prefetch(p.sp.A[li + 1], preA);
                                                  if (li != L.L - 2) prefetch(p.sp.GB[li + 1], preG);   // the top one is parked in the tile
@@ -925,7 +936,7 @@ __global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 && EP == HD && !oper_x2_a
         bsum[e] += zb[e];
       }
       store_tile8_dw(p.sp.ZB[li], fb, pb, qp, zb);
-      if (li > 0) put_x(false, fb, pb, qp, zb, 0);
+      if (li > 0) put_x(BW, fb, pb, qp, zb, 0);
     }, [&](int fb, int qp) {
       vec_store8(bsum, li * HD + ubase(fb, qp));
 #pragma unroll
@@ -939,10 +950,12 @@ __global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 && EP == HD && !oper_x2_a
 }
 
 // ---------------------------------------------------------------------------
-template <int HD, int EP, int OPER, int MODE>
+template <int HD, int EP, int OPER, int MODE, bool BW = false>
 static int launch_one(const ChainParams& p, int64_t nTiles, hipStream_t st) {
   typedef Tile<HD, EP, oper_x2_all(OPER)> T;
-  auto k = chain_kernel<HD, EP, OPER, MODE>;
+  if constexpr (!BW && MODE == 2 && oper_f16(OPER))
+    if (p.lay.bwd_f16) return launch_one<HD, EP, OPER, MODE, true>(p, nTiles, st);
+  auto k = chain_kernel<HD, EP, OPER, MODE, BW>;
   if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES) != hipSuccess) return ISDF_EHIP;
   hipLaunchKernelGGL(k, dim3((unsigned)nTiles), dim3(T::NW * 64), T::LDS_BYTES, st, p);
   return isdf_launch_status();

@@ -45,7 +45,9 @@ __device__ __forceinline__ int frag16_piece(int c, int half, int sl, int& pt, in
   return ((((sl * 8 + blk) * PB + half * HB + pbh) * 2 + qp) * 64 + lane);
 }
 
-template <int HD>
+// F16: the spilled operands are fp16 (NetLayout::bwd_f16) instead of bf16 -- the same bits through the same transpose reads,
+// v_mfma_f32_32x32x16_f16 instead of _bf16.
+template <int HD, bool F16>
 __global__ __launch_bounds__(512, 2) void dw_kernel(const DwParams p) {
   typedef DwTile<HD> T;
   constexpr int BM = T::BM, ROWB = T::ROWB, CH = T::CH;
@@ -149,7 +151,8 @@ __global__ __launch_bounds__(512, 2) void dw_kernel(const DwParams p) {
       for (int ob = 0; ob < 2; ++ob)
 #pragma unroll
         for (int ib = 0; ib < 4; ++ib)
-          acc[ob][ib] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ob], b[ib], acc[ob][ib], 0, 0, 0);
+          acc[ob][ib] = Op<F16>::mfma(__builtin_bit_cast(typename Op<F16>::v8, a[ob]), __builtin_bit_cast(typename Op<F16>::v8, b[ib]),
+                                      acc[ob][ib]);
     }
   };
 
@@ -187,16 +190,13 @@ int launch_dw(const DwParams& p, hipStream_t st) {
   if (!layout_supported(p.lay)) return ISDF_EUNSUPPORTED;
   typedef DwTile<256> T;
   const dim3 grid(dw_units(p.lay) * DW_SPLITK), block(512);
-  if (p.lay.HD == 256) {
-    auto k = dw_kernel<256>;
-    if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES) != hipSuccess) return ISDF_EHIP;
+  auto go = [&](auto k) {
+    if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES) != hipSuccess) return (int)ISDF_EHIP;
     hipLaunchKernelGGL(k, grid, block, T::LDS_BYTES, st, p);
-  } else {
-    auto k = dw_kernel<512>;
-    if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES) != hipSuccess) return ISDF_EHIP;
-    hipLaunchKernelGGL(k, grid, block, T::LDS_BYTES, st, p);
-  }
-  return isdf_launch_status();
+    return isdf_launch_status();
+  };
+  if (p.lay.HD == 256) return p.lay.bwd_f16 ? go(dw_kernel<256, true>) : go(dw_kernel<256, false>);
+  return p.lay.bwd_f16 ? go(dw_kernel<512, true>) : go(dw_kernel<512, false>);
 }
 
 }  // namespace isdf

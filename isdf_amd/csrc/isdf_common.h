@@ -33,6 +33,7 @@ struct NetLayout {
                                //    W * x_lo) so that sdf meets the reference to 1e-3
   int fwd_x2_all;             // 1: "fp16x2_full" -- EVERY forward layer is compensated (weights and inputs, embedding included): the
                                //    exact-forward instrument, sdf ~1e-6 of the fp32 reference; <256, 256> nets only
+  int bwd_f16;                // 1: the second-order sweeps and every spilled dW operand in fp16 instead of bf16 (needs fwd_f16)
   int has_transform;
   float scale_input, scale_output;
   float T[12];
@@ -52,7 +53,7 @@ struct NetLayout {
 
 // Spill tensors written by the chain kernel and read by the dW kernel.  One
 // tensor = nTiles * TILE_PTS * HD 16-bit elements in "frag16" order (see
-// chain.hip): bf16 always.
+// chain.hip): bf16, or fp16 with NetLayout::bwd_f16.
 struct SpillLayout {
   int64_t tensorElems;   // per tensor per tile (TILE_PTS * HD); the buffer is [tile][tensor][tensorElems]
   int64_t tileStride;    // elements between consecutive tiles (= tensor count * tensorElems)
@@ -106,6 +107,8 @@ inline int make_layout(const isdf_net_cfg* c, NetLayout* l) {
   l->fwd_f16 = c->fwd_operand ? 1 : 0;
   l->fwd_x2 = c->fwd_operand >= 2 ? 1 : 0;
   l->fwd_x2_all = c->fwd_operand == 3 ? 1 : 0;
+  if (c->bwd_operand < 0 || c->bwd_operand > 1 || (c->bwd_operand == 1 && !l->fwd_f16)) return ISDF_EINVAL;
+  l->bwd_f16 = c->bwd_operand;
   l->has_transform = c->has_transform;
   l->scale_input = c->scale_input; l->scale_output = c->scale_output;
   for (int i = 0; i < 12; ++i) l->T[i] = c->has_transform ? c->bounds_T[i] : (i % 5 == 0 ? 1.f : 0.f);

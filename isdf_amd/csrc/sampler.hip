@@ -85,11 +85,10 @@ __global__ __launch_bounds__(SMP_NT) void sample_rays_kernel(const isdf_sample_a
   __shared__ int sChunk, sBase;
   __shared__ uint32_t sEpoch;
   __shared__ int sPre[NW], sWaveCnt[NW];
-  // (the pad keeps the streaming instantiation above 80 KB of LDS = ONE 16-wave workgroup per CU; seven floats per ray fit two, which
+  // (the pad keeps the streaming instantiation at 82 KB of LDS = ONE 16-wave workgroup per CU; seven floats per ray fit two, which
   //  measured SLOWER: 1e6 rays 0.203 vs 0.198 ms, 1e7 rays 1.78 vs 1.61 ms -- more gathers and look-back polls in flight, same HBM)
   __shared__ float sRay[CHUNK][8];   // depth, origin xyz, dirs_W xyz, pad  (compacted order within the chunk)
   __shared__ __attribute__((aligned(16))) float sPc[NW][768];   // a wave's 256 world points, staged for 16-byte stores
-  __shared__ __attribute__((aligned(16))) float sZ[NW][256];    // ... and their 256 z values
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   unsigned long long* state = (unsigned long long*)(ws + 4);
   const int total = a.n_frames * a.n_rays;
@@ -274,8 +273,7 @@ __global__ __launch_bounds__(SMP_NT) void sample_rays_kernel(const isdf_sample_a
       z = __fadd_rn(lim, __fmul_rn(U, blen));                       // sample.py:123-126
     }
     const int64_t n = r * S + s;
-    if (fullGroup) sZ[wv][m * 64 + lane] = z;
-    else o.z_vals[n] = z;
+    o.z_vals[n] = z;      // (four 4-byte stores per lane; one 16-byte store through an LDS stage measured SLOWER: r04_sampler_z_stores.txt)
 #pragma unroll
     for (int i = 0; i < 3; ++i) {  // pc = origins + dirs_W * z, sample.py:176
       const float v = __fadd_rn(sr[1 + i], __fmul_rn(sr[4 + i], z));
@@ -293,8 +291,6 @@ __global__ __launch_bounds__(SMP_NT) void sample_rays_kernel(const isdf_sample_a
         const float4 v = *(const float4*)&sPc[wv][(k * 64 + lane) * 4];
         *(f4u*)(dst + (k * 64 + lane) * 4) = f4u{v.x, v.y, v.z, v.w};
       }
-      const float4 zv = *(const float4*)&sZ[wv][lane * 4];     // the group's z values: one 16-byte store per lane instead of four
-      *(f4u*)(o.z_vals + (int64_t)base * S + (int64_t)G * 256 + lane * 4) = f4u{zv.x, zv.y, zv.z, zv.w};   // 4-byte ones
       __builtin_amdgcn_wave_barrier();   // the next group of this wave overwrites sPc
     }
   }

@@ -35,6 +35,10 @@ class NetConfig:
     #   "fp16x2_full"  every forward layer compensated (exact-forward instrument: sdf ~1e-6, d sdf/dx < 1e-3 of the reference;
     #            hidden 256 / n_freqs <= 6 nets only, one workgroup per CU: slower)
     fwd_operand: str = "fp16x2"
+    # MFMA operand / spill type of the second-order sweeps and the dW contraction (include/isdf_hip.h `bwd_operand`):
+    #   "fp16" (default with an fp16-family forward) or "bf16" (range-safe for any loss-adjoint magnitude; the only choice with
+    #   fwd_operand "bf16").  None = the default for the forward mode.
+    bwd_operand: Optional[str] = None
 
     @property
     def emb(self):
@@ -66,6 +70,10 @@ class NetConfig:
         if self.fwd_operand not in FWD_OPERANDS:
             raise ValueError("fwd_operand must be one of %s" % (FWD_OPERANDS,))
         c.fwd_operand = FWD_OPERANDS.index(self.fwd_operand)
+        bwd = self.bwd_operand or ("bf16" if self.fwd_operand == "bf16" else "fp16")
+        if bwd not in ("bf16", "fp16") or (bwd == "fp16" and self.fwd_operand == "bf16"):
+            raise ValueError("bwd_operand must be 'bf16' or 'fp16' (fp16 needs an fp16-family fwd_operand)")
+        c.bwd_operand = 1 if bwd == "fp16" else 0
         return c
 
 

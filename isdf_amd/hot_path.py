@@ -356,7 +356,7 @@ class HotPath:
         # The window: up to 8 keyframes travel INLINE as kernel arguments (sampler, step tail) -- select_keyframes re-draws it on
         # the host every step once K > window_size, and a device copy per step (two H2D copies + new call plans) cost ~80 us of
         # the synchronised step in that regime.  Longer windows (non-incremental runs over many frames) use cached device tensors.
-        if len(idxs) <= _ffi.MAX_INLINE_FRAMES:
+        if hip.inline_window and len(idxs) <= _ffi.MAX_INLINE_FRAMES:
             fidx = tuple(int(i) for i in idxs)
             # reference quirk q4: normals are read from the UN-windowed normal_batch with
             # window-local indices (trainer.py:956,969); fix_normal_window=True uses idxs.
@@ -566,7 +566,7 @@ UNSUPPORTED_HINT = ("isdf_amd hot path: %s (the reference's own Python path is t
 
 
 def graft(trainer, rng="philox", seed=1, dist_group=None, fix_normal_window=False, fwd_operand="fp16x2",
-          fuse_optimiser=True, virtual_step_ms=None, engine_factory=None, overlap_allreduce=False):
+          fuse_optimiser=True, virtual_step_ms=None, engine_factory=None, overlap_allreduce=False, bwd_operand=None):
     """Re-bind the hot path of `trainer` (an `isdf.modules.trainer.Trainer` or a `StandinTrainer`) to the HIP
     kernels, IN PLACE, and return it.
 
@@ -576,6 +576,7 @@ def graft(trainer, rng="philox", seed=1, dist_group=None, fix_normal_window=Fals
          weights are broadcast from rank 0 here so every rank starts from the same network.
     virtual_step_ms: if set, the virtual clock advances by this much per step instead of the measured step time
          (the frame schedule is a function of measured time, trainer.py:100-101,1011-1013; pin it to compare runs).
+    bwd_operand: "fp16" | "bf16" | None (default for the forward mode): operand / spill type of the second-order sweeps and dW.
     overlap_allreduce: data parallel only -- the closing reduction in two launches and the all-reduce in two parts, the first
          one on a side stream beside the second launch (dp.allreduce_split_); two collectives per step instead of one.
     engine_factory: tests only (a stand-in engine for hosts without a GPU)."""
@@ -602,7 +603,8 @@ def graft(trainer, rng="philox", seed=1, dist_group=None, fix_normal_window=Fals
         hidden = old.out_alpha.in_features
         with torch.random.fork_rng(devices=[]):    # grafting mid-run must not advance the caller's generator: the initial
             new = SDFMapHIP(pe, hidden_size=hidden, hidden_layers_block=n_block, scale_output=old.scale_output,   # weights
-                            device=dev, fwd_operand=fwd_operand, engine_factory=engine_factory)    # are overwritten below
+                            device=dev, fwd_operand=fwd_operand, engine_factory=engine_factory,    # are overwritten below
+                            bwd_operand=bwd_operand)
         new.load_state_dict({k: v.detach() for k, v in old.state_dict().items()})
         new.train(old.training)
         trainer.sdf_map = new
@@ -622,6 +624,7 @@ def graft(trainer, rng="philox", seed=1, dist_group=None, fix_normal_window=Fals
     hip = types.SimpleNamespace(rng=rng, seed=int(seed), dist_group=dist_group, fix_normal_window=bool(fix_normal_window),
                                 fuse_optimiser=bool(fuse_optimiser), device=dev, draw_count=0, noise_count=0,
                                 step_count=0, idx_cache=None, timing_events=None,
+                                inline_window=True,      # bench.py flips it for the A/B of the window's transport
                                 overlap_allreduce=bool(overlap_allreduce) and dist_group is not None, split_event=None,
                                 comm_stream=None,
                                 virtual_step_ms=None if virtual_step_ms is None else float(virtual_step_ms),

@@ -98,6 +98,7 @@ def prepare_keyframes(seeds, n):
 
 
 FWD_OPERAND = "fp16x2"   # --fwd-operand: the HIP path's operand mode for the pinned-schedule runs
+BWD_OPERAND = None       # --bwd-operand: fp16 | bf16 (None: the forward mode's default)
 PAIRED = False           # --paired-draws: both backends draw from torch's global generators in the reference's order
 DEVICE = "cpu"           # --device: where the port backend runs ("cuda" = PyTorch-ROCm eager, the fp32 control on the same GPU)
 
@@ -106,7 +107,7 @@ def run_hip(seed, depth, normal, T, cam, steps_per_kf):
     from tests.standin_trainer import HipTrainer, FrameData
     np.random.seed(seed); torch.manual_seed(seed)
     tr = HipTrainer("cuda", config(cam), inv_bounds_transform=synthetic.bounds_transform(), rng="torch" if PAIRED else "philox",
-                    seed=seed, fwd_operand=FWD_OPERAND)
+                    seed=seed, fwd_operand=FWD_OPERAND, bwd_operand=BWD_OPERAND)
     dev = tr.device
     if PAIRED:      # the same initial network as the control: torch's xavier draw under the same seed (PortNet's constructor order)
         from oracle import torch_port as tp
@@ -335,7 +336,7 @@ def run_native_clock(backend, seed, stream, max_steps, extra_opt_steps=400, eval
     if backend == "hip":
         from tests.standin_trainer import HipTrainer
         tr = HipTrainer("cuda", config(cam), inv_bounds_transform=synthetic.bounds_transform(), rng="philox", seed=seed,
-                        fwd_operand=FWD_OPERAND, virtual_step_ms=virtual_step_ms)
+                        fwd_operand=FWD_OPERAND, bwd_operand=BWD_OPERAND, virtual_step_ms=virtual_step_ms)
         sdf_fn = lambda p: tr.sdf_map(p)
         frames_of = lambda: [int(i) for i in tr.frames.frame_id]
 
@@ -399,6 +400,8 @@ def main():
     ap.add_argument("--steps", type=int, default=1200)
     ap.add_argument("--virtual-step-ms", type=float, default=20.0)
     ap.add_argument("--fwd-operand", default="fp16x2", choices=["fp16x2", "fp16", "bf16", "fp16x2_full"])
+    ap.add_argument("--bwd-operand", default=None, choices=["fp16", "bf16"],
+                    help="HIP backend: operand / spill type of the second-order sweeps and dW (default: fp16 with an fp16-family forward)")
     ap.add_argument("--device", default="cpu", help="device of the port backend (cuda = PyTorch-ROCm eager fp32: the control)")
     ap.add_argument("--paired-draws", action="store_true",
                     help="pinned schedule: both backends start from the SAME initial network and draw pixels / offsets / noise from "
@@ -410,8 +413,8 @@ def main():
     ap.add_argument("--max-steps", type=int, default=1000000,
                     help="native-clock mode: optimisation-step cap (replicaCAD.json trainer.steps is 20000)")
     a = ap.parse_args()
-    global FWD_OPERAND, DEVICE, PAIRED
-    FWD_OPERAND, DEVICE, PAIRED = a.fwd_operand, a.device, a.paired_draws
+    global FWD_OPERAND, DEVICE, PAIRED, BWD_OPERAND
+    FWD_OPERAND, DEVICE, PAIRED, BWD_OPERAND = a.fwd_operand, a.device, a.paired_draws, a.bwd_operand
     cam = dict(synthetic.SCANNET_CAM)
     res = []
     if a.native_clock or a.reference_schedule:

@@ -17,7 +17,9 @@ EVAL_CASES = ["eval_small_ray", "eval_small_pc_l2", "eval_small_nograd", "eval_f
               # configs[4]), 720x1280 with scale_input 0.4 / 0.04, trunc_weight 30, trunc_distance 0.1,
               # dist_behind_surf 0.01 and NO bounds transform (realsense*.json)
               "eval_small_b3_f9", "eval_small_b3_f10", "eval_small_b3_f11", "eval_wide_512",
-              "eval_rs_realsense", "eval_rs_franka", "eval_rs_franka_offline"]
+              "eval_rs_realsense", "eval_rs_franka", "eval_rs_franka_offline",
+              # round 4: hidden_layers_block = 1 (the paper's 4-hidden-layer net, fc_map.py:77-90) at width 256
+              "eval_b1_256"]
 
 
 def _sample(g):

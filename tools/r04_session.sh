@@ -6,6 +6,8 @@
 #              (identical random streams and initial network, HIP vs fp32 eager), data-parallel bench modes on one GPU
 #   final      full GPU suite, end-of-round records (tools/round_records.sh 04), native-clock run of the final host path,
 #              accuracy by forward operand mode (40 seeds each)
+#   bwd16      fp16 second-order sweeps / dW operands (bwd_operand): GPU suite (both types parametrised), same-box bench A/B,
+#              accuracy control 40 seeds each, window-transport A/B inside the bench line
 #   accuracy   fp32 eager-GPU control vs the HIP path (HEAD and the reverted d490710 variant) on 10 shared seeds, the
 #              trained-weights gradient-bias probe for both libraries, reference-driver schedule and native-clock runs
 # Outputs land in gpurun_out/r04/ (scratch); what is judged is copied to profiles/ by hand.
@@ -110,4 +112,26 @@ if [ "$stage" = final ]; then
   grep -h "trained-weights eval\|worst tensor\|trained-state" $O/pytest_gpu_final.log | cut -c1-1100
   tail -n 40 $O/round_records.log
   tail -n 2 $O/native_clock_hip_final.log $O/acc_hip_24x100_fp16x2_full.log $O/acc_hip_24x100_bf16.log
+fi
+
+if [ "$stage" = bwd16 ]; then
+  python -m pytest tests -q -m gpu -s > $O/pytest_gpu_bwd16.log 2>&1; lap pytest gpu
+  for rep in 1 2; do for b in bf16 fp16; do
+    python bench.py --steps 300 --warmup 50 --no-cpu-baseline --bwd-operand $b > $O/ab3_bwd_${b}_$rep.json 2> /dev/null; lap bench $b $rep
+  done; done
+  for b in fp16 bf16; do
+    python tests/accuracy_experiment.py --backend hip --seeds $(seq 1 40) --keyframes 24 --steps-per-kf 100 --bwd-operand $b \
+        --out $O/acc_hip_24x100_bwd_$b.json > $O/acc_hip_24x100_bwd_$b.log 2>&1; lap accuracy bwd $b
+  done
+  tail -n 8 $O/pytest_gpu_bwd16.log
+  grep -h "trained-weights eval\|per-tensor rel-L2\|trained-state\|weight gradients vs oracle\|fwd .* bwd\|worst gradient deviation" $O/pytest_gpu_bwd16.log | cut -c1-700
+  for f in $O/ab3_*.json; do python - "$f" <<'PY'
+import json, sys
+j = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+print("%-22s %8.1f /s %.4f ms chain %.4f dw %.4f tail %.4f sync %.4f | windowed %s | loss %.5f" % (
+    sys.argv[1].split("ab3_")[1][:-5], j["value"], j["ms_per_step"], *list(j["kernel_ms"].values())[:3], j["trainer_step_sync_ms"],
+    json.dumps((j.get("synchronised_step_windowed") or {}).get("window_transport_ab")), j["final_total_loss"]))
+PY
+  done
+  tail -n 1 $O/acc_hip_24x100_bwd_fp16.log $O/acc_hip_24x100_bwd_bf16.log
 fi
