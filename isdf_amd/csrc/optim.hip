@@ -93,7 +93,7 @@ __global__ void pack_kernel(NetLayout L, const float* __restrict__ P, uint16_t* 
   const uint4 hA = L.fwd_f16 ? make_uint4(a16.x, a16.y, b16.x, b16.y) : make_uint4(abf.x, abf.y, bbf.x, bbf.y);
   const uint4 hB = make_uint4(abf.x, abf.y, bbf.x, bbf.y);
   *(uint4*)(shadow + (isFwd ? L.setFwdA : L.setBwdA) + e0) = hA;
-  *(uint4*)(shadow + (isFwd ? L.setFwdB : L.setBwdB) + e0) = hB;
+  if (!L.bwd_f16) *(uint4*)(shadow + (isFwd ? L.setFwdB : L.setBwdB) + e0) = hB;
   if (L.fwd_x2 && isFwd && (L.fwd_x2_all || e0 >= L.fwdMat[L.cat])) {   // fp16 residuals of the compensated layers' weights
     float r[8];
 #pragma unroll
@@ -238,7 +238,7 @@ __device__ __forceinline__ void shadow_put(const NetLayout& L, uint16_t* sh, boo
                                            bool withResidual = false) {
   const uint32_t h = pack4<true>(val, 0.f, 0.f, 0.f).x & 0xffffu, b = pack4<false>(val, 0.f, 0.f, 0.f).x & 0xffffu;
   sh[(fwdSet ? L.setFwdA : L.setBwdA) + elem] = (uint16_t)(L.fwd_f16 ? h : b);
-  sh[(fwdSet ? L.setFwdB : L.setBwdB) + elem] = (uint16_t)b;
+  if (!L.bwd_f16) sh[(fwdSet ? L.setFwdB : L.setBwdB) + elem] = (uint16_t)b;   // the bf16 copies serve only the bf16 second-order sweeps
   if (withResidual) sh[L.setFwdLo + elem] = (uint16_t)(pack4<true>(f16_residual(val), 0.f, 0.f, 0.f).x & 0xffffu);
 }
 // element offset of (row, k) inside a packed [rows/32][Kp/16][64][8] matrix (see pack_kernel)

@@ -7,7 +7,8 @@ Tolerances (BASELINE.json north_star / SURVEY 8c):
   * sdf outputs and every loss term: <= 1e-3 relative (default operand mode "fp16x2": compensated forward)
   * sdf_grad: <= 2e-3 relative at BASELINE size (measured ~1.3e-3: forward error of layers 0-2 and the fp16 first reverse
     sweep; SURVEY 8c asks 1e-3); small batches are judged on the scale of a unit gradient
-  * weight gradients: cosine >= 0.999 and <= 1e-2 rel-L2 per tensor
+  * weight gradients: cosine >= 0.999 and <= 1e-2 rel-L2 per tensor; with the default fp16 second-order sweeps the
+    BASELINE-size fixtures are held to 3e-3 (measured 0.9e-3 .. 1.2e-3; bf16 sweeps: 3.1e-3 .. 4.4e-3)
   * AdamW update given identical gradients: <= 1e-6
 """
 import numpy as np
@@ -23,6 +24,7 @@ TOL_SDF = 1e-3
 TOL_LOSS = 1e-3
 TOL_SDF_GRAD = 2e-3
 TOL_DW = 1e-2
+TOL_DW_BWD16 = 3e-3      # BASELINE-size fixtures, default operand types (fp16 second-order sweeps and dW operands)
 
 
 def _engine(g, fwd_operand="fp16x2", bwd_operand=None):
@@ -760,8 +762,9 @@ def test_base_size_train_step_vs_reference_and_oracle(case, src, fwd_operand):
     np.testing.assert_allclose(la.cpu().numpy(), g["loss_approx"], rtol=2e-2, atol=1e-5)
     assert gu.rel_err(dbg["sdf_grad"][:R].cpu().numpy(), terms["sdf_grad"]) < (TOL_SDF_GRAD if fwd_operand == "fp16x2" else 2.5e-3)
     assert gu.rel_err(dbg["tot_loss_mat"][:R].cpu().numpy(), terms["tot_loss_mat"]) < 5e-3
-    _check_grads_vs_reference_digest(eng, N, g)
-    _check_grads_vs_oracle(eng, N, grads)
+    tol = TOL_DW if bwd_operand == "bf16" else TOL_DW_BWD16
+    _check_grads_vs_reference_digest(eng, N, g, tol=tol)
+    _check_grads_vs_oracle(eng, N, grads, tol=tol)
 
 
 def _replay_hip_steps(g, eng, lc, sc, n_steps, fused):

@@ -135,3 +135,19 @@ PY
   done
   tail -n 1 $O/acc_hip_24x100_bwd_fp16.log $O/acc_hip_24x100_bwd_bf16.log
 fi
+
+if [ "$stage" = final2 ]; then      # the records of the FINAL tree (fp16 second-order sweeps by default, window inline)
+  python -m pytest tests -q -m gpu -s > $O/pytest_gpu_final2.log 2>&1; lap pytest gpu
+  bash tools/round_records.sh 04 > $O/round_records2.log 2>&1; lap records
+  cd $GRAFT_REPO_ROOT
+  python tests/accuracy_experiment.py --native-clock --backend hip --seeds $SEEDS5 --out $O/native_clock_hip_final2.json > $O/native_clock_hip_final2.log 2>&1; lap native hip
+  ISDF_BENCH_FORCE_DP=1 python bench.py --steps 300 --warmup 50 --no-cpu-baseline --overlap-allreduce 2> /dev/null | tail -1 > $O/bench_forced_dp_world1_overlap_final.json; lap dp1 overlap
+  for mode in "--scaling weak" "--scaling strong" "--scaling weak --overlap-allreduce"; do
+    tag=$(echo $mode | tr -d ' -')
+    ISDF_BENCH_BACKEND=gloo python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29611 \
+        bench.py --gpus 2 --steps 100 --warmup 20 --no-cpu-baseline $mode 2> /dev/null | tail -1 > $O/bench_dp2_gloo_final_$tag.json; lap dp2 $tag
+  done
+  tail -n 6 $O/pytest_gpu_final2.log
+  tail -n 45 $O/round_records2.log
+  tail -n 1 $O/native_clock_hip_final2.log
+fi
