@@ -565,6 +565,16 @@ UNSUPPORTED_HINT = ("isdf_amd hot path: %s (the reference's own Python path is t
                     "this build ships no second implementation)")
 
 
+def can_graft(trainer):
+    """True when `graft(trainer)` can bind the kernels: the trainer sits on a HIP device and libisdf_hip.so is built.  The guard
+    INTEGRATION.md puts in front of graft(): on a CPU-only host (BASELINE configs[0]) the reference's own Python path keeps
+    running -- this package ships no second implementation and graft() itself raises there."""
+    if ENGINE_FACTORY is not None:          # host-logic tests with a stand-in engine
+        return True
+    import os
+    return torch.device(trainer.device).type == "cuda" and torch.cuda.is_available() and os.path.exists(_ffi.LIB_PATH)
+
+
 def graft(trainer, rng="philox", seed=1, dist_group=None, fix_normal_window=False, fwd_operand="fp16x2",
           fuse_optimiser=True, virtual_step_ms=None, engine_factory=None, overlap_allreduce=False, bwd_operand=None):
     """Re-bind the hot path of `trainer` (an `isdf.modules.trainer.Trainer` or a `StandinTrainer`) to the HIP
