@@ -46,7 +46,8 @@ enum {
  *   cat_layer.0.{weight[Hd,Hd+E],bias}, mid2.i.0.{...}, out_alpha.{weight[1,Hd],bias[1]}
  * (the host mirror re-points the nn.Module parameters at views of it).       */
 typedef struct isdf_net_cfg {
-  int32_t hidden;        /* Hd: hidden_feature_size (replicaCAD.json:58)       */
+  int32_t hidden;        /* Hd: hidden_feature_size (replicaCAD.json:58): any value <= 512 (widths other than 256 / 512 run zero-padded
+                            on the 256- / 512-wide tile kernels; parameters, moments and gradients keep the reference's shapes) */
   int32_t blocks;        /* B : hidden_layers_block (replicaCAD.json:57)       */
   int32_t n_freqs;       /* n_embed_funcs + 1 (embedding.py:36); E = 42*n+3    */
   int32_t has_transform; /* 0: PE transform is None (live modes)    */

@@ -59,10 +59,26 @@ def build(force=False, verbose=True):
             print(out)
     if failed:
         raise RuntimeError("hipcc failed")
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    staged = LIB + ".staged"
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", staged] + objs
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
+    # instruction forms measured to misbehave on MI355X (isa_lint.py): a library that contains one is not installed
+    from . import isa_lint
+    try:
+        n_obj, bad = isa_lint.lint_library(staged)
+    except (OSError, subprocess.CalledProcessError) as e:      # no llvm-objdump on this host: the check cannot run (tests/test_isa_lint.py
+        n_obj, bad = 0, []                                     # then skips too); never a reason to ship nothing
+        sys.stderr.write("isa_lint could not run (%s)\n" % e)
+    if bad and not os.environ.get("ISDF_SKIP_ISA_LINT"):
+        os.remove(staged)
+        raise RuntimeError("isa_lint: %d instruction(s) of a form measured to misbehave on MI355X, e.g.\n  %s\n      %s\n"
+                           "(see isdf_amd/isa_lint.py; rewrite the source so the compiler does not pick that form)"
+                           % (len(bad), bad[0][0], bad[0][1]))
+    os.replace(staged, LIB)
+    if verbose:
+        print("isa_lint: %d code objects, clean" % n_obj)
     return LIB
 
 

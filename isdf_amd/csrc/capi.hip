@@ -49,7 +49,7 @@ const char* isdf_error_string(int code) {
   switch (code) {
     case ISDF_OK: return "ok";
     case ISDF_EINVAL: return "invalid argument";
-    case ISDF_EUNSUPPORTED: return "unsupported configuration (the tile kernels are built for hidden_feature_size 256 or 512, n_freqs = n_embed_funcs+1 in 1..12, any hidden_layers_block up to 7; bounds_method ray|pc)";
+    case ISDF_EUNSUPPORTED: return "unsupported configuration (the tile kernels take hidden_feature_size <= 512 (zero-padded to 256 / 512), n_freqs = n_embed_funcs+1 in 1..12, any hidden_layers_block up to 7; bounds_method ray|pc)";
     case ISDF_EWORKSPACE: return "workspace too small";
     case ISDF_EHIP: {
       static thread_local char buf[160];

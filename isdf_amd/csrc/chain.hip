@@ -234,11 +234,22 @@ __global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 && EP == HD && !oper_x2_a
   // feature index of (fb, qp) blocks: f0 = ubase(fb, qp) + 4*hi
   auto ubase = [&](int fb, int qp) { return w * (FB * 32) + fb * 32 + 16 * qp; };
   // 8 fp32 parameters params[off + f0 + {0..3, 8..11}]
-  auto ld_params8 = [&](int offUniform, float (&o)[8]) {
-    const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rsP, 16 * hi, offUniform * 4, 0);
-    const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(rsP, 16 * hi + 32, offUniform * 4, 0);
+  // vecBase: flat offset of a per-unit vector (a bias, w_out), ub: the block's first unit.  Units >= L.H are padding (a hidden width
+  // below the tile width, NetLayout::H): they read as 0 and nothing past the real vector is touched.
+  auto ld_params8 = [&](int vecBase, int ub, float (&o)[8]) {
+    if (L.H == HD) {
+      const int offUniform = vecBase + ub;
+      const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rsP, 16 * hi, offUniform * 4, 0);
+      const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(rsP, 16 * hi + 32, offUniform * 4, 0);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { o[e] = __uint_as_float(a[e]); o[4 + e] = __uint_as_float(b[e]); }
+      for (int e = 0; e < 4; ++e) { o[e] = __uint_as_float(a[e]); o[4 + e] = __uint_as_float(b[e]); }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int f = ub + 4 * hi + (e & 3) + 8 * (e >> 2);
+        o[e] = f < L.H ? p.params[vecBase + f] : 0.f;
+      }
+    }
   };
   // per-workgroup partial of a bias / out-layer gradient entry: sum over the half-wave's 32 points
   // The 8 values of an accumulator block (features elemUniform + 4*hi + {0..3, 8..11}) go out in ONE store: after the butterflies
@@ -466,7 +477,7 @@ __global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 && EP == HD && !oper_x2_a
     if (!last) {
       float bv[8];
       for_blocks([&](int fb, int pb, int qp, int row) {
-        if (pb == 0) ld_params8(L.offB[li] + ubase(fb, qp), bv);
+        if (pb == 0) ld_params8(L.offB[li], ubase(fb, qp), bv);
         float a[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) a[e] = softplus_f(acc[fb][pb][8 * qp + e] + bv[e]);
@@ -478,17 +489,25 @@ __global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 && EP == HD && !oper_x2_a
       float bv[8], wv[8];
       for_blocks([&](int fb, int pb, int qp, int row) {
         if (pb == 0) {
-          ld_params8(L.offB[li] + ubase(fb, qp), bv);
-          ld_params8(L.offWout + ubase(fb, qp), wv);
+          ld_params8(L.offB[li], ubase(fb, qp), bv);
+          ld_params8(L.offWout, ubase(fb, qp), wv);
         }
         float a[8], pl[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           float s1;
           a[e] = softplus_s1(acc[fb][pb][8 * qp + e] + bv[e], s1);
-          rawp[pb] += wv[e] * a[e];
           pl[e] = so * wv[e] * s1;   // p_L = q_L * sigma'(z_L), q_L = so * w_out
         }
+        // w_out . a over the block's 8 units, as four packed FMAs of ELEMENT PAIRS (wv[e], wv[e+1]) * (a[e], a[e+1]).  Written out
+        // because of what the vectoriser makes of the scalar `rawp[pb] += wv[e] * a[e]`: it pairs the two point blocks and broadcasts
+        // wv[e], i.e. v_pk_fma_f32 with op_sel:[0,1,0] for the odd e -- a form that, with two workgroups on a CU, intermittently
+        // dropped the low half's product in lanes 48-63 on MI355X (isdf_amd/isa_lint.py rule 1 has the measurements; the build refuses
+        // a library that contains it).
+        f32x2 r2 = {0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) r2 += f32x2{wv[e], wv[e + 1]} * f32x2{a[e], a[e + 1]};
+        rawp[pb] += r2[0] + r2[1];
         if (MODE >= 1) {
           store_tile8(p.sp.A[li + 1], fb, pb, qp, a);
           put_x(F16, fb, pb, qp, pl, 0);
@@ -788,7 +807,16 @@ __global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 && EP == HD && !oper_x2_a
 
   TS();   // (loss sums written)
   // ------------------------------------------------------------------ Ebar = J_pe gbar  -> region 2 (bf16)
-  if (tid < HD / 4) ((float4*)part)[tid] = ((const float4*)(p.params + L.offWout))[tid];   // w_out for the top epilogue
+  if (tid < HD / 4) {   // w_out for the top epilogue (0 for the padding units of a narrower net)
+    float4 wv4;
+    if (L.H == HD) wv4 = ((const float4*)(p.params + L.offWout))[tid];
+    else {
+      const float* wo = p.params + L.offWout;
+      const int f = 4 * tid;
+      wv4 = make_float4(f < L.H ? wo[f] : 0.f, f + 1 < L.H ? wo[f + 1] : 0.f, f + 2 < L.H ? wo[f + 2] : 0.f, f + 3 < L.H ? wo[f + 3] : 0.f);
+    }
+    ((float4*)part)[tid] = wv4;
+  }
   {
     // a wave = (BM / NW points) x (direction slices): rows are 1 KB apart, i.e. 8 banks -- 64 points per wave was 8-way conflicted
     const int pt = (tid % (BM / T::NW)) + (BM / T::NW) * (tid / 64), prt = (tid % 64) / (BM / T::NW);

@@ -23,11 +23,15 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
 
 // Parameter / packed-weight / workspace layout, computed on the host by
 // make_layout() and passed to kernels by value.
 struct NetLayout {
-  int HD, EP, E, B, L, cat, n_freqs;
+  int HD, EP, E, B, L, cat, n_freqs;   // HD: tile width of the hidden layers (256 or 512), EP: padded embedding width
+  int H;                       // hidden_feature_size itself (<= HD): the fp32 parameters have the reference's shapes [H x K]; units
+                               // H..HD-1 of every layer are padding -- zero weights and biases in the packed copies, so their
+                               // activation softplus(0) feeds nothing and every adjoint entering them is exactly zero
   int fwd_f16;                 // 1: fp16 operands in forward/first-backward GEMMs
   int fwd_x2;                  // 1: compensated forward ("fp16x2"): layers >= cat add W_lo * x (and, past the cat layer,
                                //    W * x_lo) so that sdf meets the reference to 1e-3
@@ -97,7 +101,8 @@ inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 inline int make_layout(const isdf_net_cfg* c, NetLayout* l) {
   if (!c || !l) return ISDF_EINVAL;
   if (c->blocks < 1 || 2 * c->blocks + 2 > MAXL || c->n_freqs < 1 || c->hidden < 1) return ISDF_EINVAL;
-  l->HD = c->hidden; l->B = c->blocks; l->n_freqs = c->n_freqs;
+  l->H = c->hidden; l->HD = c->hidden <= 256 ? 256 : 512; l->B = c->blocks; l->n_freqs = c->n_freqs;
+  if (c->hidden > 512) return ISDF_EUNSUPPORTED;
   l->E = 2 * N_DIRS * c->n_freqs + 3;
   // padded embedding width: a multiple of the 256-wide dW unit and at least the hidden width (the embedding
   // shares region 2 of the activation tile with hidden-width operands)
@@ -114,12 +119,12 @@ inline int make_layout(const isdf_net_cfg* c, NetLayout* l) {
   for (int i = 0; i < 12; ++i) l->T[i] = c->has_transform ? c->bounds_T[i] : (i % 5 == 0 ? 1.f : 0.f);
   int64_t off = 0;
   for (int li = 0; li < l->L; ++li) {
-    int K = li == 0 ? l->E : (li == l->cat ? l->HD + l->E : l->HD);
+    int K = li == 0 ? l->E : (li == l->cat ? l->H + l->E : l->H);
     l->K[li] = K;
-    l->offW[li] = (int32_t)off; off += (int64_t)l->HD * K;
-    l->offB[li] = (int32_t)off; off += l->HD;
+    l->offW[li] = (int32_t)off; off += (int64_t)l->H * K;
+    l->offB[li] = (int32_t)off; off += l->H;
   }
-  l->offWout = (int32_t)off; off += l->HD;
+  l->offWout = (int32_t)off; off += l->H;
   l->offBout = (int32_t)off; off += 1;
   l->n_params = off;
   int64_t f = 0, b = 0;
@@ -138,7 +143,8 @@ inline int make_layout(const isdf_net_cfg* c, NetLayout* l) {
 
 // The tile kernels are instantiated for <HD, EP> = <256, 256> (replicaCAD.json / scanNet.json: hidden 256,
 // n_freqs 6 -> E 255), <256, 512> (realsense*.json: hidden 256, n_freqs 9 / 11 -> E 381 / 465) and <512, 512>
-// (BASELINE configs[4]).  Other shapes: ISDF_EUNSUPPORTED.
+// (BASELINE configs[4]); any hidden_feature_size up to 512 runs on them zero-padded (NetLayout::H).  Other shapes
+// (hidden > 512, hidden <= 256 with more than 12 embedding octaves): ISDF_EUNSUPPORTED.
 inline bool layout_supported(const NetLayout& l) {
   // "fp16x2_full" keeps four operand regions (a, emb and their residuals) in the LDS tile: 128 KB at <256, 256>, too much beyond
   if (l.fwd_x2_all) return l.HD == 256 && l.EP == 256;

@@ -39,24 +39,27 @@ __global__ void adamw_kernel(float* __restrict__ p, float* __restrict__ m, float
 // every packed matrix is [rows/32][K/16][64 lanes][8]: lane l holds row
 // (l&31), k = ks*16 + 8*(l>>5) .. +8  -- exactly the A fragment of
 // v_mfma_f32_32x32x16, so a wave's fragment load is one contiguous 1 KB.
+// (row, k) are PADDED coordinates (HD hidden units, EP embedding features); the parameters have the reference's shapes [H x K]:
+// everything that touches a padding unit H..HD-1 or a padding feature E..EP-1 is 0
 __device__ __forceinline__ float fwd_src(const NetLayout& L, const float* P, int li, int row, int k) {
-  const int HD = L.HD;
+  const int HD = L.HD, H = L.H;
+  if (row >= H) return 0.f;
   if (li == 0) return k < L.E ? P[L.offW[0] + (int64_t)row * L.K[0] + k] : 0.f;
   if (li == L.cat) {
-    if (k < HD) return P[L.offW[li] + (int64_t)row * L.K[li] + k];
+    if (k < HD) return k < H ? P[L.offW[li] + (int64_t)row * L.K[li] + k] : 0.f;
     const int e = k - HD;
-    return e < L.E ? P[L.offW[li] + (int64_t)row * L.K[li] + HD + e] : 0.f;
+    return e < L.E ? P[L.offW[li] + (int64_t)row * L.K[li] + H + e] : 0.f;
   }
-  return P[L.offW[li] + (int64_t)row * L.K[li] + k];
+  return k < H ? P[L.offW[li] + (int64_t)row * L.K[li] + k] : 0.f;
 }
 __device__ __forceinline__ float bwd_src(const NetLayout& L, const float* P, int li, int row, int k) {
   // W_li^T restricted to the first HD inputs: [row = input i][k = output o]
-  return P[L.offW[li] + (int64_t)k * L.K[li] + row];
+  return (row < L.H && k < L.H) ? P[L.offW[li] + (int64_t)k * L.K[li] + row] : 0.f;
 }
 __device__ __forceinline__ float g_src(const NetLayout& L, const float* P, int row, int k) {
   if (row >= L.E) return 0.f;
-  if (k < L.HD) return P[L.offW[0] + (int64_t)k * L.K[0] + row];
-  return P[L.offW[L.cat] + (int64_t)(k - L.HD) * L.K[L.cat] + L.HD + row];
+  if (k < L.HD) return k < L.H ? P[L.offW[0] + (int64_t)k * L.K[0] + row] : 0.f;
+  return k - L.HD < L.H ? P[L.offW[L.cat] + (int64_t)(k - L.HD) * L.K[L.cat] + L.H + row] : 0.f;
 }
 
 __global__ void pack_kernel(NetLayout L, const float* __restrict__ P, uint16_t* __restrict__ shadow) {
@@ -299,9 +302,12 @@ __global__ __launch_bounds__(1024) void step_tail_kernel(const TailParams p) {
     const int o = du.ob * DW_BLK + rem / DW_BLK;
     const int ip = du.ib * DW_BLK + rem % DW_BLK;          // padded input column
     const int li = du.li;
+    if (o >= L.H) return;                                  // padding unit (NetLayout::H): no parameter behind it
     if (li == 0 && ip >= L.E) return;
     if (li == L.cat && ip >= HD && ip - HD >= L.E) return;
-    const int col = ip;                                    // column in the fp32 weight [HD x K_li]
+    if ((li != 0 && ip < HD && ip >= L.H)) return;         // padding input unit
+    // column in the fp32 weight [H x K_li]: the cat layer's embedding columns follow its H hidden ones
+    const int col = (li == L.cat && ip >= HD) ? L.H + (ip - HD) : ip;
     const int64_t pi = L.offW[li] + (int64_t)o * L.K[li] + col;
     float s = 0.f;
     if (PHASE == 2) s = p.grad[pi];
@@ -318,12 +324,12 @@ __global__ __launch_bounds__(1024) void step_tail_kernel(const TailParams p) {
     const float w = adamw_update(p.params, p.m, p.v, pi, s, gs, p.c);
     // packed operand copies (pack_kernel's sources, inverted): forward orientation ...
     const int KpF = li == 0 ? L.EP : (li == L.cat ? HD + L.EP : HD);
-    shadow_put(L, p.shadow, true, L.fwdMat[li] + packed_elem(o, col, KpF), w, L.fwd_x2 && (L.fwd_x2_all || li >= L.cat));
+    shadow_put(L, p.shadow, true, L.fwdMat[li] + packed_elem(o, ip, KpF), w, L.fwd_x2 && (L.fwd_x2_all || li >= L.cat));
     // ... W^T restricted to the first HD inputs (layers >= 1) ...
-    if (li >= 1 && col < HD) shadow_put(L, p.shadow, false, L.bwdMat[li] + packed_elem(col, o, HD), w);
+    if (li >= 1 && ip < HD) shadow_put(L, p.shadow, false, L.bwdMat[li] + packed_elem(ip, o, HD), w);
     // ... and the embedding-gradient matrix [W_in^T | W_cat[:, HD:]^T]
-    if (li == 0) shadow_put(L, p.shadow, false, L.bwdG + packed_elem(col, o, 2 * HD), w);
-    else if (li == L.cat && col >= HD) shadow_put(L, p.shadow, false, L.bwdG + packed_elem(col - HD, HD + o, 2 * HD), w);
+    if (li == 0) shadow_put(L, p.shadow, false, L.bwdG + packed_elem(ip, o, 2 * HD), w);
+    else if (li == L.cat && ip >= HD) shadow_put(L, p.shadow, false, L.bwdG + packed_elem(ip - HD, HD + o, 2 * HD), w);
     return;
   }
   // ---- biases (L*HD), w_out (HD), b_out (1): vec_reduce_kernel's mapping, 64 parameters x 16 tile groups
@@ -333,8 +339,8 @@ __global__ __launch_bounds__(1024) void step_tail_kernel(const TailParams p) {
   const int nVec = L.L * HD + HD + 1;
   const int nTiles = (int)((P + TILE_PTS - 1) / TILE_PTS);
   int slotA = 0, slotB = -1, dst = -1;
-  if (v < L.L * HD) { slotA = v; dst = L.offB[v / HD] + v % HD; }
-  else if (v < L.L * HD + HD) { slotA = v; slotB = v + HD; dst = L.offWout + (v - L.L * HD); }
+  if (v < L.L * HD) { slotA = v; if (v % HD < L.H) dst = L.offB[v / HD] + v % HD; }          // (padding units: no parameter)
+  else if (v < L.L * HD + HD) { slotA = v; slotB = v + HD; if (v - L.L * HD < L.H) dst = L.offWout + (v - L.L * HD); }
   else if (v < nVec) { slotA = L.L * HD + 2 * HD; dst = L.offBout; }
   if (PHASE == 2) {
     if (g == 0 && dst >= 0 && !emptyBatch) adamw_update(p.params, p.m, p.v, dst, p.grad[dst], gs, p.c);

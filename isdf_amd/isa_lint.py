@@ -1,0 +1,87 @@
+#!/usr/bin/env python3
+"""Static check of the built device code (every gfx950 code object inside libisdf_hip.so) for instruction forms this project has
+MEASURED to misbehave on MI355X.  isdf_amd/build.py runs it on the freshly linked library BEFORE installing it in-tree (a violating build is refused);
+tests/test_isa_lint.py runs it on the library the tests load.
+
+Rule 1 -- packed fp32 op whose LOW result reads the HIGH dword of a VGPR src1 pair (VOP3P `op_sel:[x,1,..]`, e.g.
+    v_pk_fma_f32 v[34:35], v[52:53], v[34:35], v[42:43] op_sel:[0,1,0]
+the form LLVM's SLP vectoriser picks for "pair (p0, p1) times a broadcast of the odd element of a register pair").  Round 4: with two
+workgroups resident on a CU the product of the LOW half was intermittently dropped (low result = src2) in lanes 48-63, nowhere else:
+  * found as sdf values off by 1e-3 .. 1e-2 in rows 16-31 of a tile, non-deterministically, only in builds whose output-layer
+    reduction the compiler happened to vectorise that way (tests/fwd_race_probe.py: the errors decompose into single missing
+    w_out[u] * a[u] terms, u in the lane half / odd elements those 7 instructions handle; the 8th odd element, which the compiler
+    encoded with op_sel_hi instead, never failed);
+  * ISA-level A/B on the failing build, nothing else changed (profiles/r04_pk_fma_opsel_erratum.txt): s_nop 3 before or after the
+    instructions -- still failing; the same instruction with src0 and src1 swapped (op_sel:[1,0,0]) -- clean; two v_fma_f32 -- clean;
+    one workgroup per CU -- clean.
+An SGPR-pair src1 with the same selector (the sampler's `v_pk_add_f32 ..., s[10:11] op_sel:[0,1]`) has run bit-exact against the
+reference at every size since round 1 and is not flagged.
+
+usage: python -m isdf_amd.isa_lint [path/to/lib.so]   -> exit status 1 and the offending lines if a rule fires"""
+import os, re, subprocess, sys, tempfile
+
+LLVM_BIN = os.environ.get("ISDF_LLVM_BIN", "/opt/rocm/lib/llvm/bin")
+# VOP3P packed fp32 ops: v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 (+ v_pk_mov_b32 moves data only).  operands: vdst, src0, src1[, src2]
+_PK = re.compile(r"\b(v_pk_(?:fma|mul|add)_f32)\s+(\S+),\s*(\S+),\s*(\S+?)(?:,\s*(\S+))?\s+(.*)$")
+_OPSEL = re.compile(r"\bop_sel:\[([01]),([01])")
+
+
+def code_objects(lib, workdir):
+    """Extract the gfx950 code objects of a HIP shared library (llvm-objdump --offloading writes them next to the input)."""
+    local = os.path.join(workdir, os.path.basename(lib))
+    with open(lib, "rb") as f, open(local, "wb") as g:
+        g.write(f.read())
+    subprocess.check_output([os.path.join(LLVM_BIN, "llvm-objdump"), "--offloading", local], stderr=subprocess.STDOUT)
+    return sorted(os.path.join(workdir, n) for n in os.listdir(workdir) if "amdgcn" in n)
+
+
+def disassemble(obj):
+    return subprocess.check_output([os.path.join(LLVM_BIN, "llvm-objdump"), "-d", "--mcpu=gfx950", obj],
+                                   stderr=subprocess.DEVNULL).decode("utf-8", "replace")
+
+
+def lint_text(text):
+    """-> [(kernel, instruction)] violating rule 1."""
+    out, kernel = [], "?"
+    for line in text.split("\n"):
+        if line.endswith(">:") and "<" in line:
+            kernel = line[line.index("<") + 1:-2]
+            continue
+        if "v_pk_" not in line or "op_sel:" not in line:
+            continue
+        ins = line.split("//")[0].strip()
+        m = _PK.search(ins)
+        s = _OPSEL.search(ins)
+        if not m or not s:
+            continue
+        src1 = m.group(4)
+        if s.group(2) == "1" and src1.startswith("v"):        # low result <- high dword of a VGPR src1 pair
+            out.append((kernel, ins))
+    return out
+
+
+def lint_library(lib):
+    with tempfile.TemporaryDirectory(prefix="isdf_lint_") as wd:
+        objs = code_objects(lib, wd)
+        if not objs:
+            raise RuntimeError("no gfx950 code object found in %s" % lib)
+        bad = []
+        for o in objs:
+            bad += lint_text(disassemble(o))
+        return len(objs), bad
+
+
+def main():
+    lib = sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(os.path.abspath(__file__)), "libisdf_hip.so")
+    n, bad = lint_library(lib)
+    if bad:
+        print("%s: %d instruction(s) of a form measured to misbehave on MI355X (isdf_amd/isa_lint.py, rule 1):" % (lib, len(bad)))
+        for k, ins in bad[:40]:
+            print("  %s\n      %s" % (k, ins))
+        return 1
+    print("%s: %d code objects, clean" % (lib, n))
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

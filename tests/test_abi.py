@@ -5,6 +5,8 @@ import ctypes as C
 import os
 import re
 
+import numpy as np
+
 import pytest
 
 from isdf_amd import _ffi, build
@@ -50,6 +52,12 @@ def test_size_queries_default_net(lib):
     assert lib.isdf_shadow_bytes(C.byref(full)) == sh and lib.isdf_check_net(C.byref(full)) == 0
     for wide in (NetConfig(fwd_operand="fp16x2_full", n_freqs=9, blocks=3), NetConfig(fwd_operand="fp16x2_full", hidden=512, n_freqs=10)):
         assert lib.isdf_check_net(C.byref(wide.to_c())) == -2     # ISDF_EUNSUPPORTED: four operand regions do not fit those tiles
+    # any hidden_feature_size up to 512 runs zero-padded on the 256 / 512 tiles; the parameter vector keeps the reference's shapes
+    for hidden, blocks, nf in ((64, 1, 6), (64, 3, 11), (128, 2, 6), (300, 2, 6)):
+        nc = NetConfig(hidden=hidden, blocks=blocks, n_freqs=nf)
+        assert lib.isdf_check_net(C.byref(nc.to_c())) == 0
+        assert lib.isdf_param_count(C.byref(nc.to_c())) == sum(int(np.prod(sh)) for _, sh in nc.param_shapes())
+    assert lib.isdf_check_net(C.byref(NetConfig(hidden=513).to_c())) == -2
     bad = NetConfig().to_c()
     bad.fwd_operand = 4
     assert lib.isdf_shadow_bytes(C.byref(bad)) == -1

@@ -1297,3 +1297,45 @@ def test_trained_trajectory_vs_reference(bwd_operand):
     assert m["update5_cos"] > 0.995 and m["update5_rel_l2"] < 0.1, m
     assert abs(m["update5_signed"]) < TOL_UPDATE_SIGNED, m
     assert m["update20_norm_err_max"] < 0.25, m
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Round 4: hidden_feature_size below the tile width.  The reference is parametric in the hidden width (trainer.py:237-238,253);
+# the tile kernels exist for 256 and 512 units.  Narrower nets run on them ZERO-PADDED (NetLayout::H: the fp32 parameters keep the
+# reference's shapes, the packed operand copies and the bias / w_out reads are zero for the padding units, whose adjoints are then
+# exactly zero).  The 64-wide reference fixtures -- oracle pins since round 1 -- become GPU parity cases: hidden_layers_block 1 and 3,
+# n_freqs 6 / 9 / 10 / 11 (the latter three on the <256, 512> tile), bounds ray / pc, L1 / L2, orien_loss, no normals, no transform.
+NARROW_CASES = ["eval_small_ray", "eval_small_pc_l2", "eval_small_nograd", "eval_small_orien", "eval_small_eikonly",
+                "eval_small_b3_f9", "eval_small_b3_f10", "eval_small_b3_f11"]
+
+
+@pytest.mark.parametrize("case", NARROW_CASES)
+def test_narrow_nets_run_zero_padded_vs_reference(case):
+    g = gu.load(case)
+    assert int(g["net"][0]) == 64
+    eng, s, dbg, terms, grads, R = _run_step(g)
+    N = R * s["S"]
+    lcf = gu.loss_of(g)
+    keys = ["sdf_loss", "total_loss"] + (["grad_loss"] if lcf.grad_weight != 0 else []) + (["eikonal_loss"] if lcf.eik_weight != 0 else [])
+    _check_losses(eng, N, g, tol=2 * TOL_LOSS, keys=keys)          # ~3 k points: a 64-wide random-init field is judged at 2e-3
+    x = g["pc"].reshape(-1, 3)
+    sdf, grad = eng.sdf_eval(_dev(x), want_grad=True)
+    e_sdf = _scaled_err(sdf.cpu().numpy(), g["sdf_nonoise"].reshape(-1), 0.14)
+    e_grad = gu.rel_err(grad.cpu().numpy(), g["sdf_grad"].reshape(-1, 3))
+    worst = (0.0, "")
+    for k in gu.params_of(g):
+        got = eng.grad_view(k).cpu().numpy().astype(np.float64) / N
+        assert got.shape == g["grad/" + k].shape                   # the gradient buffer has the REFERENCE's shapes, not the padded ones
+        e = gu.rel_err(got, g["grad/" + k])
+        if e > worst[0]:
+            worst = (e, k)
+    print("%s: sdf (scaled max) %.2e, d sdf/dx rel-L2 %.2e, worst gradient rel-L2 vs the reference %.2e at %s" % (case, e_sdf, e_grad, *worst))
+    assert e_sdf < 2 * TOL_SDF and e_grad < 2 * TOL_SDF_GRAD, (e_sdf, e_grad)
+    # (9-11 PE octaves: the non-smooth loss turns the forward rounding of any 16-bit-operand path into percent-level changes of the
+    #  summed gradient -- test_realsense_config_nets_match_oracle has the analysis; measured here: 1.5e-3 / 2.0e-3 / 2.2e-2)
+    assert worst[0] < (TOL_DW if int(g["net"][2]) <= 6 else 5e-2), worst
+    # one AdamW step through the padded layout: parameters and moments keep the reference's shapes and stay finite
+    p0 = eng.params.clone()
+    eng.adamw()
+    torch.cuda.synchronize()
+    assert torch.isfinite(eng.params).all() and not torch.equal(eng.params, p0) and eng.params.numel() == sum(v.size for v in gu.params_of(g).values())

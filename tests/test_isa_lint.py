@@ -1,0 +1,38 @@
+"""The built device code contains no instruction form this project has measured to misbehave on MI355X (isdf_amd/isa_lint.py:
+round 4's `v_pk_fma_f32 ... op_sel:[0,1,0]` finding).  CPU-side: the library is disassembled, nothing is launched."""
+import os
+import shutil
+
+import pytest
+
+from isdf_amd import _ffi, build, isa_lint
+
+BAD = [
+    "\tv_pk_fma_f32 v[34:35], v[52:53], v[34:35], v[42:43] op_sel:[0,1,0]      // 000000012340: D3B04022 1C8A6934",
+    "\tv_pk_mul_f32 v[2:3], v[4:5], v[6:7] op_sel:[1,1] op_sel_hi:[0,1]",
+    "\tv_pk_add_f32 v[12:13], v[12:13], v[10:11] op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]",
+]
+GOOD = [
+    "\tv_pk_fma_f32 v[34:35], v[34:35], v[52:53], v[42:43] op_sel:[1,0,0]",                    # the same product, selector on src0
+    "\tv_pk_fma_f32 v[42:43], v[50:51], v[34:35], v[72:73] op_sel_hi:[1,0,1]",                 # high result <- low dword of src1: never failed
+    "\tv_pk_fma_f32 v[6:7], v[26:27], v[18:19], v[34:35]",
+    "\tv_pk_add_f32 v[12:13], v[12:13], s[10:11] op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]",   # SGPR pair (the sampler): bit-exact since round 1
+    "\tv_pk_mul_f32 v[44:45], s[58:59], v[18:19]",
+    "\tv_pk_fma_f16 v2, v3, v4, v5 op_sel:[0,1,0]",                                            # not a packed-fp32 op
+]
+
+
+def test_rule_flags_exactly_the_measured_form():
+    text = "0000000000001b00 <kernel_a>:\n" + "\n".join(BAD) + "\n0000000000002b00 <kernel_b>:\n" + "\n".join(GOOD)
+    hits = isa_lint.lint_text(text)
+    assert [k for k, _ in hits] == ["kernel_a"] * len(BAD)
+    assert [i.split()[0] for _, i in hits] == ["v_pk_fma_f32", "v_pk_mul_f32", "v_pk_add_f32"]
+
+
+def test_built_library_is_clean():
+    if not os.path.exists(os.path.join(isa_lint.LLVM_BIN, "llvm-objdump")) and not shutil.which("llvm-objdump"):
+        pytest.skip("no llvm-objdump on this host")
+    build.build(verbose=False)
+    n, bad = isa_lint.lint_library(_ffi.LIB_PATH)
+    assert n >= 5                     # one code object per .hip source
+    assert not bad, bad[:4]

@@ -151,3 +151,29 @@ if [ "$stage" = final2 ]; then      # the records of the FINAL tree (fp16 second
   tail -n 45 $O/round_records2.log
   tail -n 1 $O/native_clock_hip_final2.log
 fi
+
+#   hidden     zero-padded narrow nets (NetLayout::H): the 64-wide reference fixtures as GPU parity cases, then the full GPU suite and
+#              a bench line (the 256-wide default must not have moved)
+if [ "$stage" = hidden ]; then
+  O=gpurun_out/r04hidden; mkdir -p $O
+  timeout 120 python tests/fwd_race_probe.py --reps 20 > $O/race_probe.log 2>&1; lap "race probe rc=$?"
+  grep -v "^JSON" $O/race_probe.log | tail -4
+  timeout 300 python -m pytest tests/test_gpu_parity.py -q -m gpu -k narrow_nets -s > $O/pytest_narrow.log 2>&1; lap "narrow rc=$?"
+  grep "sdf (scaled\|passed\|failed" $O/pytest_narrow.log
+  timeout 600 python -m pytest tests -q -m gpu > $O/pytest_gpu.log 2>&1; lap "pytest gpu rc=$?"
+  tail -5 $O/pytest_gpu.log
+  timeout 300 python bench.py --no-cpu-baseline > $O/bench.json 2> $O/bench.err; lap bench
+  cat $O/bench.json
+fi
+
+#   race       tests/fwd_race_probe.py over variants/lib_*.so: which points of a 27 000-point sdf_eval a misbehaving chain-kernel
+#              build gets wrong (the padded-width change and, earlier, the bias-from-LDS experiment both broke exactly the cases with
+#              more than 256 tiles)
+if [ "$stage" = race ]; then
+  O=gpurun_out/r04race; mkdir -p $O
+  for f in ${RACE_LIBS:-variants/lib_*.so}; do
+    name=$(basename $f .so)
+    ISDF_HIP_LIB=$PWD/$f timeout 120 python tests/fwd_race_probe.py --reps ${RACE_REPS:-15} $([ $name = lib_partk ] && echo --partk) > $O/$name.log 2>&1; lap "$name rc=$?"
+    grep -v "^JSON" $O/$name.log | tail -${RACE_TAIL:-14}
+  done
+fi
