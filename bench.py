@@ -500,13 +500,18 @@ def main():
     # ---- the same synchronised step() once the keyframe set has outgrown the window (K = 8 > window_size = 5): the regime
     # every real run is in after the first few seconds -- `select_keyframes` (trainer.py:652-674, the reference's own code: two
     # device ops + a .cpu()) draws a new window on the host EVERY step; the window travels inline as kernel arguments
-    windowed_ms, transport_ab = None, None
+    windowed_ms, transport_ab, losses_ab = None, None, None
     if group is None and not args.wide:
         K8 = 8
         d8, n8, T8 = (torch.cat([t, t[:K8 - F]]) for t in (tr.frames.depth_batch, tr.frames.normal_batch, tr.frames.T_WC_batch))
         saved = tr.frames
-        frames8 = FrameData(frame_id=np.arange(K8), depth_batch=d8, T_WC_batch=T8, normal_batch=n8,
-                            frame_avg_losses=torch.full((K8,), 0.1, device=dev))
+        def frames_k8(losses):
+            return FrameData(frame_id=np.arange(K8), depth_batch=d8, T_WC_batch=T8, normal_batch=n8, frame_avg_losses=losses,
+                             host_losses=not losses.is_cuda)       # (a device tensor stays on the device: the A/B's other arm)
+        # where the K frame-average losses live once K > window_size: pinned host memory (isdf_amd.frame_store moves them there: the
+        # closing launch writes them zero-copy, select_keyframes runs on the host) or the device (the reference's own FrameData)
+        frames8 = frames_k8(torch.full((K8,), 0.1).pin_memory())
+        frames8_dev = frames_k8(torch.full((K8,), 0.1, device=dev))
 
         def timed_steps(n=n_sync, warm=60):
             for _ in range(warm):
@@ -523,6 +528,9 @@ def main():
             tr.frames = frames8
             transport_ab[label] = {"sync_step_ms_K5": round(fixed, 4), "sync_step_ms_K8_windowed": round(timed_steps(), 4)}
         tr._hip.inline_window = True
+        tr.frames = frames8_dev
+        losses_ab = {"pinned_host (isdf_amd.frame_store)": transport_ab["inline_kernel_arguments"]["sync_step_ms_K8_windowed"],
+                     "device (the reference's FrameData)": round(timed_steps(), 4)}
         tr.frames = saved
         windowed_ms = transport_ab["inline_kernel_arguments"]["sync_step_ms_K8_windowed"]
 
@@ -610,7 +618,10 @@ def main():
             "synchronised_step_windowed": None if windowed_ms is None else {
                 "ms_per_step": round(windowed_ms, 4), "steps_per_s": round(1e3 / windowed_ms, 2), "keyframes": 8, "window": F,
                 "what": "HipTrainer.step() with K = 8 keyframes > window_size: the reference's select_keyframes draws a new window "
-                        "on the host every step (two device ops + a device->host copy), the window goes to the kernels inline",
+                        "on the host every step from frames.frame_avg_losses -- in pinned host memory with isdf_amd.frame_store (the "
+                        "closing launch writes it zero-copy), on the device with the reference's FrameData (two device ops + a "
+                        "synchronising copy per step); the window goes to the kernels inline",
+                "frame_avg_losses_placement_ab": losses_ab,
                 "window_transport_ab": transport_ab},
             "clock_ramp": {"untimed_steps_before_warmup": ramp_steps, "seconds": args.ramp_seconds},
             "chain_us_per_step": {"first5": [round(float(v), 1) for v in chain_us[:5]], "min": round(float(chain_us.min()), 1),

@@ -349,6 +349,13 @@ class HotPath:
 
         K = self.frames.T_WC_batch.shape[0]
         if len(self.frames) > self.window_size and self.incremental:
+            # from here on select_keyframes reads frames.frame_avg_losses EVERY step: a store that can keep them in pinned host
+            # memory (isdf_amd.frame_store; not the reference's FrameData) is asked to, once -- the closing launch then writes
+            # them zero-copy and the draw below never touches the device
+            if hip.device.type == "cuda" and self.frames.frame_avg_losses.device.type == "cuda":
+                to_host = getattr(self.frames, "losses_to_host", None)
+                if to_host is not None:
+                    to_host()
             idxs = self._select_window()               # the reference's select_keyframes; replicated under data parallelism
         else:
             idxs = np.arange(K)
@@ -377,7 +384,9 @@ class HotPath:
 
         fal = self.frames.frame_avg_losses
         fused = hip.dist_group is None and hip.fuse_optimiser
-        direct = fal.is_contiguous() and fal.dtype == torch.float32 and fal.device == hip.device
+        # the kernels write the window's averages straight into the keyframe store: a device tensor (the reference's FrameData), or
+        # pinned host memory (isdf_amd.frame_store: select_keyframes then never touches the device)
+        direct = fal.is_contiguous() and fal.dtype == torch.float32 and (fal.device == hip.device or self._pinned(fal))
         dbg = self._step_kernels(s, sc, fused, (fal, fidx) if direct else None)
         eng = self.engine
         if not fused and direct and hip.fuse_optimiser:
@@ -424,6 +433,16 @@ class HotPath:
         self.tot_step_time += (1 / self.frac_time_perception) * (clock_ms / 1000.0)
         self.steps_since_frame += 1
         return losses, step_time
+
+    def _pinned(self, t):
+        """t is a pinned host tensor the HIP device can write (is_pinned() is a driver query: asked once per buffer)"""
+        hip = self._hip
+        if t.device.type != "cpu" or hip.device.type != "cuda":
+            return False
+        key = (t.data_ptr(), t.numel())
+        if getattr(hip, "pinned_key", None) != key:
+            hip.pinned_key, hip.pinned_ok = key, bool(t.is_pinned())
+        return hip.pinned_ok
 
     def _select_window(self):
         """The reference's window draw (`select_keyframes`, trainer.py:652-674) runs unchanged.  Under data parallelism
@@ -538,6 +557,9 @@ class HotPath:
                 if twin == "im_batch_np":     # the host twin is the raw 0..255 image, the device batch is float in [0, 1]
                     t = (t * 255).round().to(torch.uint8)          # (trainer.py:536-547)
                 setattr(fr, twin, t.cpu().numpy())
+        fal = getattr(fr, "frame_avg_losses", None)
+        if fal is not None and fal.device.type == "cpu" and hip.device.type == "cuda" and not fal.is_pinned():
+            fr.frame_avg_losses = fal.pin_memory()      # the ring store keeps them in pinned host memory (frame_store.py)
         self.frames = fr
         c = sd["clock"]
         self.tot_step_time, self.steps_since_frame = c["tot_step_time"], c["steps_since_frame"]

@@ -1339,3 +1339,54 @@ def test_narrow_nets_run_zero_padded_vs_reference(case):
     eng.adamw()
     torch.cuda.synchronize()
     assert torch.isfinite(eng.params).all() and not torch.equal(eng.params, p0) and eng.params.numel() == sum(v.size for v in gu.params_of(g).values())
+
+
+def test_frame_losses_in_pinned_host_memory_equal_the_device_placement():
+    """isdf_amd.frame_store keeps frames.frame_avg_losses in pinned host memory: the closing launch writes the window's averages
+    there zero-copy and the reference's select_keyframes (trainer.py:652-674) runs on the host.  Same run with the losses on the
+    device (the reference's FrameData placement): identical windows, bit-identical frame averages and parameters, step after step."""
+    from tests.standin_trainer import HipTrainer, FrameData
+    from isdf_amd import synthetic
+    import bench
+    cam = dict(synthetic.SCANNET_CAM)
+    cfg = bench.reference_config()
+    cfg["dataset"]["camera"] = {"w": cam["W"], "h": cam["H"], "fx": cam["fx"], "fy": cam["fy"], "cx": cam["cx"], "cy": cam["cy"]}
+    depth, normal, T = synthetic.keyframes(8, cam, seed=4, stride=30)
+    fal0 = torch.rand(8, generator=torch.Generator().manual_seed(3)) + 0.5
+    runs = {}
+    for place in ("pinned", "device"):
+        np.random.seed(11); torch.manual_seed(11)
+        tr = HipTrainer("cuda", cfg, inv_bounds_transform=synthetic.bounds_transform(), rng="philox")
+        fal = fal0.clone().pin_memory() if place == "pinned" else fal0.clone().cuda()
+        tr.frames = FrameData(frame_id=np.arange(8), depth_batch=_dev(depth), T_WC_batch=_dev(T), normal_batch=_dev(normal),
+                              frame_avg_losses=fal, host_losses=place == "pinned")
+        windows, fals = [], []
+        for i in range(12):
+            tr.step()
+            windows.append([int(v) for v in tr.active_idxs])
+            fals.append(tr.frames.frame_avg_losses.cpu().numpy().copy())
+        assert tr.frames.frame_avg_losses.data_ptr() == fal.data_ptr()          # written in place, not replaced
+        runs[place] = (windows, np.stack(fals), tr.engine.params.cpu().numpy().copy())
+    assert runs["pinned"][0] == runs["device"][0] and len({tuple(w) for w in runs["pinned"][0]}) > 1
+    assert np.array_equal(runs["pinned"][1], runs["device"][1]) and np.array_equal(runs["pinned"][2], runs["device"][2])
+    assert not np.array_equal(runs["pinned"][1][-1], fal0.numpy())
+    # the ring store starts on the device and is moved by the first step that has to draw a window (K > window_size); it grows there
+    np.random.seed(11); torch.manual_seed(11)
+    tr = HipTrainer("cuda", cfg, inv_bounds_transform=synthetic.bounds_transform(), rng="philox")
+    for k in range(8):
+        tr.frames.add_frame_data(FrameData(frame_id=np.arange(k, k + 1), depth_batch=_dev(depth[k:k + 1]), T_WC_batch=_dev(T[k:k + 1]),
+                                           normal_batch=_dev(normal[k:k + 1])), replace=False)
+        assert tr.frames.frame_avg_losses.is_cuda
+        if k == 4:
+            tr.step()                                    # K = 5 = window_size: nothing to draw, the losses stay on the device
+            assert tr.frames.frame_avg_losses.is_cuda and float(tr.frames.frame_avg_losses.min()) > 0
+            kept = tr.frames.frame_avg_losses.cpu().numpy().copy()
+    tr.step()
+    fal = tr.frames.frame_avg_losses
+    assert fal.device.type == "cpu" and fal.is_pinned() and fal.shape == (8,) and tr.frames.depth_batch.is_cuda
+    assert all(fal[i] == kept[i] or i in tr.active_idxs for i in range(5)) and all(float(fal[i]) > 0 for i in tr.active_idxs)
+    tr.frames.add_frame_data(FrameData(frame_id=np.arange(8, 9), depth_batch=_dev(depth[:1]), T_WC_batch=_dev(T[:1]),
+                                       normal_batch=_dev(normal[:1])), replace=False)
+    assert tr.frames.frame_avg_losses.is_pinned() and tr.frames.frame_avg_losses.shape == (9,) and float(tr.frames.frame_avg_losses[8]) == 0
+    tr.step()
+    assert float(tr.frames.frame_avg_losses[8]) > 0      # the newest keyframe is always in the window

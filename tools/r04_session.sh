@@ -177,3 +177,19 @@ if [ "$stage" = race ]; then
     grep -v "^JSON" $O/$name.log | tail -${RACE_TAIL:-14}
   done
 fi
+
+#   pinned     tools/probes/pk_fma_opsel (the instruction form of isa_lint rule 1 in isolation), the pinned-host frame_avg_losses
+#              test, a bench line with the placement A/B
+if [ "$stage" = pinned ]; then
+  O=gpurun_out/r04pinned; mkdir -p $O
+  timeout 120 tools/probes/pk_fma_opsel ${PK_ITERS:-4000} > $O/pk_fma_opsel.txt 2>&1; lap "pk probe rc=$?"
+  cat $O/pk_fma_opsel.txt
+  timeout 300 python -m pytest tests/test_gpu_parity.py -q -m gpu -k "pinned_host or trainer_step_contract or checkpoint or driver_schedule" > $O/pytest_pinned.log 2>&1; lap "pytest rc=$?"
+  tail -4 $O/pytest_pinned.log
+  timeout 300 python bench.py --no-cpu-baseline > $O/bench.json 2> $O/bench.err; lap bench
+  python - <<'PY'
+import json
+j = json.loads(open("gpurun_out/r04pinned/bench.json").read().strip().split("\n")[-1])
+print("value", j["value"], "sync ms", j["trainer_step_sync_ms"], "windowed", json.dumps(j["synchronised_step_windowed"])[:900])
+PY
+fi
