@@ -10,7 +10,11 @@
 #              accuracy control 40 seeds each, window-transport A/B inside the bench line
 #   accuracy   fp32 eager-GPU control vs the HIP path (HEAD and the reverted d490710 variant) on 10 shared seeds, the
 #              trained-weights gradient-bias probe for both libraries, reference-driver schedule and native-clock runs
-# Outputs land in gpurun_out/r04/ (scratch); what is judged is copied to profiles/ by hand.
+#   hidden     zero-padded narrow nets (the 64-wide reference fixtures on the GPU), fwd_race_probe on the in-tree library, full GPU
+#              suite, a bench line
+#   race       tests/fwd_race_probe.py over variants/lib_*.so (source-patch and ISA-edit variants: the v_pk_fma_f32 op_sel hunt)
+#   pinned     tools/probes/pk_fma_opsel (the instruction form in isolation), frame_avg_losses in pinned host memory: test + bench A/B
+# Outputs land in gpurun_out/r04*/ (scratch); what is judged is copied to profiles/ by hand.
 set -u
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
