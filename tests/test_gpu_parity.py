@@ -139,7 +139,7 @@ def test_input_gradient_vs_reference_fixture():
 
 
 def _run_step(g, bounds_method=None, loss_type=None, fwd_operand="fp16x2", oracle=True, identity_transform=False,
-              with_normals=None, bwd_operand=None, **loss_over):
+              with_normals=None, bwd_operand=None, linearised=False, **loss_over):
     """HIP sampler (injected draws) + training step on a fixture, and the oracle on the same inputs.
     loss_over: LossConfig fields to override on both sides (orien_loss=True, eik_weight=0.0, ...)."""
     if identity_transform:
@@ -177,9 +177,12 @@ def _run_step(g, bounds_method=None, loss_type=None, fwd_operand="fp16x2", oracl
     # the sampler's outputs (bit-exact gathers, z / pc within 1e-6 of the reference: sampler tests) feed the oracle
     pc, z = s["pc"][:R].cpu().numpy(), s["z_vals"][:R].cpu().numpy()
     T_WC_sample = g["T_WC_batch"][s["indices_b"][:R].cpu().numpy()]
-    terms, grads = orc.loss_and_grads(params, cfg, lco, pc, z, s["depth_sample"][:R].cpu().numpy(),
-                                      s["dirs_C_sample"][:R].cpu().numpy(), T_WC_sample,
-                                      s["norm_sample"][:R].cpu().numpy() if with_normals else None, noise=noise)
+    oargs = (params, cfg, lco, pc, z, s["depth_sample"][:R].cpu().numpy(), s["dirs_C_sample"][:R].cpu().numpy(), T_WC_sample,
+             s["norm_sample"][:R].cpu().numpy() if with_normals else None)
+    terms, grads = orc.loss_and_grads(*oargs, noise=noise)
+    if linearised:      # the backward arithmetic alone: loss adjoints evaluated at the outputs the kernel itself produced
+        hip_out = (dbg["sdf"][:R].cpu().numpy(), dbg["sdf_grad"][:R].cpu().numpy())
+        dbg["grads_lin"] = orc.loss_and_grads(*oargs, noise=noise, adjoints_from=hip_out)[1]
     return eng, s, dbg, terms, grads, R
 
 
@@ -804,27 +807,29 @@ def test_hip_step_x3_default_net_vs_reference_fixture(fused):
     frame_avg_losses vs the reference, the AdamW moments tensor by tensor vs the oracle trajectory (exp_avg is
     linear in the gradients: 1e-2; exp_avg_sq quadratic: 2e-2), and the reference's digests of the parameter
     update and both moments."""
-    from tests.test_oracle_golden import replay_step_fixture, check_step_digests
+    from tests.test_oracle_golden import replay_step_fixture, check_step_digests, step_digest_deviations
     g = gu.load("step_full_k7")
     eng = _engine(g)
     lc, sc = _cfgs(g)
     n = int(g["n_steps"][0])
     res = _replay_hip_steps(g, eng, lc, sc, n, fused)
     S = sc.S
+    worst_loss, worst_fal = [0.0, 0.0], 0.0
     for st, r in enumerate(res):
         N = r["R"] * S
         assert r["ls"][4] == N
-        # Step 0 runs on identical weights: 1e-3.  From step 1 on the weights differ: AdamW's first update is
-        # exactly -lr*sign(g) per element (m_hat/sqrt(v_hat) = g/|g|), so every element whose gradient is smaller
-        # than the gradient error (~1 % of them at 1e-2 relative accuracy, and likewise for ANY finite accuracy)
-        # lands 2*lr = 2.6e-3 away from the reference's value -- a 4 % perturbation of ~1 % of the weights, i.e.
-        # loss deviations of a few 1e-3 (measured 2.4e-3 on grad_loss).  The tight trajectory check is on the
-        # moments below.
-        tol = TOL_LOSS if st == 0 else 5e-3
+        # Step 0 runs on identical weights; from step 1 on they differ by the first AdamW updates (-lr*sign(g) per element: an
+        # element whose gradient is smaller than the gradient error lands 2*lr away from the reference's value).  With bf16
+        # second-order sweeps (rounds 1-3) that cost a few 1e-3 on the later steps' losses and the bar was 5e-3; with the fp16
+        # sweeps the measured deviations are 5e-5 (step 0) and 1.8e-4 (steps 1-2): 1e-3 on every step.
+        tol = TOL_LOSS
         for k, name in [(0, "sdf_loss"), (1, "grad_loss"), (2, "eikonal_loss"), (3, "total_loss")]:
             ref = g["s%d/%s" % (st, name)][0]
+            worst_loss[min(st, 1)] = max(worst_loss[min(st, 1)], abs(r["ls"][k] / N - ref) / abs(ref))
             assert abs(r["ls"][k] / N - ref) < tol * abs(ref), (st, name, r["ls"][k] / N, ref)
-        np.testing.assert_allclose(r["fal"], g["s%d/frame_avg_losses" % st], rtol=5 * tol, atol=1e-6)
+        ref_fal = g["s%d/frame_avg_losses" % st]
+        worst_fal = max(worst_fal, float(np.max(np.abs(r["fal"] - ref_fal) / np.maximum(np.abs(ref_fal), 1e-6))))
+        np.testing.assert_allclose(r["fal"], ref_fal, rtol=2e-3, atol=1e-6)           # measured 1.9e-4
     # oracle trajectory on the same fixture (pinned to the reference by tests/test_oracle_golden.py)
     cfg, lco, params = gu.net_of(g), gu.loss_of(g), gu.params_of(g)
     init = {k: v.astype(np.float64) for k, v in params.items()}
@@ -832,17 +837,22 @@ def test_hip_step_x3_default_net_vs_reference_fixture(fused):
     state = orc.new_adam_state()
     replay_step_fixture(g, lambda s_, idxs, frames, draws: orc.train_step(params, state, cfg, lco, frames, cam, sco, draws))
     hip_p, hip_m, hip_v = {}, {}, {}
+    worst_m = worst_v = 0.0
     for k, (off, shp) in eng.slices.items():
         cnt = int(np.prod(shp))
         hip_p[k] = eng.params[off:off + cnt].view(*shp).cpu().numpy()
         hip_m[k] = eng.exp_avg[off:off + cnt].view(*shp).cpu().numpy()
         hip_v[k] = eng.exp_avg_sq[off:off + cnt].view(*shp).cpu().numpy()
-        assert gu.rel_err(hip_m[k], state["exp_avg"][k]) < TOL_DW, (k, gu.rel_err(hip_m[k], state["exp_avg"][k]))
-        assert gu.rel_err(hip_v[k], state["exp_avg_sq"][k]) < 2 * TOL_DW, (k, gu.rel_err(hip_v[k], state["exp_avg_sq"][k]))
-    # ... and the reference's own digests of both moments.  The digest of the parameter UPDATE is only a sanity bound
-    # (15 %): three steps in, the update is ~lr*sign(g) per element, i.e. decided by the SIGN of near-zero gradients; the
-    # moments above and here carry the trajectory check.
-    check_step_digests(g, hip_p, init, hip_m, hip_v, 0.15, TOL_DW, 2 * TOL_DW)
+        worst_m, worst_v = max(worst_m, gu.rel_err(hip_m[k], state["exp_avg"][k])), max(worst_v, gu.rel_err(hip_v[k], state["exp_avg_sq"][k]))
+        assert gu.rel_err(hip_m[k], state["exp_avg"][k]) < 4e-3, (k, gu.rel_err(hip_m[k], state["exp_avg"][k]))          # measured 1.9e-3
+        assert gu.rel_err(hip_v[k], state["exp_avg_sq"][k]) < 3e-3, (k, gu.rel_err(hip_v[k], state["exp_avg_sq"][k]))   # measured 9.7e-4
+    # ... and the reference's own digests of the parameter update and both moments (measured: 1.9e-3 / 1.1e-4 / 1.5e-4; rounds 1-3
+    # judged the update digest at 15 %: three steps in it is ~lr*sign(g) per element, and the bf16 sweeps flipped enough signs)
+    dev = step_digest_deviations(g, hip_p, init, hip_m, hip_v)
+    print("step x3 (fused %s): losses step 0 %.2e, steps 1-2 %.2e; frame averages %.2e; exp_avg %.2e / exp_avg_sq %.2e vs the oracle; "
+          "reference digests: update %.2e, exp_avg %.2e, exp_avg_sq %.2e" % (fused, worst_loss[0], worst_loss[1], worst_fal, worst_m, worst_v,
+                                                                              dev["param_after_"], dev["exp_avg_"], dev["exp_avg_sq_"]))
+    check_step_digests(g, hip_p, init, hip_m, hip_v, 1e-2, 2e-3, 2e-3, head_p=0.6)
 
 
 @pytest.mark.parametrize("name,kw", [
@@ -1130,8 +1140,12 @@ SHAPE_CASES = ["eval_wide_512", "eval_rs_realsense", "eval_rs_franka", "eval_rs_
 # loss.py:122-164, trainer.py:814-816) and with 9-11 PE octaves a random-init field oscillates so fast that the forward
 # rounding of a 16-bit-operand implementation flips some of those signs; measured bounds per fixture (rel to the norm)
 # (measured worst deviation: 4.6e-3, 3.9e-3, 1.7e-2, 6.0e-3 -- only scale_input 0.4, the fastest-oscillating field, leaves 1e-2)
-SHAPE_DW_TOL = {"eval_wide_512": 1e-2, "eval_rs_realsense": 1e-2, "eval_rs_franka": 3e-2, "eval_rs_franka_offline": 1e-2,
-                "eval_b1_256": 1e-2}
+# measured with the default operand types (fp16 second-order sweeps): 1.9e-3 / 6.6e-4 / 1.64e-2 / 3.6e-3 / 5.6e-4.  eval_rs_franka
+# (scale_input 0.4: the fastest-oscillating field of the shipped configs) is the non-smooth-loss case -- the forward rounding flips
+# loss branches -- so its END-TO-END bar stays at 3e-2 while the backward arithmetic alone is held to SHAPE_DW_LIN_TOL like the rest
+SHAPE_DW_TOL = {"eval_wide_512": 4e-3, "eval_rs_realsense": 2e-3, "eval_rs_franka": 3e-2, "eval_rs_franka_offline": 8e-3,
+                "eval_b1_256": 2e-3}
+SHAPE_DW_LIN_TOL = 6e-3        # measured 0.6e-3 .. 3.0e-3 (eval_rs_franka: 2.7e-3)
 
 
 @pytest.mark.parametrize("case", SHAPE_CASES)
@@ -1159,7 +1173,7 @@ def test_other_network_shapes_vs_reference(case):
     assert err < TOL_SDF, err
     assert gerr < TOL_SDF_GRAD, gerr
     # training step: the four loss means and the digests of all gradient tensors vs the reference; then vs the oracle
-    eng, s, dbg, terms, grads, R = _run_step(g)
+    eng, s, dbg, terms, grads, R = _run_step(g, linearised=True)
     N = R * s["S"]
     _check_losses(eng, N, g)
     _check_losses(eng, N, terms)
@@ -1173,7 +1187,10 @@ def test_other_network_shapes_vs_reference(case):
         nrm, dot = g["gdig/" + k]
         worst = max(worst, abs(np.linalg.norm(v) - nrm) / nrm, abs((v * probe).sum() - dot) / (nrm * np.sqrt(v.size)),
                     gu.rel_err(v, grads[k]))
-    print("%s: worst gradient deviation (reference norm / probe digests, oracle rel-L2) %.3e" % (case, worst))
+    worst_lin = max(gu.rel_err(eng.grad_view(k).cpu().numpy().astype(np.float64) / N, dbg["grads_lin"][k]) for k in grads)
+    print("%s: worst gradient deviation (reference norm / probe digests, oracle rel-L2) %.3e; backward arithmetic alone (adjoints at "
+          "the kernel's own outputs) %.3e" % (case, worst, worst_lin))
+    assert worst_lin < SHAPE_DW_LIN_TOL, worst_lin
     _check_grads_vs_reference_digest(eng, N, g, tol=SHAPE_DW_TOL[case])
     _check_grads_vs_oracle(eng, N, grads, tol=SHAPE_DW_TOL[case])
 

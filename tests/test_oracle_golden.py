@@ -192,8 +192,10 @@ def replay_step_fixture(g, step_fn):
         np.testing.assert_allclose(fal, g["s%d/frame_avg_losses" % s], rtol=out.get("fa_rtol", 5e-4), atol=1e-6)
 
 
-def check_step_digests(g, params, init, exp_avg, exp_avg_sq, tol_p, tol_m, tol_v):
-    """final parameter UPDATE and AdamW moments vs the (norm, probe dot, first 64 values) digests of the reference"""
+def check_step_digests(g, params, init, exp_avg, exp_avg_sq, tol_p, tol_m, tol_v, head_p=None):
+    """final parameter UPDATE and AdamW moments vs the (norm, probe dot, first 64 values) digests of the reference.
+    head_p: separate bound for the first 64 VALUES of the update (a 16-bit-operand path flips the sign of a few near-zero
+    gradients, and one flipped element of an early AdamW update is off by 2*lr whatever the accuracy of the rest)"""
     prng = np.random.RandomState(4321)
     for k in params:
         for prefix, v, tol in (("param_after_", np.asarray(params[k], np.float64) - init[k], tol_p),
@@ -204,7 +206,21 @@ def check_step_digests(g, params, init, exp_avg, exp_avg_sq, tol_p, tol_m, tol_v
             assert abs(np.linalg.norm(v) - nrm) < tol * nrm, (prefix, k, np.linalg.norm(v), nrm)
             assert abs((v * probe).sum() - dot) < tol * nrm * np.sqrt(v.size), (prefix, k)
             head = g[prefix + "head/" + k]
-            assert np.abs(v.reshape(-1)[:64] - head).max() < 4 * tol * max(np.abs(head).max(), nrm / np.sqrt(v.size)), (prefix, k)
+            htol = head_p if (head_p is not None and prefix == "param_after_") else 4 * tol
+            assert np.abs(v.reshape(-1)[:64] - head).max() < htol * max(np.abs(head).max(), nrm / np.sqrt(v.size)), (prefix, k)
+
+
+def step_digest_deviations(g, params, init, exp_avg, exp_avg_sq):
+    """worst relative deviation (norm, probe dot) per quantity from the reference's digests: what check_step_digests bounds"""
+    prng = np.random.RandomState(4321)
+    worst = {"param_after_": 0.0, "exp_avg_": 0.0, "exp_avg_sq_": 0.0}
+    for k in params:
+        for prefix, v in (("param_after_", np.asarray(params[k], np.float64) - init[k]), ("exp_avg_", exp_avg[k]), ("exp_avg_sq_", exp_avg_sq[k])):
+            v = np.asarray(v, np.float64)
+            probe = prng.standard_normal(v.shape)
+            nrm, dot = g[prefix + "dig/" + k]
+            worst[prefix] = max(worst[prefix], abs(np.linalg.norm(v) - nrm) / nrm, abs((v * probe).sum() - dot) / (nrm * np.sqrt(v.size)))
+    return worst
 
 
 def test_default_net_trainer_step_x3_matches_reference():
