@@ -196,7 +196,13 @@ def _check_losses(eng, N, ref, tol=TOL_LOSS, keys=("sdf_loss", "grad_loss", "eik
         assert abs(got - want) <= tol * abs(want) + 1e-12, (name, got, want)
 
 
-def _check_grads_vs_oracle(eng, N, grads, tol=TOL_DW):
+def _dw_tol(eng):
+    """gradient bar by the operand type of the second-order sweeps: fp16 (default) 3e-3, bf16 1e-2 (measured 0.5e-3 .. 1.2e-3 / 3.1e-3 .. 4.4e-3)"""
+    return TOL_DW_BWD16 if int(eng.cnet.bwd_operand) == 1 else TOL_DW
+
+
+def _check_grads_vs_oracle(eng, N, grads, tol=None):
+    tol = _dw_tol(eng) if tol is None else tol
     worst = (0.0, 1.0, "")
     for k in grads:
         got = (eng.grad_view(k).cpu().numpy().astype(np.float64) / N).reshape(-1)
@@ -208,7 +214,8 @@ def _check_grads_vs_oracle(eng, N, grads, tol=TOL_DW):
     print("weight gradients vs oracle (N=%d): worst rel-L2 %.2e (cos %.6f) at %s" % ((N,) + worst))
 
 
-def _check_grads_vs_reference_digest(eng, N, g, tol=TOL_DW):
+def _check_grads_vs_reference_digest(eng, N, g, tol=None):
+    tol = _dw_tol(eng) if tol is None else tol
     prng = np.random.RandomState(1234)
     for k in gu.params_of(g):
         v = eng.grad_view(k).cpu().numpy().astype(np.float64) / N
@@ -247,7 +254,7 @@ def test_train_step_losses_and_gradients(bm, lt):
         got = (eng.grad_view(k).cpu().numpy().astype(np.float64) / N).reshape(-1)
         ref = grads[k].astype(np.float64).reshape(-1)
         cos = got @ ref / (np.linalg.norm(got) * np.linalg.norm(ref))
-        assert cos > 0.999 and gu.rel_err(got, ref) < TOL_DW, (k, cos, gu.rel_err(got, ref))
+        assert cos > 0.999 and gu.rel_err(got, ref) < _dw_tol(eng), (k, cos, gu.rel_err(got, ref))
 
 
 def test_train_step_vs_reference_fixture_digest():
@@ -263,8 +270,8 @@ def test_train_step_vs_reference_fixture_digest():
         v = eng.grad_view(k).cpu().numpy().astype(np.float64) / N
         probe = prng.standard_normal(v.shape)
         nrm, dot = g["gdig/" + k]
-        assert abs(np.linalg.norm(v) - nrm) < TOL_DW * nrm, k
-        assert abs((v * probe).sum() - dot) < TOL_DW * nrm * np.sqrt(v.size), k
+        assert abs(np.linalg.norm(v) - nrm) < _dw_tol(eng) * nrm, k
+        assert abs((v * probe).sum() - dot) < _dw_tol(eng) * nrm * np.sqrt(v.size), k
 
 
 def test_adamw_matches_oracle_given_identical_grads():
@@ -877,7 +884,7 @@ def test_train_step_config_coverage_vs_oracle(name, kw):
         keys.append("eikonal_loss")
     _check_losses(eng, N, terms, tol=(8 if bf16 else 1) * TOL_LOSS, keys=keys)
     assert gu.rel_err(dbg["sdf"][:R].cpu().numpy(), terms["sdf"]) < (8e-3 if bf16 else TOL_SDF)
-    _check_grads_vs_oracle(eng, N, grads, tol=(3 if bf16 else 1) * TOL_DW)
+    _check_grads_vs_oracle(eng, N, grads, tol=3 * TOL_DW if bf16 else None)
 
 
 @pytest.mark.parametrize("blocks,n_freqs,E", [(2, 9, 381), (3, 11, 465)])
@@ -927,7 +934,7 @@ def test_realsense_config_nets_match_oracle(blocks, n_freqs, E):
     # adjoints evaluated at the outputs the kernel itself produced: 1e-2 / 1.5e-2 like everywhere else ...
     hip_out = (dbg["sdf"][:R].cpu().numpy(), dbg["sdf_grad"][:R].cpu().numpy())
     _, grads_lin = orc.loss_and_grads(*oargs, noise=noise, adjoints_from=hip_out)
-    _check_grads_vs_oracle(eng, N, grads_lin, tol=1.5 * TOL_DW)
+    _check_grads_vs_oracle(eng, N, grads_lin, tol=TOL_DW)          # measured 3.2e-3 / 7.0e-3
     # ... and end to end (adjoints from the oracle's own fp32 forward) by direction
     worst_cos, worst_rel = 1.0, 0.0
     for k in grads:
