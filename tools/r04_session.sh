@@ -197,3 +197,13 @@ j = json.loads(open("gpurun_out/r04pinned/bench.json").read().strip().split("\n"
 print("value", j["value"], "sync ms", j["trainer_step_sync_ms"], "windowed", json.dumps(j["synchronised_step_windowed"])[:900])
 PY
 fi
+
+if [ "$stage" = final3 ]; then      # the records of the FINAL tree of round 4 (padded widths, element-pair reduction, pinned frame losses)
+  python -m pytest tests -q -m gpu -s > $O/pytest_gpu_final3.log 2>&1; lap pytest gpu
+  bash tools/round_records.sh 04 > $O/round_records3.log 2>&1; lap records
+  cd $GRAFT_REPO_ROOT
+  python tests/accuracy_experiment.py --native-clock --backend hip --seeds $SEEDS5 --out $O/native_clock_hip_final3.json > $O/native_clock_hip_final3.log 2>&1; lap native hip
+  tail -n 4 $O/pytest_gpu_final3.log
+  tail -n 45 $O/round_records3.log
+  tail -n 1 $O/native_clock_hip_final3.log
+fi
