@@ -224,7 +224,6 @@ __global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 && EP == HD && !oper_x2_a
   const rsrc_t rsW = make_rsrc(p.shadow, 0x7fffffffu);
   const rsrc_t rsS = make_rsrc(spillTile, (uint32_t)(p.sp.tileStride * 2));   // loads (compiler-tracked)
   const i32x4 srdS = make_srd(spillTile, (uint32_t)(p.sp.tileStride * 2));     // stores (bstore16_nt)
-  const rsrc_t rsP = make_rsrc(p.params, 0x7fffffffu);
   // byte offset of this wave's first piece of a spilled tensor (frag16 order, see frag16_off)
   auto sbase = [&](int64_t tensorOff) { return (int)(tensorOff * 2) + w * (FB * PB * 2) * 1024; };
   constexpr auto cidx = [](int fb, int pb, int qp) { return (fb * PB + pb) * 2 + qp; };   // piece-of-64-lanes index within the wave
@@ -233,23 +232,16 @@ __global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 && EP == HD && !oper_x2_a
   (void)setFwdB; (void)setBwdB; (void)setFwdLo; (void)rsS; (void)rsV; (void)srdS;
   // feature index of (fb, qp) blocks: f0 = ubase(fb, qp) + 4*hi
   auto ubase = [&](int fb, int qp) { return w * (FB * 32) + fb * 32 + 16 * qp; };
-  // 8 fp32 parameters params[off + f0 + {0..3, 8..11}]
-  // vecBase: flat offset of a per-unit vector (a bias, w_out), ub: the block's first unit.  Units >= L.H are padding (a hidden width
-  // below the tile width, NetLayout::H): they read as 0 and nothing past the real vector is touched.
+  // 8 fp32 parameters of a per-unit vector (a bias, w_out) at flat offset vecBase: units ub + 4*hi + {0..3, 8..11}.  Units >= L.H are
+  // padding (a hidden width below the tile width, NetLayout::H): they read as 0 and nothing past the real vector is touched.
   auto ld_params8 = [&](int vecBase, int ub, float (&o)[8]) {
-    if (L.H == HD) {
-      const int offUniform = vecBase + ub;
-      const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rsP, 16 * hi, offUniform * 4, 0);
-      const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(rsP, 16 * hi + 32, offUniform * 4, 0);
+    // a buffer descriptor over exactly this vector: every dword at or beyond unit L.H is out of range and reads as 0 (the range check of
+    // a raw buffer load is per dword), so a narrower net needs no mask and no branch here
+    const rsrc_t rv = make_rsrc(p.params + vecBase, (uint32_t)L.H * 4u);
+    const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rv, 16 * hi, ub * 4, 0);
+    const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(rv, 16 * hi + 32, ub * 4, 0);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { o[e] = __uint_as_float(a[e]); o[4 + e] = __uint_as_float(b[e]); }
-    } else {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const int f = ub + 4 * hi + (e & 3) + 8 * (e >> 2);
-        o[e] = f < L.H ? p.params[vecBase + f] : 0.f;
-      }
-    }
+    for (int e = 0; e < 4; ++e) { o[e] = __uint_as_float(a[e]); o[4 + e] = __uint_as_float(b[e]); }
   };
   // per-workgroup partial of a bias / out-layer gradient entry: sum over the half-wave's 32 points
   // The 8 values of an accumulator block (features elemUniform + 4*hi + {0..3, 8..11}) go out in ONE store: after the butterflies
@@ -807,14 +799,9 @@ __global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 && EP == HD && !oper_x2_a
 
   TS();   // (loss sums written)
   // ------------------------------------------------------------------ Ebar = J_pe gbar  -> region 2 (bf16)
-  if (tid < HD / 4) {   // w_out for the top epilogue (0 for the padding units of a narrower net)
-    float4 wv4;
-    if (L.H == HD) wv4 = ((const float4*)(p.params + L.offWout))[tid];
-    else {
-      const float* wo = p.params + L.offWout;
-      const int f = 4 * tid;
-      wv4 = make_float4(f < L.H ? wo[f] : 0.f, f + 1 < L.H ? wo[f + 1] : 0.f, f + 2 < L.H ? wo[f + 2] : 0.f, f + 3 < L.H ? wo[f + 3] : 0.f);
-    }
+  if (tid < HD / 4) {   // w_out for the top epilogue (0 for the padding units of a narrower net: out of the descriptor's range)
+    const u32x4 w4 = __builtin_amdgcn_raw_buffer_load_b128(make_rsrc(p.params + L.offWout, (uint32_t)L.H * 4u), tid * 16, 0, 0);
+    const float4 wv4 = make_float4(__uint_as_float(w4[0]), __uint_as_float(w4[1]), __uint_as_float(w4[2]), __uint_as_float(w4[3]));
     ((float4*)part)[tid] = wv4;
   }
   {

@@ -1417,7 +1417,7 @@ def test_frame_losses_in_pinned_host_memory_equal_the_device_placement():
 
 
 @pytest.mark.parametrize("hidden,blocks,n_freqs,tile", [(300, 2, 6, "<512, 512>"), (128, 1, 9, "<256, 512>"), (96, 3, 4, "<256, 256>"),
-                                                        (500, 1, 10, "<512, 512>")])
+                                                        (500, 1, 10, "<512, 512>"), (250, 2, 6, "<256, 256>"), (61, 2, 5, "<256, 256>")])
 def test_odd_hidden_widths_match_oracle(hidden, blocks, n_freqs, tile):
     """Zero-padded widths on each of the three tile instantiations (the 64-wide REFERENCE fixtures above only reach the 256-wide ones):
     forward, input gradient, losses, all gradient tensors in the reference's shapes, and the fused AdamW step against the oracle's
