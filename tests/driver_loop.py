@@ -8,7 +8,7 @@ it only talks to the public `Trainer` surface
 so it runs unchanged against a grafted reference `Trainer`, a `HipTrainer`, or a CPU port."""
 
 
-def run_train_loop(trainer, get_frame, size_dataset, n_steps, incremental=True, on_step=None, t0=0):
+def run_train_loop(trainer, get_frame, size_dataset, n_steps, incremental=True, on_step=None, t0=0, first_frame_iters=200):
     """get_frame(frame_id) -> FrameData for `trainer.add_frame` (the drivers call trainer.get_data([id])).
     t0: step counter to continue from (t == 0 is the drivers' special first iteration).
     Returns (next step counter, list of (step, frame_id) ingests, last losses)."""
@@ -29,7 +29,7 @@ def run_train_loop(trainer, get_frame, size_dataset, n_steps, incremental=True, 
                 ingests.append((t, new_frame_id))
                 if t == 0:
                     trainer.last_is_keyframe = True                                  # train.py:125-127
-                    trainer.optim_frames = 200
+                    trainer.optim_frames = first_frame_iters                         # 200 in the drivers; CPU tests shorten it
         losses, step_time = trainer.step()                                           # train.py:136
         if on_step is not None:
             on_step(t, losses, step_time)

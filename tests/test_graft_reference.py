@@ -172,14 +172,15 @@ def _stream(n, H=48, W=64):
     return depth, T
 
 
-def _drive(tr, depth, T, n_steps, get_frame):
+def _drive(tr, depth, T, n_steps, get_frame, first_frame_iters=60):
     log = []
 
     def on_step(t, losses, ms):
         log.append(dict(t=t, clock=tr.tot_step_time, ssf=tr.steps_since_frame, noise=tr.noise_std, K=len(tr.frames),
                         kf=tr.last_is_keyframe, total=float(losses["total_loss"])))
     with contextlib.redirect_stdout(io.StringIO()):
-        n, ingests, losses = run_train_loop(tr, get_frame, depth.shape[0], n_steps, on_step=on_step)
+        # (the drivers optimise the first frame alone for 200 steps, train.py:125-127: 60 here -- every step runs the numpy oracle)
+        n, ingests, losses = run_train_loop(tr, get_frame, depth.shape[0], n_steps, on_step=on_step, first_frame_iters=first_frame_iters)
     return n, ingests, log
 
 
@@ -223,7 +224,7 @@ def test_reference_driver_loop_on_grafted_reference_trainer(ref_mods):
     np.random.seed(3); torch.manual_seed(3)
     with contextlib.redirect_stdout(io.StringIO()):
         graft(tr, rng="torch", virtual_step_ms=12.0, engine_factory=FakeEngine)
-    n, ingests, log = _drive(tr, depth, T, 300, lambda i: tr.get_data([i]))
+    n, ingests, log = _drive(tr, depth, T, 160, lambda i: tr.get_data([i]))
     _check_schedule(tr, n, ingests, log, 12.0, 30, 3, 0.08, 0.04)
     assert isinstance(tr.frozen_sdf_map, SDFMapHIP) and tr.frozen_sdf_map is not tr.sdf_map   # deepcopy at trainer.py:576
     assert tr.frozen_sdf_map.engine is not tr.sdf_map.engine
@@ -243,7 +244,7 @@ def test_reference_driver_loop_on_hiptrainer_standin():
     np.random.seed(3); torch.manual_seed(3)
     tr = HipTrainer("cpu", cfg, inv_bounds_transform=gu.bounds_transform(), rng="philox", seed=3,
                     virtual_step_ms=12.0, engine_factory=FakeEngine)
-    n, ingests, log = _drive(tr, depth, T, 300, lambda i: tr.make_frame(i, depth[i], T[i]))
+    n, ingests, log = _drive(tr, depth, T, 160, lambda i: tr.make_frame(i, depth[i], T[i]))
     _check_schedule(tr, n, ingests, log, 12.0, 30, 3, 0.08, 0.04)
     # checkpoint while a NON-keyframe is being optimised, resume in a fresh trainer, keyframe test still works
     t = n
