@@ -330,11 +330,12 @@ def test_bounds_pc_against_gathered_surface_set():
         np.testing.assert_allclose(got_g[ok], g_ref[rows][ok], rtol=0, atol=2e-4)
 
 
-def test_fused_adamw_step_is_bit_identical_to_two_call_path():
+@pytest.mark.parametrize("case", ["eval_full_ray", "eval_small_b3_f11"])      # default net; a 64-wide net zero-padded on the <256, 512> tile
+def test_fused_adamw_step_is_bit_identical_to_two_call_path(case):
     """isdf_train_step_adamw (single-GPU tail: slab reduction + AdamW + operand repack + finalisation in one
     launch) must leave exactly the state isdf_train_step followed by isdf_adamw leaves: fp32 parameters,
     both moments, all four packed 16-bit operand sets, and the reduce buffer."""
-    g = gu.load("eval_full_ray")
+    g = gu.load(case)
     lc, sc = _cfgs(g)
     F = g["depth_batch"].shape[0]
     idx = torch.arange(F, dtype=torch.int32, device="cuda")
