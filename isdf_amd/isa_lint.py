@@ -59,7 +59,7 @@ def lint_text(text):
         if not m or not s:
             continue
         src1 = m.group(4)
-        if s.group(2) == "1" and src1.startswith("v"):        # low result <- high dword of a VGPR src1 pair
+        if s.group(2) == "1" and src1[:1] in ("v", "a"):      # low result <- high dword of a VGPR (or AGPR) src1 pair
             out.append((kernel, ins))
     return out
 

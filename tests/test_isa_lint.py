@@ -11,6 +11,7 @@ BAD = [
     "\tv_pk_fma_f32 v[34:35], v[52:53], v[34:35], v[42:43] op_sel:[0,1,0]      // 000000012340: D3B04022 1C8A6934",
     "\tv_pk_mul_f32 v[2:3], v[4:5], v[6:7] op_sel:[1,1] op_sel_hi:[0,1]",
     "\tv_pk_add_f32 v[12:13], v[12:13], v[10:11] op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]",
+    "\tv_pk_fma_f32 v[2:3], v[4:5], a[6:7], v[8:9] op_sel:[0,1,0]",
 ]
 GOOD = [
     "\tv_pk_fma_f32 v[34:35], v[34:35], v[52:53], v[42:43] op_sel:[1,0,0]",                    # the same product, selector on src0
@@ -26,7 +27,7 @@ def test_rule_flags_exactly_the_measured_form():
     text = "0000000000001b00 <kernel_a>:\n" + "\n".join(BAD) + "\n0000000000002b00 <kernel_b>:\n" + "\n".join(GOOD)
     hits = isa_lint.lint_text(text)
     assert [k for k, _ in hits] == ["kernel_a"] * len(BAD)
-    assert [i.split()[0] for _, i in hits] == ["v_pk_fma_f32", "v_pk_mul_f32", "v_pk_add_f32"]
+    assert [i.split()[0] for _, i in hits] == ["v_pk_fma_f32", "v_pk_mul_f32", "v_pk_add_f32", "v_pk_fma_f32"]
 
 
 def test_built_library_is_clean():
