@@ -580,6 +580,11 @@ def main():
         "eval_b1_256": lambda: run_eval_case(mods, "eval_b1_256", dict(H=256, B=1, n_freqs=6, scale_input=0.05937489, scale_output=0.14),
                                              LOSS_DEFAULT, dict(SAMPLE_DEFAULT, n_rays=24), 5, cam_s, 58, 0.08, False),
         "trained_default": lambda: run_trained_case(mods, "trained_default"),
+        # hidden widths the tile kernels run zero-padded (NetLayout::H): 128 on the <256, 256> tile, 300 with 10 octaves on <512, 512>
+        "eval_h128": lambda: run_eval_case(mods, "eval_h128", dict(H=128, B=2, n_freqs=6, scale_input=0.05937489, scale_output=0.14),
+                                           LOSS_DEFAULT, dict(SAMPLE_DEFAULT, n_rays=24), 5, cam_s, 59, 0.08, False),
+        "eval_h300_f10": lambda: run_eval_case(mods, "eval_h300_f10", dict(H=300, B=2, n_freqs=10, scale_input=0.05937489, scale_output=0.14),
+                                               LOSS_DEFAULT, dict(SAMPLE_DEFAULT, n_rays=24), 5, cam_s, 60, 0.08, False),
     }
     if only == "round4":
         for fn in round4.values():

@@ -1143,7 +1143,8 @@ def test_sampler_ray_count_sweep(F, n):
 # (<256,512>): n_freqs 9 and 11, hidden_layers_block 3, scale_input 0.4 / 0.04, trunc_weight 30, trunc_distance 0.1,
 # dist_behind_surf 0.01, depth_range[0] 0.1 / 0.15.  embedding.py:36-72, fc_map.py:77-92, realsense_franka_offline.json:63-71)
 # round 4: "eval_b1_256" -- hidden_layers_block = 1, the paper's 4-hidden-layer network (fc_map.py:77-90) at width 256
-SHAPE_CASES = ["eval_wide_512", "eval_rs_realsense", "eval_rs_franka", "eval_rs_franka_offline", "eval_b1_256"]
+SHAPE_CASES = ["eval_wide_512", "eval_rs_realsense", "eval_rs_franka", "eval_rs_franka_offline", "eval_b1_256",
+               "eval_h128", "eval_h300_f10"]          # the last two: zero-padded widths (NetLayout::H) against the REFERENCE
 # summed weight gradients of the high-frequency nets: the loss is NOT smooth (L1 / eikonal signs, free-space branch,
 # loss.py:122-164, trainer.py:814-816) and with 9-11 PE octaves a random-init field oscillates so fast that the forward
 # rounding of a 16-bit-operand implementation flips some of those signs; measured bounds per fixture (rel to the norm)
@@ -1152,7 +1153,7 @@ SHAPE_CASES = ["eval_wide_512", "eval_rs_realsense", "eval_rs_franka", "eval_rs_
 # (scale_input 0.4: the fastest-oscillating field of the shipped configs) is the non-smooth-loss case -- the forward rounding flips
 # loss branches -- so its END-TO-END bar stays at 3e-2 while the backward arithmetic alone is held to SHAPE_DW_LIN_TOL like the rest
 SHAPE_DW_TOL = {"eval_wide_512": 4e-3, "eval_rs_realsense": 2e-3, "eval_rs_franka": 3e-2, "eval_rs_franka_offline": 8e-3,
-                "eval_b1_256": 2e-3}
+                "eval_b1_256": 2e-3, "eval_h128": 2e-3, "eval_h300_f10": 8e-3}      # (the last two measured 6.8e-4 / 3.2e-3)
 SHAPE_DW_LIN_TOL = 6e-3        # measured 0.6e-3 .. 3.0e-3 (eval_rs_franka: 2.7e-3)
 
 

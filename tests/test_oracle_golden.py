@@ -19,7 +19,9 @@ EVAL_CASES = ["eval_small_ray", "eval_small_pc_l2", "eval_small_nograd", "eval_f
               "eval_small_b3_f9", "eval_small_b3_f10", "eval_small_b3_f11", "eval_wide_512",
               "eval_rs_realsense", "eval_rs_franka", "eval_rs_franka_offline",
               # round 4: hidden_layers_block = 1 (the paper's 4-hidden-layer net, fc_map.py:77-90) at width 256
-              "eval_b1_256"]
+              "eval_b1_256",
+              # ... and two widths the tile kernels run zero-padded: 128 (on <256, 256>), 300 with 10 octaves (on <512, 512>)
+              "eval_h128", "eval_h300_f10"]
 
 
 def _sample(g):
