@@ -64,6 +64,35 @@ def lint_text(text):
     return out
 
 
+def kernel_resources(lib):
+    """{kernel name: dict(vgpr, sgpr, vgpr_spill, sgpr_spill, scratch)} from the code objects' metadata notes -- the facts the
+    kernels' design leans on (no scratch anywhere; the <256, 256> chain kernels within the 128-VGPR budget of two workgroups per CU),
+    checked by tests/test_isa_lint.py so that a compiler or source change cannot take them away silently."""
+    keys = {".vgpr_count": "vgpr", ".sgpr_count": "sgpr", ".vgpr_spill_count": "vgpr_spill", ".sgpr_spill_count": "sgpr_spill",
+            ".private_segment_fixed_size": "scratch"}
+    out = {}
+    with tempfile.TemporaryDirectory(prefix="isdf_lint_") as wd:
+        for o in code_objects(lib, wd):
+            txt = subprocess.check_output([os.path.join(LLVM_BIN, "llvm-readelf"), "--notes", o], stderr=subprocess.DEVNULL).decode("utf-8", "replace")
+            cur = None
+            for line in txt.split("\n"):
+                t = line.strip()
+                if t.startswith("- ."):              # first key of a new kernel record (or of an argument record: no .name follows)
+                    cur = {}
+                    t = t[2:]
+                if cur is None or ":" not in t:
+                    continue
+                k, v = t.split(":", 1)
+                if k == ".name" and "(" not in v and v.strip().startswith("_Z"):
+                    cur["name"] = v.strip()
+                elif k in keys:
+                    cur[keys[k]] = int(v)
+                if k == ".wavefront_size" and "name" in cur:      # last key of a kernel record
+                    out[cur.pop("name")] = cur
+                    cur = None
+    return out
+
+
 def lint_library(lib):
     with tempfile.TemporaryDirectory(prefix="isdf_lint_") as wd:
         objs = code_objects(lib, wd)

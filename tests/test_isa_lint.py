@@ -37,3 +37,18 @@ def test_built_library_is_clean():
     n, bad = isa_lint.lint_library(_ffi.LIB_PATH)
     assert n >= 5                     # one code object per .hip source
     assert not bad, bad[:4]
+
+
+def test_hot_kernels_keep_their_register_budgets():
+    """What the kernels' design leans on: no scratch and no spilled VGPRs in any kernel of the step, and the <256, 256>
+    chain kernels inside the 128-VGPR budget that lets two workgroups share a CU."""
+    if not os.path.exists(os.path.join(isa_lint.LLVM_BIN, "llvm-readelf")):
+        pytest.skip("no llvm-readelf on this host")
+    build.build(verbose=False)
+    res = isa_lint.kernel_resources(_ffi.LIB_PATH)
+    hot = {k: v for k, v in res.items() if any(t in k for t in ("chain_kernel", "dw_kernel", "step_tail_kernel", "sample_rays_kernel"))}
+    assert len(hot) >= 40, len(hot)
+    for k, v in hot.items():
+        assert v["scratch"] == 0 and v["vgpr_spill"] == 0, (k, v)
+    two_per_cu = [v["vgpr"] for k, v in hot.items() if "chain_kernelILi256ELi256ELi" in k and "ELi256ELi3E" not in k]    # (OPER 3: one per CU)
+    assert len(two_per_cu) >= 9 and max(two_per_cu) <= 128, two_per_cu
