@@ -11,13 +11,16 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libisdf_hip.so")
-SOURCES = ["chain.hip", "dw.hip", "sampler.hip", "optim.hip", "ingest.hip", "capi.hip"]
+SOURCES = ["chain.hip", "fwd_pair.hip", "dw.hip", "sampler.hip", "optim.hip", "ingest.hip", "capi.hip"]
 HEADERS = ["isdf_common.h", "chain_params.h", "chain_dev.h", "chain_debug.h", os.path.join("..", "..", "include", "isdf_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-command-line-argument",
          "-fno-gpu-rdc"] + os.environ.get("ISDF_EXTRA_HIPCC_FLAGS", "").split()
 
 
-PER_FILE = {}   # per-source extra flags (none in the shipped build)
+# per-source extra flags.  fwd_pair.hip: its stages are hand-interleaved streams of [MFMA, one epilogue element, ...] groups; the SLP
+# vectoriser pairs the elements of neighbouring groups into packed fp32 operations, which undoes the interleave (and packed fp32
+# VALU next to MFMAs measures slower than two scalar operations on this chip)
+PER_FILE = {"fwd_pair.hip": ["-fno-slp-vectorize"]}
 
 
 def _hipcc():
@@ -31,7 +34,7 @@ def needs_build():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
+    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__), os.path.join(HERE, "isa_lint.py")]
     return any(os.path.getmtime(d) > t for d in deps)
 
 
@@ -66,19 +69,26 @@ def build(force=False, verbose=True):
     subprocess.check_call(cmd)
     # instruction forms measured to misbehave on MI355X (isa_lint.py): a library that contains one is not installed
     from . import isa_lint
+    lint_ran = True
     try:
         n_obj, bad = isa_lint.lint_library(staged)
-    except (OSError, subprocess.CalledProcessError) as e:      # no llvm-objdump on this host: the check cannot run (tests/test_isa_lint.py
-        n_obj, bad = 0, []                                     # then skips too); never a reason to ship nothing
-        sys.stderr.write("isa_lint could not run (%s)\n" % e)
-    if bad and not os.environ.get("ISDF_SKIP_ISA_LINT"):
+    except (OSError, subprocess.CalledProcessError, RuntimeError) as e:   # no llvm-objdump on this host, or nothing extracted: the check
+        n_obj, bad, lint_ran = 0, [], False                               # cannot run (tests/test_isa_lint.py then skips too); never a
+        sys.stderr.write("isa_lint could not run (%s)\n" % e)             # reason to ship nothing
+    skip = bool(os.environ.get("ISDF_SKIP_ISA_LINT"))
+    if bad and not skip:
         os.remove(staged)
         raise RuntimeError("isa_lint: %d instruction(s) of a form measured to misbehave on MI355X, e.g.\n  %s\n      %s\n"
                            "(see isdf_amd/isa_lint.py; rewrite the source so the compiler does not pick that form)"
                            % (len(bad), bad[0][0], bad[0][1]))
     os.replace(staged, LIB)
     if verbose:
-        print("isa_lint: %d code objects, clean" % n_obj)
+        if not lint_ran:
+            print("isa_lint: NOT RUN (see stderr)")
+        elif bad:
+            print("isa_lint: %d code objects, %d flagged instruction(s) -- overridden by ISDF_SKIP_ISA_LINT" % (n_obj, len(bad)))
+        else:
+            print("isa_lint: %d code objects, clean" % n_obj)
     return LIB
 
 

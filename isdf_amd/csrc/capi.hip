@@ -114,6 +114,8 @@ int isdf_sample_rays(const isdf_sample_args* a, const isdf_sample_out* o, void* 
       !o->pc)
     return ISDF_EINVAL;
   if (a->n_inline != 0 && (a->n_inline != a->n_frames || a->n_inline > ISDF_MAX_INLINE_FRAMES)) return ISDF_EINVAL;
+  for (int f = 0; f < a->n_inline; ++f)   // inline window indices are host values: reject what would gather in front of the keyframe buffers
+    if (a->frame_idx_inline[f] < 0 || (a->normal_batch && a->normal_idx_inline[f] < 0)) return ISDF_EINVAL;
   if (a->n_inline == 0 && (!a->frame_idx || (a->normal_batch && !a->normal_idx))) return ISDF_EINVAL;
   if (a->n_frames < 1 || a->n_rays < 1 || a->H < 1 || a->W < 1 || a->n_strat < 1 || a->n_surf < 0) return ISDF_EINVAL;
   if ((int64_t)a->n_frames * a->n_rays > 0x7fffffff / 64) return ISDF_EINVAL;
@@ -140,6 +142,8 @@ int isdf_sdf_eval(const isdf_net_cfg* net, const float* params, const void* shad
     if (!workspace || workspace_bytes < w.totalBytes) return ISDF_EWORKSPACE;
     p.spill = (uint16_t*)((char*)workspace + w.offSpill); p.sp = w.sp;
   }
+  // (development build only: phase stamps go to the last 4 KB of a caller-provided workspace; no-op in the shipped build)
+  chain_debug_from_env(p.dbg, workspace && workspace_bytes >= 4096 ? (char*)workspace + workspace_bytes - 4096 : nullptr);
   return launch_chain(p, mode, w.nTiles, (hipStream_t)stream);
 }
 
@@ -237,10 +241,12 @@ int isdf_train_step(const isdf_net_cfg* net, const isdf_loss_cfg* loss, const fl
 int isdf_train_step_adamw(const isdf_net_cfg* net, const isdf_loss_cfg* loss, const isdf_step_args* a,
                           const isdf_step_out* o, const isdf_optim_args* opt, void* workspace,
                           int64_t workspace_bytes, void* stream) {
-  if (!opt || !opt->params || !opt->exp_avg || !opt->exp_avg_sq || !opt->shadow || opt->step < 1) return ISDF_EINVAL;
+  if (!a || !opt || !opt->params || !opt->exp_avg || !opt->exp_avg_sq || !opt->shadow || opt->step < 1) return ISDF_EINVAL;
   if ((opt->loss_approx == nullptr) != (opt->frame_avg == nullptr)) return ISDF_EINVAL;   // both or neither
   if (opt->frame_avg_inline_n != 0 && (opt->frame_avg_inline_n != a->n_frames || opt->frame_avg_inline_n > ISDF_MAX_INLINE_FRAMES))
     return ISDF_EINVAL;
+  for (int f = 0; f < opt->frame_avg_inline_n; ++f)   // inline indices are host values: a negative one would write in front of frame_avg
+    if (opt->frame_avg_index_inline[f] < 0) return ISDF_EINVAL;
   if (o && o->split_event) return ISDF_EINVAL;   // the fused form has no message to split
   return train_step_impl(net, loss, opt->params, opt->shadow, a, o, workspace, workspace_bytes, stream, opt);
 }
@@ -256,6 +262,8 @@ int isdf_train_step_finish(const isdf_net_cfg* net, const isdf_optim_args* opt, 
   if (opt->loss_approx && n_frames < 1) return ISDF_EINVAL;
   if (opt->frame_avg_inline_n != 0 && (opt->frame_avg_inline_n != n_frames || opt->frame_avg_inline_n > ISDF_MAX_INLINE_FRAMES))
     return ISDF_EINVAL;
+  for (int f = 0; f < opt->frame_avg_inline_n; ++f)
+    if (opt->frame_avg_index_inline[f] < 0) return ISDF_EINVAL;
   if (extra_floats < 0 || extra_floats > 1016 || n_frames < 0) return ISDF_EINVAL;
   if (extra_floats > 0 && !host_mailbox) return ISDF_EINVAL;   // the reduced tail has nowhere to go: say so instead of dropping it
   const float* lossSums = reduce_buf + l.n_params;

@@ -208,9 +208,10 @@ __global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 && EP == HD && !oper_x2_a
   TS();
   // Issue priority between the two workgroups of a CU: with equal priority the OLDER workgroup's waves win
   // VALU/MFMA arbitration all the way, finish ~33 us early and leave the younger one to run the rest alone at the poor
-  // single-workgroup rate.  The second workgroup of a CU (dispatch round `gen` odd; the grid is <= 512 at the reference
-  // batch) therefore raises its priority for the two middle sweeps and the pair finishes together.
-  const bool genOdd = (blockIdx.x >> 8) & 1;
+  // single-workgroup rate.  The second workgroup of a CU (dispatch round blockIdx / #CUs odd -- the CU count of the device the
+  // launch goes to, not a constant: a partitioned (CPX) device has 32) therefore raises its priority for the two middle sweeps and
+  // the pair finishes together.  Speed only: nothing depends on the dispatch order actually being round-robin.
+  const bool genOdd = ((int)blockIdx.x / p.n_cu) & 1;
   auto PRIO = [&](int phase) {   // phase 0 fwd, 1 first reverse, 2 adjoint, 3 reverse
     if (genOdd) { if (phase == 1 || phase == 2) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
   };
@@ -993,11 +994,30 @@ static int launch_mode(const ChainParams& p, int64_t nTiles, hipStream_t st) {
   return launch_oper<512, 512, MODE>(p, nTiles, st);                         // BASELINE configs[4]
 }
 
-int launch_chain(const ChainParams& p, int mode, int64_t nTiles, hipStream_t st) {
-  if (!layout_supported(p.lay)) return ISDF_EUNSUPPORTED;
+bool fwd_pair_supported(const NetLayout& l);                                        // fwd_pair.hip
+int launch_fwd_pair(const ChainParams& p, int64_t nTiles, hipStream_t st);
+
+// compute units of the current device (cached per device ordinal; 256 on an unpartitioned MI355X)
+static int device_cu_count() {
+  static int cached[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  if (!cached[dev]) {
+    int n = 0;
+    cached[dev] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+  }
+  return cached[dev];
+}
+
+int launch_chain(const ChainParams& p0, int mode, int64_t nTiles, hipStream_t st) {
+  if (!layout_supported(p0.lay)) return ISDF_EUNSUPPORTED;
   if (nTiles <= 0) return ISDF_OK;
+  ChainParams p = p0;
+  p.n_cu = device_cu_count();
   switch (mode) {
-    case 0: return launch_mode<0>(p, nTiles, st);
+    case 0:   // forward only: the pair-tile kernel where it exists (<256, 256>), the one-tile kernel elsewhere
+      if (fwd_pair_supported(p.lay)) return launch_fwd_pair(p, nTiles, st);
+      return launch_mode<0>(p, nTiles, st);
     case 1: return launch_mode<1>(p, nTiles, st);
     case 2: return launch_mode<2>(p, nTiles, st);
   }

@@ -26,6 +26,7 @@ struct ChainParams {
   float* vec_part;            // [nTiles][vecStride] bias / out-layer gradient partials (no atomics)
   int32_t vecStride;
   uint16_t* spill; SpillLayout sp;
+  int32_t n_cu;               // compute units of the device the launch goes to (set by launch_chain): dispatch round of a workgroup = blockIdx / n_cu
   ChainDebug dbg;             // empty in the shipped build (chain_debug.h)
 };
 

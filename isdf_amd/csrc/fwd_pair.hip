@@ -1,0 +1,344 @@
+// Pair-tile forward kernel (K2, MODE 0, <HD = 256, EP = 256>): positional encoding -> SDF MLP forward for TWO 64-point
+// tiles ("halves") per workgroup, ONE workgroup per CU, software-pipelined so that inside every wave the MFMAs of one half's
+// GEMM issue between the Softplus / pack / LDS-write instructions of the other half's epilogue.  Replaces, for 128 points,
+//   embedding.PostionalEncoding.forward   isdf/modules/embedding.py:95-111
+//   SDFMap.forward                        isdf/modules/fc_map.py:94-111
+// (the same arithmetic, operand types and accumulation order as chain_kernel<256, 256, OPER, 0>: results are bit-identical).
+//
+// Why: chain.hip gets its MFMA / VALU overlap only from the hardware scheduler picking between two independent
+// workgroups per CU; all eight waves of a workgroup are in a GEMM or in an epilogue at the same time, every GEMM starts with an
+// exposed L2 round trip for its weight fragments and every tile streams its own copy of every matrix through the CU's 64 B/clk
+// vector-memory path (as busy as the matrix pipe would be at 100 %).  Here, per wave (256 VGPRs):
+//
+//      stage 2l+1 :  GEMM of half A, layer l      interleaved with   epilogue of half B, layer l-1        (barrier)
+//      stage 2l+2 :  GEMM of half B, layer l      interleaved with   epilogue of half A, layer l          (barrier)
+//
+//   * "interleaved" is by construction, not by the scheduler's choice: the stage is one unrolled instruction stream of
+//     [LDS operand read, MFMA, one epilogue element, MFMA, one epilogue element, weight request] groups separated by
+//     sched_barriers, so VALU and matrix pipe are busy in the same cycles of the same wave;
+//   * the weight fragments of a layer sit in a 16-fragment window (64 VGPRs) and serve BOTH halves: half B re-requests every
+//     register with the next layer's fragment right after its last use, a full stage before half A needs it -- no GEMM waits for
+//     L2, and a K = 256 layer is fetched once per 128 points (K = 512 and the compensated layers stream through the window once
+//     per half);
+//   * one barrier per GEMM (the stage's GEMM reads one half of the tile, its epilogue writes the other).
+#include "chain_dev.h"
+
+namespace isdf {
+
+struct FwdPairTile {
+  static constexpr int HD = 256, HB = TILE_PTS, BM = 2 * TILE_PTS, NW = 8;
+  static constexpr int ROWB = 4 * HD;                  // bytes per LDS row: [a | emb] 16-bit elements (emb -> a_lo past the cat layer, fp16x2)
+  static constexpr int HALFB = HB * ROWB;              // one half of the tile (64 KB)
+  static constexpr int OFF_RAW = 2 * HALFB;            // float [NW][BM]: per-wave partial of the output layer
+  static constexpr int OFF_BIAS = OFF_RAW + NW * BM * 4;   // float [MAXL][HD] hidden biases, then [HD] w_out (zero beyond unit H)
+  static constexpr int LDS_BYTES = OFF_BIAS + (MAXL + 1) * HD * 4;
+};
+static_assert(FwdPairTile::LDS_BYTES <= 160 * 1024, "one workgroup per CU");
+static_assert(TILE_PTS == 64, "a half is one 64-point tile");
+
+// unit kinds: the fragment stream a layer's GEMM consumes per half (16 fragments = K 256 of one packed matrix slice)
+enum { UK_NONE = 0, UK_16 = 1, UK_32 = 2, UK_16T = 3, UK_32L = 4 };
+//   UK_16   one matrix, K = 256                                   (input layer, hidden layers)
+//   UK_32   one matrix, K = 512                                   (cat layer)
+//   UK_16T  W (a + a_lo) in one pass over W, then W_lo a          (fp16x2: hidden layers past the cat layer)
+//   UK_32L  W [a | emb], then W_lo[:, HD:] emb                    (fp16x2: cat layer)
+enum { EK_NONE = 0, EK_HID = 1, EK_HILO = 2, EK_LAST = 3 };
+constexpr int uk_frags(int uk) { return uk == UK_16 ? 16 : uk == UK_32 ? 32 : uk == UK_16T ? 32 : uk == UK_32L ? 48 : 0; }
+
+template <typename F, int... I>
+__device__ __forceinline__ void static_layers(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+
+struct FwdUnit { int kind, soff0, soff1, col0; };   // byte offsets of the wave's slice of the unit's matrices; LDS column (bytes) of its first operand
+
+// NL / CAT: the number of hidden layers and the index of the cat layer as COMPILE-TIME constants: the layer loop unrolls into one
+// straight-line stream of stages (no stage dispatch at run time, no 128-register PHIs at loop joins -- with a run-time loop the
+// register allocator spilled a dozen window fragments right behind their loads).
+template <int OPER, int NL, int CAT>
+__global__ __launch_bounds__(FwdPairTile::NW * 64, 2) void fwd_pair_kernel(const ChainParams p) {
+  typedef FwdPairTile T;
+  constexpr bool F16 = OPER >= 1, X2 = OPER >= 2;
+  constexpr int HD = T::HD, EP = T::HD, HB = T::HB, BM = T::BM, ROWB = T::ROWB;
+  typedef typename Op<F16>::v8 v8;
+  typedef typename Op<F16>::e opT;
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  float* rawL = (float*)(smem + T::OFF_RAW);
+  float* biasL = (float*)(smem + T::OFF_BIAS);
+
+  const NetLayout& L = p.lay;
+  const int tid = threadIdx.x;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63, j = lane & 31, hi = lane >> 5, lane16 = lane * 16;
+  const int64_t P = p.n_valid ? (int64_t)(*p.n_valid) * p.S : p.n_points_host;
+  const int64_t n0 = (int64_t)blockIdx.x * BM;
+  if (n0 >= P) return;
+  const int nf = L.n_freqs;
+  const float so = L.scale_output;
+  ChainStamps TS(p.dbg);
+  TS();
+  TS.wall(0);
+
+  const rsrc_t rsW = make_rsrc(p.shadow, 0x7fffffffu);
+  auto unit_of = [&](int li) __attribute__((always_inline)) {
+    FwdUnit u;
+    const int kp = li == 0 ? EP : (li == CAT ? HD + EP : HD);
+    u.soff0 = (int)((L.setFwdA + L.fwdMat[li]) * 2) + w * (kp / 16) * 1024;
+    u.soff1 = (int)((L.setFwdLo + L.fwdMat[li]) * 2) + w * (kp / 16) * 1024 + (li == CAT ? (HD / 16) * 1024 : 0);
+    u.col0 = li == 0 ? HD * 2 : 0;
+    const bool comp = X2 && li >= CAT;
+    u.kind = li == CAT ? (comp ? UK_32L : UK_32) : (comp ? UK_16T : UK_16);
+    return u;
+  };
+  // fragment t of a unit's stream: one 1 KB wave-load (the wave's 32 rows x 16 k)
+  auto frag = [&](int soff, int ks) __attribute__((always_inline)) { return bload16<0>(rsW, lane16 + (ks & 3) * 1024, soff + (ks >> 2) * 4096); };
+  uint4 W[16];
+  {
+    const FwdUnit u0 = unit_of(0);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) W[r] = frag(u0.soff0, r);
+  }
+
+  // ------------------------------------------------------------------ biases / w_out -> LDS (zero beyond unit H), PE of both halves
+  for (int q = tid; q < (NL + 1) * HD; q += T::NW * 64) {
+    const int li = q / HD, u = q % HD;
+    float v = 0.f;
+    if (u < L.H) v = p.params[(li < NL ? L.offB[li] : L.offWout) + u];
+    biasL[(li < NL ? li : MAXL) * HD + u] = v;
+  }
+#pragma unroll 1
+  for (int h = 0; h < 2; ++h) {
+    // a wave = (HB / NW points) x (direction slices): rows are 1 KB apart, i.e. 8 banks (chain.hip's PE stage, per half)
+    const int pt = (tid % (HB / T::NW)) + (HB / T::NW) * (tid / 64), prt = (tid % 64) / (HB / T::NW);
+    constexpr int NPART = (T::NW * 64) / HB;
+    const int64_t n = n0 + h * HB + pt;
+    float x0 = 0.f, x1 = 0.f, x2 = 0.f;
+    if (n < P) { x0 = p.pts[n * 3]; x1 = p.pts[n * 3 + 1]; x2 = p.pts[n * 3 + 2]; }
+    // transform_3D_grid (transform.py:287-304) then * scale (embedding.py:12-22)
+    const float y0 = (L.T[0] * x0 + L.T[1] * x1 + L.T[2] * x2 + L.T[3]) * L.scale_input;
+    const float y1 = (L.T[4] * x0 + L.T[5] * x1 + L.T[6] * x2 + L.T[7]) * L.scale_input;
+    const float y2 = (L.T[8] * x0 + L.T[9] * x1 + L.T[10] * x2 + L.T[11]) * L.scale_input;
+    char* row = smem + h * T::HALFB + pt * ROWB;
+    auto put = [&](int feat, float v) __attribute__((always_inline)) { *(opT*)(row + swz(pt, (HD + feat) * 2)) = (opT)v; };
+    if (prt == 0) {
+      put(0, y0); put(1, y1); put(2, y2);
+      for (int f = L.E; f < EP; ++f) put(f, 0.f);
+    }
+    for (int d = prt; d < N_DIRS; d += NPART) {
+      const float proj = y0 * kDirs[0][d] + y1 * kDirs[1][d] + y2 * kDirs[2][d];
+      float fr = 1.f;
+      for (int f = 0; f < nf; ++f) {
+        const float xb = proj * fr;
+        put(3 + d * nf + f, __sinf(xb));
+        put(3 + N_DIRS * nf + d * nf + f, __sinf(xb + kHalfPi));
+        fr *= 2.f;
+      }
+    }
+  }
+  TS();
+  lds_barrier();
+  TS();
+
+  // ------------------------------------------------------------------ the stage
+  // LDS byte offsets (within a half) of this lane's operand reads and epilogue writes (chain.hip: gemm() / put_x())
+  const int xlane = j * ROWB + ((hi * 16) ^ ((j & 15) << 4));
+  const int xw = j * ROWB + 8 * hi + (((j & 15) << 4) ^ ((w & 3) * 64)) + (w >> 2) * 256;
+  f32x16 accA[2], accB[2];
+  float rawp[2];
+
+  // GEMM of half `xg` (unit `u`, kind UK) into accG, interleaved with the epilogue EK of accE into half `xe`.
+  // IS_B: the second half to use the unit: every window register is re-requested with the NEXT unit's fragment after its last use.
+  auto stage = [&](auto ukc, auto ekc, auto isb, f32x16 (&accG)[2], f32x16 (&accE)[2], const FwdUnit u, const int nxtSoff0,
+                   const char* xg, char* xe, const int eli, const int eh) __attribute__((always_inline)) {
+    constexpr int UK = decltype(ukc)::value, EK = decltype(ekc)::value;
+    constexpr bool IS_B = decltype(isb)::value;
+    constexpr int NT = UK == UK_NONE ? 16 : uk_frags(UK);   // steps of the stage (an epilogue-only stage runs its 16 pieces)
+    constexpr bool TWO = UK == UK_16T;
+    // per-stage lane bases, opaque to the optimiser: otherwise every (k-step, half) address is hoisted out of the layer loop as a
+    // lane constant (two dozen VGPRs at a budget that has none to spare) instead of one v_xor next to its ds_read
+    int xgl = xlane + (int)(xg - smem), xel = xw + (int)(xe - smem);
+    asm volatile("" : "+v"(xgl), "+v"(xel));
+    // epilogue state: the 8 biases (and, last layer, out-layer weights) of the running qp block -- features 32 w + 16 qp + 4 hi + {0..3, 8..11}
+    float bv[8], wv[8], av[8];
+    f32x2 r2 = {0.f, 0.f};
+    auto load_bv = [&](int qp) __attribute__((always_inline)) {
+      if constexpr (EK != EK_NONE) {
+        const float* bsrc = biasL + eli * HD + w * 32 + 16 * qp + 4 * hi;
+        const float4 b0 = *(const float4*)bsrc, b1 = *(const float4*)(bsrc + 8);
+        bv[0] = b0.x; bv[1] = b0.y; bv[2] = b0.z; bv[3] = b0.w; bv[4] = b1.x; bv[5] = b1.y; bv[6] = b1.z; bv[7] = b1.w;
+        if constexpr (EK == EK_LAST) {
+          const float* wsrc = biasL + MAXL * HD + w * 32 + 16 * qp + 4 * hi;
+          const float4 w0 = *(const float4*)wsrc, w1 = *(const float4*)(wsrc + 8);
+          wv[0] = w0.x; wv[1] = w0.y; wv[2] = w0.z; wv[3] = w0.w; wv[4] = w1.x; wv[5] = w1.y; wv[6] = w1.z; wv[7] = w1.w;
+        }
+      }
+    };
+    load_bv(0);
+    if constexpr (EK == EK_LAST) { rawp[0] = 0.f; rawp[1] = 0.f; }
+    (void)wv; (void)r2; (void)av; (void)bv;
+    // one epilogue element: piece pc in 0..31 -> block (qp, pb) = (pc >> 4, (pc >> 3) & 1), element e = pc & 7
+    auto epi = [&](int pc) __attribute__((always_inline)) {
+      if constexpr (EK != EK_NONE) {
+        const int qp = pc >> 4, pb = (pc >> 3) & 1, e = pc & 7;
+        av[e] = softplus_f(accE[pb][8 * qp + e] + bv[e]);
+        if constexpr (EK == EK_LAST) {
+          // w_out . a as packed FMAs of ELEMENT PAIRS (never a broadcast operand: isa_lint rule 1), same grouping as chain.hip
+          if (e & 1) {
+            r2 += f32x2{wv[e - 1], wv[e]} * f32x2{av[e - 1], av[e]};
+            if (e == 7) { rawp[pb] += r2[0] + r2[1]; r2 = f32x2{0.f, 0.f}; }
+          }
+        } else if (e == 3 || e == 7) {   // four values -> one 8-byte piece of the tile (features f0 .. f0+3 | f0+8 .. f0+11)
+          const int lb = ((xel ^ (32 * qp)) + pb * 32 * ROWB) ^ (e == 7 ? 16 : 0);
+          if constexpr (EK == EK_HILO) {   // region 1 <- fp16(a), region 2 <- fp16(a - fp16(a))
+            *(uint2*)(smem + lb) = pack4<true>(av[e - 3], av[e - 2], av[e - 1], av[e]);
+            *(uint2*)(smem + lb + HD * 2) = pack4<true>(f16_residual(av[e - 3]), f16_residual(av[e - 2]), f16_residual(av[e - 1]), f16_residual(av[e]));
+          } else {
+            *(uint2*)(smem + lb) = pack4<F16>(av[e - 3], av[e - 2], av[e - 1], av[e]);
+          }
+        }
+        if (pc == 15) load_bv(1);   // the second block's parameters, behind the first block's last use
+      }
+    };
+    // operand reads of step t: segment / k-step / LDS column.  The first operand is read one step ahead (double-buffered); the second
+    // operand of a two-operand step (a_lo) at the start of its own step, two MFMAs ahead of its use.
+    v8 bq[2][2], bl[2];
+    auto opaddr = [&](int t) __attribute__((always_inline)) {
+      int ks, col;
+      if (UK == UK_16 || UK == UK_32) { ks = t; col = u.col0; }
+      else if (UK == UK_16T) { ks = t & 15; col = 0; }
+      else { ks = t < 32 ? t : t - 32; col = t < 32 ? 0 : HD * 2; }
+      return (xgl ^ ((ks & 7) * 32)) + (ks >> 3) * 256 + col;
+    };
+    auto readb = [&](int t, v8 (&b)[2]) __attribute__((always_inline)) {
+      if constexpr (UK != UK_NONE) {
+        const int a = opaddr(t);
+#pragma unroll
+        for (int pb = 0; pb < 2; ++pb) b[pb] = __builtin_bit_cast(v8, *(const uint4*)(smem + a + pb * 32 * ROWB));
+      }
+    };
+    auto readlo = [&](int t) __attribute__((always_inline)) {
+      if constexpr (TWO) {
+        const int a = opaddr(t) + HD * 2;
+#pragma unroll
+        for (int pb = 0; pb < 2; ++pb) bl[pb] = __builtin_bit_cast(v8, *(const uint4*)(smem + a + pb * 32 * ROWB));
+      }
+    };
+    (void)bl;
+    readb(0, bq[0]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int r = t & 15;
+      if constexpr (UK != UK_NONE) {
+        if (t + 1 < NT) readb(t + 1, bq[(t + 1) & 1]);
+        if (TWO && t < 16) readlo(t);
+        __builtin_amdgcn_sched_barrier(0);
+        accG[0] = Op<F16>::mfma(__builtin_bit_cast(v8, W[r]), bq[t & 1][0], t == 0 ? f32x16(0.f) : accG[0]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (t < 16) epi(2 * t);
+      if constexpr (UK != UK_NONE) {
+        __builtin_amdgcn_sched_barrier(0);
+        accG[1] = Op<F16>::mfma(__builtin_bit_cast(v8, W[r]), bq[t & 1][1], t == 0 ? f32x16(0.f) : accG[1]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (t < 16) epi(2 * t + 1);
+      if constexpr (UK != UK_NONE) {
+        if constexpr (TWO) {
+          if (t < 16) {
+            __builtin_amdgcn_sched_barrier(0);
+            accG[0] = Op<F16>::mfma(__builtin_bit_cast(v8, W[r]), bl[0], accG[0]);
+            accG[1] = Op<F16>::mfma(__builtin_bit_cast(v8, W[r]), bl[1], accG[1]);
+          }
+        }
+        // the window register's next tenant
+        constexpr int NF = uk_frags(UK);
+        if (t + 16 < NF) {   // this unit's fragment t + 16
+          const int tt = t + 16;
+          if (UK == UK_32) W[r] = frag(u.soff0, tt);
+          else if (UK == UK_16T) W[r] = frag(u.soff1, tt - 16);
+          else W[r] = tt < 32 ? frag(u.soff0, tt) : frag(u.soff1, tt - 32);
+        } else if (IS_B) {
+          W[r] = frag(nxtSoff0, r);              // the next unit's fragment r, a stage ahead of half A
+        } else if (NF > 16) {
+          W[r] = frag(u.soff0, r);               // half B starts the unit over
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if constexpr (EK == EK_LAST) {
+#pragma unroll
+      for (int pb = 0; pb < 2; ++pb) {
+        const float v = rawp[pb] + __shfl_xor(rawp[pb], 32, 64);   // add the two feature halves
+        if (hi == 0) rawL[w * BM + eh * HB + pb * 32 + j] = v;
+      }
+    }
+  };
+
+  // the stages, unrolled at compile time: unit kind and epilogue kind of every stage are constants
+  char* const XA = smem;
+  char* const XB = smem + T::HALFB;
+  auto soff0_of = [&](int li) __attribute__((always_inline)) { return (int)((L.setFwdA + L.fwdMat[li]) * 2) + w * ((li == 0 ? EP : (li == CAT ? HD + EP : HD)) / 16) * 1024; };
+  auto layer = [&](auto lic) __attribute__((always_inline)) {
+    constexpr int li = decltype(lic)::value;
+    constexpr bool comp = X2 && li >= CAT;
+    constexpr int UK = li == CAT ? (comp ? UK_32L : UK_32) : (comp ? UK_16T : UK_16);
+    constexpr int EKprev = li == 0 ? EK_NONE : (X2 && li > CAT ? EK_HILO : EK_HID);                   // epilogue of layer li - 1 (never the last)
+    constexpr int EKcur = li == NL - 1 ? EK_LAST : (X2 && li + 1 > CAT ? EK_HILO : EK_HID);
+    const FwdUnit u = unit_of(li);
+    const int nxt = soff0_of(li + 1 < NL ? li + 1 : 0);   // (past the last layer: a harmless re-request of layer 0)
+    // stage 2 li + 1: GEMM of half A, layer li || epilogue of half B, layer li - 1
+    stage(std::integral_constant<int, UK>{}, std::integral_constant<int, EKprev>{}, std::false_type{}, accA, accB, u, nxt, XA, XB, li - 1, 1);
+    TS();
+    lds_barrier();
+    TS();
+    // stage 2 li + 2: GEMM of half B, layer li || epilogue of half A, layer li
+    stage(std::integral_constant<int, UK>{}, std::integral_constant<int, EKcur>{}, std::true_type{}, accB, accA, u, nxt, XB, XA, li, 0);
+    TS();
+    lds_barrier();
+    TS();
+  };
+  static_layers(layer, std::make_integer_sequence<int, NL>{});
+  {   // epilogue of half B, last layer
+    const FwdUnit u = unit_of(0);
+    stage(std::integral_constant<int, UK_NONE>{}, std::integral_constant<int, EK_LAST>{}, std::false_type{}, accA, accB, u, u.soff0, XA, XB, NL - 1, 1);
+  }
+  lds_barrier();
+  TS();
+
+  // sdf = (raw + noise) * so   (fc_map.py:104-109)
+  if (tid < BM) {
+    float r = p.params[L.offBout];
+#pragma unroll
+    for (int k = 0; k < T::NW; ++k) r += rawL[k * BM + tid];
+    const int64_t n = n0 + tid;
+    if (p.noise) { if (n < P) r += p.noise[n]; }
+    else if (p.noise_std != 0.f) {   // Box-Muller on Philox4x32-10 keyed by (seed, offset, point) -- chain.hip's tail
+      const uint4 u = philox4x32_10(make_uint4((uint32_t)n, (uint32_t)(n >> 32), (uint32_t)p.noise_off, (uint32_t)(p.noise_off >> 32)),
+                                    make_uint2((uint32_t)p.noise_seed, (uint32_t)(p.noise_seed >> 32) ^ 0x5eedu));
+      const float u1 = fmaxf(u01(u.x), 1e-7f), u2 = u01(u.y);
+      r += p.noise_std * sqrtf(-2.f * __logf(u1)) * __cosf(6.2831853f * u2);
+    }
+    if (p.sdf && n < P) p.sdf[n] = r * so;
+  }
+  TS.wall(1);
+}
+
+template <int OPER>
+static int launch_fwd_pair_oper(const ChainParams& p, int64_t nPairs, hipStream_t st) {
+  auto k = fwd_pair_kernel<OPER, 6, 3>;
+  if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, FwdPairTile::LDS_BYTES) != hipSuccess) return ISDF_EHIP;
+  hipLaunchKernelGGL(k, dim3((unsigned)nPairs), dim3(FwdPairTile::NW * 64), FwdPairTile::LDS_BYTES, st, p);
+  return isdf_launch_status();
+}
+
+// MODE 0 of the <256, 256> tile with hidden_layers_block = 2 (every shipped config: 6 hidden layers, cat layer 3) for the bf16 /
+// fp16 / fp16x2 operand modes; other depths and fp16x2_full (four operand regions) stay on chain.hip's one-tile kernel
+bool fwd_pair_supported(const NetLayout& l) { return l.HD == 256 && l.EP == 256 && !l.fwd_x2_all && l.L == 6 && l.cat == 3; }
+
+int launch_fwd_pair(const ChainParams& p, int64_t nTiles, hipStream_t st) {
+  const int64_t nPairs = (nTiles + 1) / 2;
+  if (nPairs <= 0) return ISDF_OK;
+  if (p.lay.fwd_x2) return launch_fwd_pair_oper<2>(p, nPairs, st);
+  return p.lay.fwd_f16 ? launch_fwd_pair_oper<1>(p, nPairs, st) : launch_fwd_pair_oper<0>(p, nPairs, st);
+}
+
+}  // namespace isdf

@@ -546,10 +546,17 @@ class Engine:
         return self.reduce_buf[self.n_params:self.n_params + 8]
 
     def frame_avg(self, n_frames, out=None, index=None):
-        if isinstance(index, (tuple, list)):
-            index = torch.as_tensor([int(v) for v in index], dtype=torch.int32, device=self.device)
         """loss.frame_avg from the (reduced) bins.  out/index: write frame f's average to out[index[f]] (the
-        keyframe store's frame_avg_losses and the window's keyframe ids) instead of a fresh [F] tensor."""
+        keyframe store's frame_avg_losses and the window's keyframe ids) instead of a fresh [F] tensor.
+        A tuple / list index (the host-side window) is converted once per distinct window and cached."""
+        if isinstance(index, (tuple, list)):
+            key = tuple(int(v) for v in index)
+            cache = self.__dict__.setdefault("_fa_index_cache", {})
+            if key not in cache:
+                if len(cache) > 64:
+                    cache.clear()
+                cache[key] = torch.as_tensor(key, dtype=torch.int32, device=self.device)
+            index = cache[key]
         la = torch.empty(n_frames, 8, 8, dtype=torch.float32, device=self.device)
         if out is None:
             fa = torch.empty(n_frames, dtype=torch.float32, device=self.device)

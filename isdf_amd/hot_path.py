@@ -17,7 +17,7 @@ with the `torch.optim.AdamW` surface.  Everything else (`get_data`, `add_frame`,
 `check_keyframe_latest`, `select_keyframes`, evaluation, visualisation) keeps running as the
 reference's own code on the same object.
 
-Where the reference is not importable (the GPU box, bench.py), `tests/standin_trainer.py` (test / bench infrastructure, outside
+Where the reference is not importable (the GPU box, bench.py), `bench_support/standin_trainer.py` (test / bench infrastructure, outside
 this package) restates the driver-side methods; its `HipTrainer` is `graft()` applied to that stand-in -- the same code path.
 
 There is no CPU fallback: without the HIP library or a HIP device `graft` raises.

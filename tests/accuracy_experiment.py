@@ -104,7 +104,7 @@ DEVICE = "cpu"           # --device: where the port backend runs ("cuda" = PyTor
 
 
 def run_hip(seed, depth, normal, T, cam, steps_per_kf):
-    from tests.standin_trainer import HipTrainer, FrameData
+    from bench_support.standin_trainer import HipTrainer, FrameData
     np.random.seed(seed); torch.manual_seed(seed)
     tr = HipTrainer("cuda", config(cam), inv_bounds_transform=synthetic.bounds_transform(), rng="torch" if PAIRED else "philox",
                     seed=seed, fwd_operand=FWD_OPERAND, bwd_operand=BWD_OPERAND)
@@ -130,14 +130,14 @@ def run_hip(seed, depth, normal, T, cam, steps_per_kf):
 
 
 def run_hip_reference_schedule(seed, cam, n_steps=1200, virtual_step_ms=20.0, n_frames=600, quiet=True):
-    """The reference driver's frame scheduling (train.py:86-136, restated in tests/driver_loop.py) on the
+    """The reference driver's frame scheduling (train.py:86-136, restated in bench_support/driver_loop.py) on the
     synthetic 30 fps stream: after `optim_frames` steps on the latest frame, `check_keyframe_latest` (keyframe
     test on the frozen net, trainer.py:586-650) decides whether it becomes a keyframe; the next frame id is
     int(tot_step_time * fps) (trainer.py:100).  The virtual clock advances by `virtual_step_ms` per step
     (pinned) instead of the measured step time so the schedule is reproducible."""
     import contextlib, io
-    from tests.standin_trainer import HipTrainer
-    from tests.driver_loop import run_train_loop
+    from bench_support.standin_trainer import HipTrainer
+    from bench_support.driver_loop import run_train_loop
     np.random.seed(seed); torch.manual_seed(seed)
     tr = HipTrainer("cuda", config(cam), inv_bounds_transform=synthetic.bounds_transform(), rng="philox", seed=seed,
                     virtual_step_ms=virtual_step_ms)
@@ -164,7 +164,7 @@ def run_port_reference_schedule(seed, cam, n_steps=1200, virtual_step_ms=20.0, n
     import contextlib, io
     import oracle.isdf_oracle as orc
     from oracle.torch_port import PortTrainer
-    from tests.driver_loop import run_train_loop
+    from bench_support.driver_loop import run_train_loop
     if threads:
         torch.set_num_threads(threads)
     np.random.seed(seed); torch.manual_seed(seed)
@@ -330,11 +330,11 @@ def run_native_clock(backend, seed, stream, max_steps, extra_opt_steps=400, eval
     run ends `extra_opt_steps` after the stream does (train.py:30,114) or at `max_steps` (replicaCAD.json "steps": 20000).
     virtual_step_ms: pin the clock instead (the `--reference-schedule` mode: same loop, reproducible schedule)."""
     import contextlib, io
-    from tests.driver_loop import run_train_loop
+    from bench_support.driver_loop import run_train_loop
     cam = stream.cam
     np.random.seed(seed); torch.manual_seed(seed)
     if backend == "hip":
-        from tests.standin_trainer import HipTrainer
+        from bench_support.standin_trainer import HipTrainer
         tr = HipTrainer("cuda", config(cam), inv_bounds_transform=synthetic.bounds_transform(), rng="philox", seed=seed,
                         fwd_operand=FWD_OPERAND, bwd_operand=BWD_OPERAND, virtual_step_ms=virtual_step_ms)
         sdf_fn = lambda p: tr.sdf_map(p)

@@ -141,7 +141,7 @@ def _step_worker(rank, world, port, ret):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
     torch.set_num_threads(2)
-    from tests.standin_trainer import HipTrainer
+    from bench_support.standin_trainer import HipTrainer
     from isdf_amd import synthetic
     from tests.accuracy_experiment import config
     from tests.fake_engine import FakeEngine

@@ -96,7 +96,7 @@ def _run_engine(bounds, ranks, group, out, overlap=False):
 
 def _run_trainer(rank, group, out):
     import contextlib, io
-    from tests.standin_trainer import HipTrainer
+    from bench_support.standin_trainer import HipTrainer
     from isdf_amd import synthetic
     from tests.accuracy_experiment import config
     cfg = config(CAM)
@@ -143,7 +143,7 @@ def _run_trainer(rank, group, out):
 def _run_trainer_overlap(rank, group, out):
     """HipTrainer(overlap_allreduce=True): the same steps as a twin with the one-message all-reduce, collectives counted"""
     import contextlib, io
-    from tests.standin_trainer import HipTrainer
+    from bench_support.standin_trainer import HipTrainer
     from isdf_amd import synthetic
     from tests.accuracy_experiment import config
     cfg = config(CAM)

@@ -438,7 +438,7 @@ def test_in_kernel_noise_is_standard_normal_and_deterministic():
 def test_hip_trainer_step_contract():
     """Host mirror: HipTrainer.step returns (losses, step_time_ms) with the reference's keys/types
     and side effects (trainer.py:951-1016), K > window exercises select_keyframes."""
-    from tests.standin_trainer import HipTrainer, FrameData
+    from bench_support.standin_trainer import HipTrainer, FrameData
     from isdf_amd import synthetic
     import bench
     cam = dict(synthetic.SCANNET_CAM)
@@ -530,7 +530,7 @@ def test_checkpoint_resume_is_exact():
     """Full resume (model, AdamW moments + step, keyframes, RNG counters, virtual clock): a restored
     trainer continues bit-identically (the reference restores only the weights, trainer.py:441-444)."""
     import io
-    from tests.standin_trainer import HipTrainer, FrameData
+    from bench_support.standin_trainer import HipTrainer, FrameData
     from isdf_amd import synthetic
     import bench
     cam = dict(synthetic.SCANNET_CAM)
@@ -1057,7 +1057,7 @@ def test_public_seams_match_step_and_autograd_callers_work():
     PUBLIC methods -- sample_points -> sdf_eval_and_loss -> total_loss.backward() -> optimiser.step() (trainer.py:
     968-986) -- leaves the same network as step() does for the same draws; (ii) a caller-assembled sample dict (no
     private fields) is accepted; (iii) `fc_map.gradient`-style autograd through trainer.sdf_map returns d sdf / d x."""
-    from tests.standin_trainer import HipTrainer, FrameData
+    from bench_support.standin_trainer import HipTrainer, FrameData
     from isdf_amd import synthetic
     import bench
     cam = dict(synthetic.SCANNET_CAM)
@@ -1371,7 +1371,7 @@ def test_frame_losses_in_pinned_host_memory_equal_the_device_placement():
     """isdf_amd.frame_store keeps frames.frame_avg_losses in pinned host memory: the closing launch writes the window's averages
     there zero-copy and the reference's select_keyframes (trainer.py:652-674) runs on the host.  Same run with the losses on the
     device (the reference's FrameData placement): identical windows, bit-identical frame averages and parameters, step after step."""
-    from tests.standin_trainer import HipTrainer, FrameData
+    from bench_support.standin_trainer import HipTrainer, FrameData
     from isdf_amd import synthetic
     import bench
     cam = dict(synthetic.SCANNET_CAM)

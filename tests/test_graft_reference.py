@@ -21,7 +21,7 @@ import pytest
 import torch
 
 from tests import golden_util as gu
-from tests.driver_loop import run_train_loop
+from bench_support.driver_loop import run_train_loop
 from tests.fake_engine import FakeEngine
 
 REF = "/root/reference"
@@ -234,7 +234,7 @@ def test_reference_driver_loop_on_grafted_reference_trainer(ref_mods):
 
 def test_reference_driver_loop_on_hiptrainer_standin():
     """the same loop against HipTrainer (= graft applied to the in-repo stand-in; the object the GPU box runs)"""
-    from tests.standin_trainer import HipTrainer
+    from bench_support.standin_trainer import HipTrainer
     from tests.accuracy_experiment import config
     cam = dict(H=48, W=64, fx=60.0, fy=60.0, cx=31.5, cy=23.5)
     cfg = config(cam)
@@ -272,7 +272,7 @@ def test_reference_driver_loop_on_hiptrainer_standin():
 
 def test_graft_refuses_cpu_device_and_unsupported_configs():
     from isdf_amd import _ffi
-    from tests.standin_trainer import HipTrainer
+    from bench_support.standin_trainer import HipTrainer
     from tests.accuracy_experiment import config
     cam = dict(H=48, W=64, fx=60.0, fy=60.0, cx=31.5, cy=23.5)
     with pytest.raises(_ffi.IsdfError):
@@ -286,7 +286,7 @@ def test_graft_refuses_cpu_device_and_unsupported_configs():
 
 
 def test_optimiser_facade_resets_moments_for_an_empty_checkpoint():
-    from tests.standin_trainer import HipTrainer
+    from bench_support.standin_trainer import HipTrainer
     from tests.accuracy_experiment import config
     cam = dict(H=48, W=64, fx=60.0, fy=60.0, cx=31.5, cy=23.5)
     cfg = config(cam); cfg["model"].update(hidden_feature_size=64, hidden_layers_block=1)

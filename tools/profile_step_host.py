@@ -3,7 +3,7 @@ import os, sys, cProfile, pstats, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import bench
-from tests.standin_trainer import HipTrainer, FrameData
+from bench_support.standin_trainer import HipTrainer, FrameData
 from isdf_amd import synthetic
 cfg = bench.reference_config()
 cam = dict(synthetic.REPLICA_CAM)
