@@ -20,7 +20,9 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-com
 # per-source extra flags.  fwd_pair.hip: its stages are hand-interleaved streams of [MFMA, one epilogue element, ...] groups; the SLP
 # vectoriser pairs the elements of neighbouring groups into packed fp32 operations, which undoes the interleave (and packed fp32
 # VALU next to MFMAs measures slower than two scalar operations on this chip)
-PER_FILE = {"fwd_pair.hip": ["-fno-slp-vectorize"]}
+# The stages are fully unrolled streams of up to 48 k-steps, each with its share of the epilogue: beyond the default size limit of
+# `#pragma unroll` (a rolled stage would index the weight window dynamically, i.e. put it in scratch memory).
+PER_FILE = {"fwd_pair.hip": ["-fno-slp-vectorize", "-mllvm", "-pragma-unroll-threshold=1000000"]}
 
 
 def _hipcc():

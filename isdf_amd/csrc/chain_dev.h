@@ -117,6 +117,18 @@ __device__ __forceinline__ float softplus_s1(float z, float& s1) {   // also sig
   s1 = t * __builtin_amdgcn_rcpf(u);
   return fmaxf(z, kC2 * __builtin_amdgcn_logf(u));
 }
+// The pair-tile forward kernel (fwd_pair.hip) works on the base-2 image of the pre-activation, x = beta log2(e) (acc + b) =
+// fma(kC1, acc, kC1 b) with the bias pre-scaled when it is staged in LDS, and scales back after the max: a = kC2 max(x, log2(1 + 2^x))
+// -- five plain VALU operations and two transcendental ones per element instead of six and two; the same function to fp32 rounding
+// (its outputs sit <= 3e-5 of the output scale from the one-tile kernel's: profiles/r05_fwd_pair_v3_ab.txt).  Why an operation
+// matters: on this chip every VALU wave-instruction next to MFMAs costs ~4 issue cycles of its SIMD, a transcendental 8, an MFMA 8
+// of its 32 (tools/probes/valu_rate.hip, profiles/r05_probe_valu_rate.txt), and a K = 256 layer's Softplus epilogue then needs MORE
+// issue cycles than its 64 MFMAs take to execute: the instruction count of the epilogues, not the matrix pipe, bounds these kernels.
+__device__ __forceinline__ float softplus_x(float acc, float bs) {   // bs = kC1 * bias
+  const float x = __builtin_fmaf(kC1, acc, bs);
+  const float t = __builtin_amdgcn_exp2f(fminf(x, 30.f));
+  return kC2 * fmaxf(x, __builtin_amdgcn_logf(1.f + t));
+}
 // sigma'(z) recovered from the stored activation: 1 - exp(-beta a)
 __device__ __forceinline__ float s1_from_a(float a) {
   return 1.f - __builtin_amdgcn_exp2f(-kC1 * a);

@@ -3,7 +3,9 @@
 // GEMM issue between the Softplus / pack / LDS-write instructions of the other half's epilogue.  Replaces, for 128 points,
 //   embedding.PostionalEncoding.forward   isdf/modules/embedding.py:95-111
 //   SDFMap.forward                        isdf/modules/fc_map.py:94-111
-// (the same arithmetic, operand types and accumulation order as chain_kernel<256, 256, OPER, 0>: results are bit-identical).
+// (the same operand types and accumulation order as chain_kernel<256, 256, OPER, 0>; Softplus as chain_dev.h's softplus_x(): the first
+// two versions of this kernel, with softplus_f(), were bit-identical to the one-tile kernel on every ragged size and operand mode --
+// profiles/r05_fwd_pair_v1_ab.txt -- this one sits <= 3e-5 of the output scale from it, fp32 rounding of the reformulated epilogue).
 //
 // Why: chain.hip gets its MFMA / VALU overlap only from the hardware scheduler picking between two independent
 // workgroups per CU; all eight waves of a workgroup are in a GEMM or in an epilogue at the same time, every GEMM starts with an
@@ -53,7 +55,7 @@ struct FwdUnit { int kind, soff0, soff1, col0; };   // byte offsets of the wave'
 // NL / CAT: the number of hidden layers and the index of the cat layer as COMPILE-TIME constants: the layer loop unrolls into one
 // straight-line stream of stages (no stage dispatch at run time, no 128-register PHIs at loop joins -- with a run-time loop the
 // register allocator spilled a dozen window fragments right behind their loads).
-template <int OPER, int NL, int CAT>
+template <int OPER, int NL, int CAT, int NF>
 __global__ __launch_bounds__(FwdPairTile::NW * 64, 2) void fwd_pair_kernel(const ChainParams p) {
   typedef FwdPairTile T;
   constexpr bool F16 = OPER >= 1, X2 = OPER >= 2;
@@ -71,7 +73,6 @@ __global__ __launch_bounds__(FwdPairTile::NW * 64, 2) void fwd_pair_kernel(const
   const int64_t P = p.n_valid ? (int64_t)(*p.n_valid) * p.S : p.n_points_host;
   const int64_t n0 = (int64_t)blockIdx.x * BM;
   if (n0 >= P) return;
-  const int nf = L.n_freqs;
   const float so = L.scale_output;
   ChainStamps TS(p.dbg);
   TS();
@@ -98,39 +99,78 @@ __global__ __launch_bounds__(FwdPairTile::NW * 64, 2) void fwd_pair_kernel(const
   }
 
   // ------------------------------------------------------------------ biases / w_out -> LDS (zero beyond unit H), PE of both halves
-  for (int q = tid; q < (NL + 1) * HD; q += T::NW * 64) {
-    const int li = q / HD, u = q % HD;
-    float v = 0.f;
-    if (u < L.H) v = p.params[(li < NL ? L.offB[li] : L.offWout) + u];
-    biasL[(li < NL ? li : MAXL) * HD + u] = v;
-  }
-#pragma unroll 1
-  for (int h = 0; h < 2; ++h) {
-    // a wave = (HB / NW points) x (direction slices): rows are 1 KB apart, i.e. 8 banks (chain.hip's PE stage, per half)
-    const int pt = (tid % (HB / T::NW)) + (HB / T::NW) * (tid / 64), prt = (tid % 64) / (HB / T::NW);
-    constexpr int NPART = (T::NW * 64) / HB;
-    const int64_t n = n0 + h * HB + pt;
-    float x0 = 0.f, x1 = 0.f, x2 = 0.f;
-    if (n < P) { x0 = p.pts[n * 3]; x1 = p.pts[n * 3 + 1]; x2 = p.pts[n * 3 + 2]; }
-    // transform_3D_grid (transform.py:287-304) then * scale (embedding.py:12-22)
-    const float y0 = (L.T[0] * x0 + L.T[1] * x1 + L.T[2] * x2 + L.T[3]) * L.scale_input;
-    const float y1 = (L.T[4] * x0 + L.T[5] * x1 + L.T[6] * x2 + L.T[7]) * L.scale_input;
-    const float y2 = (L.T[8] * x0 + L.T[9] * x1 + L.T[10] * x2 + L.T[11]) * L.scale_input;
-    char* row = smem + h * T::HALFB + pt * ROWB;
-    auto put = [&](int feat, float v) __attribute__((always_inline)) { *(opT*)(row + swz(pt, (HD + feat) * 2)) = (opT)v; };
-    if (prt == 0) {
-      put(0, y0); put(1, y1); put(2, y2);
-      for (int f = L.E; f < EP; ++f) put(f, 0.f);
+  {
+    // all of a thread's loads in flight together: a load -> store loop pays one dependent L2 / HBM round trip per iteration
+    constexpr int NB = ((NL + 1) * HD + T::NW * 64 - 1) / (T::NW * 64);
+    float bvv[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int q = tid + i * T::NW * 64, li = q / HD, u = q % HD;
+      bvv[i] = 0.f;
+      if (q < (NL + 1) * HD && u < L.H) bvv[i] = p.params[(li < NL ? L.offB[li] : L.offWout) + u];
     }
-    for (int d = prt; d < N_DIRS; d += NPART) {
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int q = tid + i * T::NW * 64, li = q / HD, u = q % HD;
+      if (q < (NL + 1) * HD)   // hidden biases on the base-2 scale of softplus_x() (chain_dev.h)
+        biasL[(li < NL ? li : MAXL) * HD + u] = li < NL ? bvv[i] * kC1 : bvv[i];
+    }
+  }
+  {
+    // PE (embedding.py:95-111).  A lane is a POINT of a half, a wave takes (direction, half) items w, w + 8, ... of the 42: the
+    // direction is wave-uniform, so a feature's column is a scalar and its LDS address one v_xad of the lane's row base and swizzle;
+    // the octaves are unrolled (NF is a template constant), and octave pairs (1,2), (3,4) of a direction -- 4-byte aligned in the
+    // row, never across a 16-byte swizzle slot -- leave as one packed store.  (chain.hip's mapping, 8 points x 8 direction slices
+    // per wave with run-time octave loops, took 12.9 k of this workgroup's 70 k cycles: profiles/r05_fwd_pair_v1_timeline_fp16.txt.)
+    // Same arithmetic per value as chain.hip: xb = proj * 2^f, sin(xb), sin(xb + pi/2).
+    float ys[2][3];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int64_t n = n0 + h * HB + lane;
+      float x0 = 0.f, x1 = 0.f, x2 = 0.f;
+      if (n < P) { x0 = p.pts[n * 3]; x1 = p.pts[n * 3 + 1]; x2 = p.pts[n * 3 + 2]; }
+      // transform_3D_grid (transform.py:287-304) then * scale (embedding.py:12-22)
+      ys[h][0] = (L.T[0] * x0 + L.T[1] * x1 + L.T[2] * x2 + L.T[3]) * L.scale_input;
+      ys[h][1] = (L.T[4] * x0 + L.T[5] * x1 + L.T[6] * x2 + L.T[7]) * L.scale_input;
+      ys[h][2] = (L.T[8] * x0 + L.T[9] * x1 + L.T[10] * x2 + L.T[11]) * L.scale_input;
+    }
+    const int sw = (lane & 15) << 4;
+    auto put1 = [&](int rowb, int feat, float v) __attribute__((always_inline)) { *(opT*)(smem + rowb + (((HD + feat) * 2) ^ sw)) = (opT)v; };
+    auto put2 = [&](int rowb, int feat, float v0, float v1) __attribute__((always_inline)) {   // features feat, feat + 1 at a 4-byte aligned column
+      typedef opT op2 __attribute__((ext_vector_type(2)));
+      const op2 q = {(opT)v0, (opT)v1};
+      *(uint32_t*)(smem + rowb + (((HD + feat) * 2) ^ sw)) = __builtin_bit_cast(uint32_t, q);
+    };
+    if (w == T::NW - 1) {   // the identity features and the padding column, on the wave with the fewest items
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int rowb = h * T::HALFB + lane * ROWB;
+        put1(rowb, 0, ys[h][0]); put1(rowb, 1, ys[h][1]); put1(rowb, 2, ys[h][2]);
+        for (int f = 3 + 2 * N_DIRS * NF; f < EP; ++f) put1(rowb, f, 0.f);
+      }
+    }
+#pragma unroll 1
+    for (int it = w; it < 2 * N_DIRS; it += T::NW) {
+      const int h = it >= N_DIRS, d = h ? it - N_DIRS : it;
+      const float y0 = h ? ys[1][0] : ys[0][0], y1 = h ? ys[1][1] : ys[0][1], y2 = h ? ys[1][2] : ys[0][2];
+      const int rowb = h * T::HALFB + lane * ROWB;
       const float proj = y0 * kDirs[0][d] + y1 * kDirs[1][d] + y2 * kDirs[2][d];
+      float sv[NF], cv[NF];
       float fr = 1.f;
-      for (int f = 0; f < nf; ++f) {
+#pragma unroll
+      for (int f = 0; f < NF; ++f) {
         const float xb = proj * fr;
-        put(3 + d * nf + f, __sinf(xb));
-        put(3 + N_DIRS * nf + d * nf + f, __sinf(xb + kHalfPi));
+        sv[f] = __sinf(xb);
+        cv[f] = __sinf(xb + kHalfPi);
         fr *= 2.f;
       }
+      // column of (d, f) is 3 + d NF + f (+ N_DIRS NF for the shifted block): odd for f = 0 when NF is even, so the pairs start at f = 1
+      const int fs = 3 + d * NF, fc = 3 + N_DIRS * NF + d * NF;
+      static_assert(NF % 2 == 0, "the pairing below assumes an even number of octaves (odd first column of every direction)");
+      put1(rowb, fs, sv[0]); put1(rowb, fc, cv[0]);
+#pragma unroll
+      for (int f = 1; f + 1 < NF; f += 2) { put2(rowb, fs + f, sv[f], sv[f + 1]); put2(rowb, fc + f, cv[f], cv[f + 1]); }
+      put1(rowb, fs + NF - 1, sv[NF - 1]); put1(rowb, fc + NF - 1, cv[NF - 1]);
     }
   }
   TS();
@@ -150,51 +190,76 @@ __global__ __launch_bounds__(FwdPairTile::NW * 64, 2) void fwd_pair_kernel(const
                    const char* xg, char* xe, const int eli, const int eh) __attribute__((always_inline)) {
     constexpr int UK = decltype(ukc)::value, EK = decltype(ekc)::value;
     constexpr bool IS_B = decltype(isb)::value;
-    constexpr int NT = UK == UK_NONE ? 16 : uk_frags(UK);   // steps of the stage (an epilogue-only stage runs its 16 pieces)
     constexpr bool TWO = UK == UK_16T;
     // per-stage lane bases, opaque to the optimiser: otherwise every (k-step, half) address is hoisted out of the layer loop as a
     // lane constant (two dozen VGPRs at a budget that has none to spare) instead of one v_xor next to its ds_read
     int xgl = xlane + (int)(xg - smem), xel = xw + (int)(xe - smem);
     asm volatile("" : "+v"(xgl), "+v"(xel));
-    // epilogue state: the 8 biases (and, last layer, out-layer weights) of the running qp block -- features 32 w + 16 qp + 4 hi + {0..3, 8..11}
-    float bv[8], wv[8], av[8];
+    // ---- the epilogue as a software pipeline of PHASES over groups of four elements (one 8-byte piece of the tile):
+    //   phase 0  x = fma(beta log2(e), acc, bias')       phase 1  y = 2^min(x, 30)      phase 2  y = log2(1 + y)
+    //   phase 3  a = ln2/beta max(x, y), pack, store     (phase 4, fp16x2: the residual piece a - fp16(a))
+    // One phase runs behind one MFMA: its four elements are independent (the dependent steps of Softplus -- two of them
+    // transcendental -- are an MFMA apart instead of back to back: the first version, one element at a time, was bound by that
+    // latency chain: profiles/r05_fwd_pair_v1_timeline_fp16.txt), and the phases are spread evenly over the stage's MFMA slots.
+    // The same operations on the same values as chain_dev.h's softplus_x().
+    constexpr int PH = EK == EK_HILO ? 5 : 4;
+    constexpr int NQ = EK == EK_NONE ? 0 : 8 * PH;                                        // phases of the stage's epilogue
+    constexpr int NS = UK == UK_NONE ? NQ : (UK == UK_16 ? 32 : UK == UK_32 ? 64 : 96);   // MFMA slots of the stage's GEMM
+    static_assert(NS >= NQ, "at most one phase per MFMA slot");
+    float bv[2][8], wv[2][8], z[4], y[4];
     f32x2 r2 = {0.f, 0.f};
-    auto load_bv = [&](int qp) __attribute__((always_inline)) {
+    auto load_bv = [&](int qp) __attribute__((always_inline)) {   // features 32 w + 16 qp + 4 hi + {0..3, 8..11}
       if constexpr (EK != EK_NONE) {
         const float* bsrc = biasL + eli * HD + w * 32 + 16 * qp + 4 * hi;
         const float4 b0 = *(const float4*)bsrc, b1 = *(const float4*)(bsrc + 8);
-        bv[0] = b0.x; bv[1] = b0.y; bv[2] = b0.z; bv[3] = b0.w; bv[4] = b1.x; bv[5] = b1.y; bv[6] = b1.z; bv[7] = b1.w;
+        bv[qp][0] = b0.x; bv[qp][1] = b0.y; bv[qp][2] = b0.z; bv[qp][3] = b0.w; bv[qp][4] = b1.x; bv[qp][5] = b1.y; bv[qp][6] = b1.z; bv[qp][7] = b1.w;
         if constexpr (EK == EK_LAST) {
           const float* wsrc = biasL + MAXL * HD + w * 32 + 16 * qp + 4 * hi;
           const float4 w0 = *(const float4*)wsrc, w1 = *(const float4*)(wsrc + 8);
-          wv[0] = w0.x; wv[1] = w0.y; wv[2] = w0.z; wv[3] = w0.w; wv[4] = w1.x; wv[5] = w1.y; wv[6] = w1.z; wv[7] = w1.w;
+          wv[qp][0] = w0.x; wv[qp][1] = w0.y; wv[qp][2] = w0.z; wv[qp][3] = w0.w; wv[qp][4] = w1.x; wv[qp][5] = w1.y; wv[qp][6] = w1.z; wv[qp][7] = w1.w;
         }
       }
     };
     load_bv(0);
     if constexpr (EK == EK_LAST) { rawp[0] = 0.f; rawp[1] = 0.f; }
-    (void)wv; (void)r2; (void)av; (void)bv;
-    // one epilogue element: piece pc in 0..31 -> block (qp, pb) = (pc >> 4, (pc >> 3) & 1), element e = pc & 7
-    auto epi = [&](int pc) __attribute__((always_inline)) {
+    (void)wv; (void)r2; (void)z; (void)y; (void)bv;
+    auto phase = [&](int q) __attribute__((always_inline)) {
       if constexpr (EK != EK_NONE) {
-        const int qp = pc >> 4, pb = (pc >> 3) & 1, e = pc & 7;
-        av[e] = softplus_f(accE[pb][8 * qp + e] + bv[e]);
-        if constexpr (EK == EK_LAST) {
-          // w_out . a as packed FMAs of ELEMENT PAIRS (never a broadcast operand: isa_lint rule 1), same grouping as chain.hip
-          if (e & 1) {
-            r2 += f32x2{wv[e - 1], wv[e]} * f32x2{av[e - 1], av[e]};
-            if (e == 7) { rawp[pb] += r2[0] + r2[1]; r2 = f32x2{0.f, 0.f}; }
+        const int g = q / PH, ph = q % PH;
+        const int qp = g >> 2, pb = (g >> 1) & 1, hb = g & 1;     // elements 8 qp + 4 hb + {0..3} of accE[pb]
+        if (ph == 0) {
+          if (g == 2) load_bv(1);                                 // the second block's parameters, well ahead of group 4
+#pragma unroll
+          for (int i = 0; i < 4; ++i) z[i] = __builtin_fmaf(kC1, accE[pb][8 * qp + 4 * hb + i], bv[qp][4 * hb + i]);
+        } else if (ph == 1) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) y[i] = __builtin_amdgcn_exp2f(fminf(z[i], 30.f));
+        } else if (ph == 2) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) y[i] = __builtin_amdgcn_logf(1.f + y[i]);
+        } else if (ph == 3) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) z[i] = kC2 * fmaxf(z[i], y[i]);          // z <- the activation
+          if constexpr (EK == EK_LAST) {
+            // w_out . a as packed FMAs of ELEMENT PAIRS (never a broadcast operand: isa_lint rule 1), same grouping as chain.hip
+            r2 += f32x2{wv[qp][4 * hb], wv[qp][4 * hb + 1]} * f32x2{z[0], z[1]};
+            r2 += f32x2{wv[qp][4 * hb + 2], wv[qp][4 * hb + 3]} * f32x2{z[2], z[3]};
+            if (hb == 1) { rawp[pb] += r2[0] + r2[1]; r2 = f32x2{0.f, 0.f}; }
+          } else {   // four values -> one 8-byte piece of the tile (features f0 .. f0+3 | f0+8 .. f0+11)
+            const int lb = ((xel ^ (32 * qp)) + pb * 32 * ROWB) ^ (hb ? 16 : 0);
+            *(uint2*)(smem + lb) = pack4<EK == EK_HILO ? true : F16>(z[0], z[1], z[2], z[3]);
           }
-        } else if (e == 3 || e == 7) {   // four values -> one 8-byte piece of the tile (features f0 .. f0+3 | f0+8 .. f0+11)
-          const int lb = ((xel ^ (32 * qp)) + pb * 32 * ROWB) ^ (e == 7 ? 16 : 0);
-          if constexpr (EK == EK_HILO) {   // region 1 <- fp16(a), region 2 <- fp16(a - fp16(a))
-            *(uint2*)(smem + lb) = pack4<true>(av[e - 3], av[e - 2], av[e - 1], av[e]);
-            *(uint2*)(smem + lb + HD * 2) = pack4<true>(f16_residual(av[e - 3]), f16_residual(av[e - 2]), f16_residual(av[e - 1]), f16_residual(av[e]));
-          } else {
-            *(uint2*)(smem + lb) = pack4<F16>(av[e - 3], av[e - 2], av[e - 1], av[e]);
-          }
+        } else {     // fp16x2: region 2 <- fp16(a - fp16(a)), the second operand of the next layer's compensated GEMM
+          const int lb = ((xel ^ (32 * qp)) + pb * 32 * ROWB) ^ (hb ? 16 : 0);
+          *(uint2*)(smem + lb + HD * 2) = pack4<true>(f16_residual(z[0]), f16_residual(z[1]), f16_residual(z[2]), f16_residual(z[3]));
         }
-        if (pc == 15) load_bv(1);   // the second block's parameters, behind the first block's last use
+      }
+    };
+    // the phases that run behind MFMA slot m: phase q sits in slot q NS / NQ
+    auto slot_done = [&](int m) __attribute__((always_inline)) {
+      if constexpr (EK != EK_NONE) {
+        const int q = (m * NQ + NS - 1) / NS;          // the only candidate (NS >= NQ): the smallest q with q NS / NQ >= m
+        if (q < NQ && q * NS / NQ == m) phase(q);
       }
     };
     // operand reads of step t: segment / k-step / LDS column.  The first operand is read one step ahead (double-buffered); the second
@@ -208,57 +273,61 @@ __global__ __launch_bounds__(FwdPairTile::NW * 64, 2) void fwd_pair_kernel(const
       return (xgl ^ ((ks & 7) * 32)) + (ks >> 3) * 256 + col;
     };
     auto readb = [&](int t, v8 (&b)[2]) __attribute__((always_inline)) {
-      if constexpr (UK != UK_NONE) {
-        const int a = opaddr(t);
+      const int a = opaddr(t);
 #pragma unroll
-        for (int pb = 0; pb < 2; ++pb) b[pb] = __builtin_bit_cast(v8, *(const uint4*)(smem + a + pb * 32 * ROWB));
-      }
+      for (int pb = 0; pb < 2; ++pb) b[pb] = __builtin_bit_cast(v8, *(const uint4*)(smem + a + pb * 32 * ROWB));
     };
     auto readlo = [&](int t) __attribute__((always_inline)) {
-      if constexpr (TWO) {
-        const int a = opaddr(t) + HD * 2;
+      const int a = opaddr(t) + HD * 2;
 #pragma unroll
-        for (int pb = 0; pb < 2; ++pb) bl[pb] = __builtin_bit_cast(v8, *(const uint4*)(smem + a + pb * 32 * ROWB));
-      }
+      for (int pb = 0; pb < 2; ++pb) bl[pb] = __builtin_bit_cast(v8, *(const uint4*)(smem + a + pb * 32 * ROWB));
     };
-    (void)bl;
-    readb(0, bq[0]);
-    __builtin_amdgcn_sched_barrier(0);
+    (void)bl; (void)bq;
+    if constexpr (UK == UK_NONE) {
+      // epilogue-only stage (the last layer of the second half): no MFMA to hide behind, the scheduler may interleave the groups freely
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      const int r = t & 15;
-      if constexpr (UK != UK_NONE) {
+      for (int q = 0; q < NQ; ++q) phase(q);
+    } else {
+      constexpr int NT = uk_frags(UK);
+      readb(0, bq[0]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int r = t & 15;
+        const bool two = TWO && t < 16;
+        const int m0 = TWO ? (t < 16 ? 4 * t : 64 + 2 * (t - 16)) : 2 * t;   // first MFMA slot of the step
         if (t + 1 < NT) readb(t + 1, bq[(t + 1) & 1]);
-        if (TWO && t < 16) readlo(t);
+        if constexpr (TWO) { if (t < 16) readlo(t); }
         __builtin_amdgcn_sched_barrier(0);
         accG[0] = Op<F16>::mfma(__builtin_bit_cast(v8, W[r]), bq[t & 1][0], t == 0 ? f32x16(0.f) : accG[0]);
         __builtin_amdgcn_sched_barrier(0);
-      }
-      if (t < 16) epi(2 * t);
-      if constexpr (UK != UK_NONE) {
+        slot_done(m0);
         __builtin_amdgcn_sched_barrier(0);
         accG[1] = Op<F16>::mfma(__builtin_bit_cast(v8, W[r]), bq[t & 1][1], t == 0 ? f32x16(0.f) : accG[1]);
         __builtin_amdgcn_sched_barrier(0);
-      }
-      if (t < 16) epi(2 * t + 1);
-      if constexpr (UK != UK_NONE) {
+        slot_done(m0 + 1);
         if constexpr (TWO) {
-          if (t < 16) {
+          if (two) {
             __builtin_amdgcn_sched_barrier(0);
             accG[0] = Op<F16>::mfma(__builtin_bit_cast(v8, W[r]), bl[0], accG[0]);
+            __builtin_amdgcn_sched_barrier(0);
+            slot_done(m0 + 2);
+            __builtin_amdgcn_sched_barrier(0);
             accG[1] = Op<F16>::mfma(__builtin_bit_cast(v8, W[r]), bl[1], accG[1]);
+            __builtin_amdgcn_sched_barrier(0);
+            slot_done(m0 + 3);
           }
         }
         // the window register's next tenant
-        constexpr int NF = uk_frags(UK);
-        if (t + 16 < NF) {   // this unit's fragment t + 16
+        constexpr int NF_ = uk_frags(UK);
+        if (t + 16 < NF_) {   // this unit's fragment t + 16
           const int tt = t + 16;
           if (UK == UK_32) W[r] = frag(u.soff0, tt);
           else if (UK == UK_16T) W[r] = frag(u.soff1, tt - 16);
           else W[r] = tt < 32 ? frag(u.soff0, tt) : frag(u.soff1, tt - 32);
         } else if (IS_B) {
           W[r] = frag(nxtSoff0, r);              // the next unit's fragment r, a stage ahead of half A
-        } else if (NF > 16) {
+        } else if (NF_ > 16) {
           W[r] = frag(u.soff0, r);               // half B starts the unit over
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -324,15 +393,16 @@ __global__ __launch_bounds__(FwdPairTile::NW * 64, 2) void fwd_pair_kernel(const
 
 template <int OPER>
 static int launch_fwd_pair_oper(const ChainParams& p, int64_t nPairs, hipStream_t st) {
-  auto k = fwd_pair_kernel<OPER, 6, 3>;
+  auto k = fwd_pair_kernel<OPER, 6, 3, 6>;
   if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, FwdPairTile::LDS_BYTES) != hipSuccess) return ISDF_EHIP;
   hipLaunchKernelGGL(k, dim3((unsigned)nPairs), dim3(FwdPairTile::NW * 64), FwdPairTile::LDS_BYTES, st, p);
   return isdf_launch_status();
 }
 
-// MODE 0 of the <256, 256> tile with hidden_layers_block = 2 (every shipped config: 6 hidden layers, cat layer 3) for the bf16 /
+// MODE 0 of the <256, 256> tile with hidden_layers_block = 2 and 6 PE octaves (replicaCAD.json / scanNet.json: 6 hidden layers, cat
+// layer 3, E = 255) for the bf16 /
 // fp16 / fp16x2 operand modes; other depths and fp16x2_full (four operand regions) stay on chain.hip's one-tile kernel
-bool fwd_pair_supported(const NetLayout& l) { return l.HD == 256 && l.EP == 256 && !l.fwd_x2_all && l.L == 6 && l.cat == 3; }
+bool fwd_pair_supported(const NetLayout& l) { return l.HD == 256 && l.EP == 256 && !l.fwd_x2_all && l.L == 6 && l.cat == 3 && l.n_freqs == 6; }
 
 int launch_fwd_pair(const ChainParams& p, int64_t nTiles, hipStream_t st) {
   const int64_t nPairs = (nTiles + 1) / 2;

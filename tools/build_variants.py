@@ -5,7 +5,10 @@ carry no `#if` experiment switches):
 
     python tools/build_variants.py name1="-DFLAG=1 ..." name2=@tools/variants/some.patch      (base = the tree as it is, always built)
 
-A patch is applied (`patch -p1`, paths as `git diff` writes them) to a scratch copy of isdf_amd/csrc + include/."""
+A patch is applied (`patch -p1`, paths as `git diff` writes them) to a scratch copy of isdf_amd/csrc + include/.
+A spec of the form  name=sed:FILE:SCRIPT  runs `sed -E SCRIPT` over csrc/FILE of the scratch copy instead (one-line variants that
+survive edits of the surrounding code), e.g. the A/B partner of the pair-tile forward kernel:
+    onetile='sed:fwd_pair.hip:s/^(bool fwd_pair_supported\(const NetLayout& l\) \{).*$/\1 (void)l; return false; }/'"""
 import os, shutil, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -17,7 +20,14 @@ def patched_sources(patch):
     os.makedirs(os.path.join(tmp, "isdf_amd"))
     shutil.copytree(b.CSRC, os.path.join(tmp, "isdf_amd", "csrc"))
     shutil.copytree(os.path.join(ROOT, "include"), os.path.join(tmp, "include"))
-    subprocess.check_call(["patch", "-p1", "-s", "-i", os.path.abspath(patch)], cwd=tmp)
+    if patch.startswith("sed:"):
+        _, fname, script = patch.split(":", 2)
+        target = os.path.join(tmp, "isdf_amd", "csrc", fname)
+        before = open(target).read()
+        subprocess.check_call(["sed", "-E", "-i", script, target])
+        assert open(target).read() != before, "sed variant changed nothing: " + patch
+    else:
+        subprocess.check_call(["patch", "-p1", "-s", "-i", os.path.abspath(patch)], cwd=tmp)
     return os.path.join(tmp, "isdf_amd", "csrc")
 
 
@@ -33,6 +43,8 @@ def main():
         csrc, flags = b.CSRC, spec
         if spec.startswith("@"):
             csrc, flags = patched_sources(spec[1:]), ""
+        elif spec.startswith("sed:"):
+            csrc, flags = patched_sources(spec), ""
         for src in b.SOURCES:
             if not spec:
                 continue
