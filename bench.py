@@ -279,15 +279,24 @@ def infer_bench(args, tr, eng, rank):
             key = name if op == eng.net.fwd_operand else name + "[fwd_operand=%s]" % op
             out[key] = {"points": n, "ms": round(t * 1e3, 4), "points_per_s": round(n / t, 1), "fwd_operand": op,
                         "TFLOPs": round(flop * n / t / 1e12, 1), "frac_of_mfma_peak": round(flop * n / t / MFMA_PEAK, 4)}
+    issue_port, ipath = None, latest_profile("issue_port.json")
+    if ipath:
+        with open(ipath) as fh:
+            ij = json.load(fh)
+        if "fwd_pair_kernel" in ij:
+            ck = ij["fwd_pair_kernel"]
+            issue_port = {"utilisation": ck["issue_port_utilisation"], "matrix_pipe_utilisation_at_clock": ck["matrix_pipe_utilisation"],
+                          "valu_instructions_per_mfma": ck["valu_instructions_per_mfma"], "source": os.path.relpath(ipath, ROOT),
+                          "what": "fp16 operands, 2 M points (tools/pmc_issue_mix.sh); model: " + ij.get("model", "")}
     f = out["forward"]
     res = {"metric": "inference points/s (SDFMap.forward on the fused kernel, one call)", "value": f["points_per_s"], "unit": "points/s",
            "n_gpus": 1, "steps": max(args.steps // 30, 5), "warmup": 3, "ms_per_step": f["ms"], "higher_is_better": True,
            "scaling": "weak", "vs_baseline": None, "dtype": "f16 MFMA operands (%s), f32 accumulate" % eng.net.fwd_operand, "data": "synthetic",
            "config": {"workload": "%d uniform points in the synthetic room, default 6x256 net (meshing / slice grid size)" % N},
            "modes": out,
-           "roofline": {"bound": "mfma", "kernel": "chain_kernel MODE 0 (PE + MLP forward)", "achieved": f["TFLOPs"], "peak": MFMA_PEAK / 1e12,
+           "roofline": {"bound": "mfma", "kernel": "fwd_pair_kernel (PE + MLP forward, two 64-point halves per workgroup; csrc/fwd_pair.hip)", "achieved": f["TFLOPs"], "peak": MFMA_PEAK / 1e12,
                         "unit": "TFLOP/s", "frac": f["frac_of_mfma_peak"], "traffic": None,
-                        "algorithmic_flop_per_launch": 2.0 * M * N}}
+                        "algorithmic_flop_per_launch": 2.0 * M * N, "issue_port": issue_port}}
     if rank == 0:
         print(json.dumps(res), flush=True)
 
@@ -570,6 +579,19 @@ def main():
         with open(tpath) as f:                                    # the committed rocprofv3 --pmc measurement of this
             tj = json.load(f)                                     # command (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)
         traffic, traffic_src = tj["chain_kernel"]["hbm_bytes"], tj["source"]
+    # the SIMD issue-port model of the kernel (tools/issue_model.py on a committed rocprofv3 --pmc summary, like `traffic`): on this chip
+    # a VALU wave-instruction next to MFMAs costs ~4 issue cycles of its SIMD (transcendental 8, MFMA 8 of the 32 it executes for):
+    # with ~11 VALU instructions per MFMA the tile kernels run out of issue slots long before they run out of matrix pipe
+    issue_port, ipath = None, latest_profile("issue_port.json")
+    if ipath and args.rays_per_frame == 200 and not args.wide:
+        with open(ipath) as f:
+            ij = json.load(f)
+        if "chain_kernel" in ij:
+            ck = ij["chain_kernel"]
+            issue_port = {"utilisation": ck["issue_port_utilisation"], "matrix_pipe_utilisation_at_clock": ck["matrix_pipe_utilisation"],
+                          "valu_instructions_per_mfma": ck["valu_instructions_per_mfma"],
+                          "valu_cycles_per_instruction": ck["valu_cycles_per_instruction"],
+                          "source": os.path.relpath(ipath, ROOT), "model": ij.get("model")}
     batches = world if (args.scaling == "weak" or world == 1) else 1
     per_rank_chain_us, per_rank_elapsed = [round(t_chain * 1e6, 1)], [round(my_elapsed, 4)]
     if group is not None:      # every rank's own chain-kernel time and wall clock in the line (rank 0 prints)
@@ -651,6 +673,7 @@ def main():
                          "traffic_unit": "HBM bytes per launch (rocprofv3 --pmc, separate passes)", "traffic_source": traffic_src,
                          "hbm_GBps_at_that_traffic": None if traffic is None else round(traffic / t_chain / 1e9, 1),
                          "algorithmic_flop_per_launch": flops_chain,
+                         "issue_port": issue_port,
                          "whole_step_frac_of_mfma_peak": round(12.0 * m_mac * P * K / elapsed / MFMA_PEAK, 5)},
         }
         if world == 1 and not args.no_cpu_baseline:

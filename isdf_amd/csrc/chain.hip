@@ -262,6 +262,43 @@ __global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 && EP == HD && !oper_x2_a
   // thread (pt, part): embedding.py:95-111.  Region 2 of X (cols HD..) gets the
   // embedding in the forward operand type; region 1 a bf16 copy staged for the
   // spill (dW operand A_0).
+  if constexpr (!WIDE_E && BM == 64) {
+    // Round 5: a lane is a POINT, a wave takes directions w, w + 8, w + 16: the direction is wave-uniform, so a feature's column is
+    // a scalar and its LDS address one v_xad of the lane's row base and swizzle, instead of a handful of per-lane integer operations
+    // per 2-byte store (the 8 points x 8 direction slices mapping below took 12.9 k cycles per tile in the forward kernel, this one
+    // ~7 k: profiles/r05_fwd_pair_v1/v2_timeline_fp16.txt).  Same arithmetic per value, so the same bits.
+    const int ln = tid & 63;
+    const int64_t n = n0 + ln;
+    float x0 = 0.f, x1 = 0.f, x2 = 0.f;
+    if (n < P) { x0 = p.pts[n * 3]; x1 = p.pts[n * 3 + 1]; x2 = p.pts[n * 3 + 2]; }
+    // transform_3D_grid (transform.py:287-304) then * scale (embedding.py:12-22)
+    const float y0 = (L.T[0] * x0 + L.T[1] * x1 + L.T[2] * x2 + L.T[3]) * L.scale_input;
+    const float y1 = (L.T[4] * x0 + L.T[5] * x1 + L.T[6] * x2 + L.T[7]) * L.scale_input;
+    const float y2 = (L.T[8] * x0 + L.T[9] * x1 + L.T[10] * x2 + L.T[11]) * L.scale_input;
+    typedef typename Op<F16>::e opT;
+    const int sw = (ln & 15) << 4;
+    char* row = X + ln * ROWB;
+    auto put = [&](int feat, float v) {
+      *(opT*)(row + (((HD + feat) * 2) ^ sw)) = (opT)v;
+      if (X2ALL) *(opT*)(row + (((LO + HD + feat) * 2) ^ sw)) = (opT)(v - (float)(opT)v);   // emb_lo
+      if (MODE == 2) *(spillT*)(row + ((feat * 2) ^ sw)) = (spillT)v;   // copy in the spill type, staged for the spill
+    };
+    if (w == T::NW - 1) {   // (the wave with the fewest directions)
+      xs[ln * 4] = y0; xs[ln * 4 + 1] = y1; xs[ln * 4 + 2] = y2;
+      put(0, y0); put(1, y1); put(2, y2);
+      for (int f = L.E; f < EP; ++f) put(f, 0.f);
+    }
+    for (int d = w; d < N_DIRS; d += T::NW) {
+      const float proj = y0 * kDirs[0][d] + y1 * kDirs[1][d] + y2 * kDirs[2][d];
+      float fr = 1.f;
+      for (int f = 0; f < nf; ++f) {
+        const float xb = proj * fr;
+        put(3 + d * nf + f, __sinf(xb));
+        put(3 + N_DIRS * nf + d * nf + f, __sinf(xb + kHalfPi));
+        fr *= 2.f;
+      }
+    }
+  } else
   {
     // a wave = (BM / NW points) x (direction slices): rows are 1 KB apart, i.e. 8 banks -- 64 points per wave was 8-way conflicted
     const int pt = (tid % (BM / T::NW)) + (BM / T::NW) * (tid / 64), prt = (tid % 64) / (BM / T::NW);
@@ -393,6 +430,13 @@ __global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 && EP == HD && !oper_x2_a
     load_tile8(pr, fb, pb, qp, o);
 #pragma unroll
     for (int e = 0; e < 8; ++e) o[e] = s1_from_a(o[e]);
+  };
+  // ... and t = 1 - sigma' = exp(-beta a) with it: the injected second-order term needs (1 - sigma') / sigma', and 1 - (1 - t) is the
+  // less accurate (and one instruction longer) way to get t back
+  auto load_s1t = [&](const Pre& pr, int fb, int pb, int qp, float (&o)[8], float (&t)[8]) {
+    load_tile8(pr, fb, pb, qp, o);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { t[e] = __builtin_amdgcn_exp2f(-kC1 * o[e]); o[e] = 1.f - t[e]; }
   };
   auto put_x = [&](bool f16, int fb, int pb, int qp, const float (&v)[8], int colElemBase) {
     uint2 a, b;
@@ -606,6 +650,32 @@ __global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 && EP == HD && !oper_x2_a
     }
   lds_barrier();
   TS();   // (Eg staged in LDS)
+  if constexpr (BM == 64) {
+    // lane = point, wave = direction slice w (the partial sum of slice w lands where slice `prt` of the mapping below put it: same
+    // partial sums, same summation order in the loss stage)
+    static_assert(T::NPART == T::NW, "one partial g per wave");
+    const int ln = tid & 63, sw = (ln & 15) << 4;
+    const float y0 = xs[ln * 4], y1 = xs[ln * 4 + 1], y2 = xs[ln * 4 + 2];
+    const char* row = X + ln * ROWB;
+    auto eg = [&](int feat) { return *(const float*)(row + ((feat * 4) ^ sw)); };
+    float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+    if (w == 0) { g0 = eg(0); g1 = eg(1); g2 = eg(2); }
+    const int half = N_DIRS * nf;
+    for (int d = w; d < N_DIRS; d += T::NW) {
+      const float dx = kDirs[0][d], dy = kDirs[1][d], dz = kDirs[2][d];
+      const float proj = y0 * dx + y1 * dy + y2 * dz;
+      float fr = 1.f, c = 0.f;
+      for (int f = 0; f < nf; ++f) {
+        const float xb = proj * fr;
+        // d sin(xb)/d proj = cos(xb) fr ;  d sin(xb + pi/2)/d proj = cos(xb + pi/2) fr
+        c += (__cosf(xb) * eg(3 + d * nf + f) + __cosf(xb + kHalfPi) * eg(3 + half + d * nf + f)) * fr;
+        fr *= 2.f;
+      }
+      g0 += c * dx; g1 += c * dy; g2 += c * dz;
+    }
+    float* dst = part + (w * BM + ln) * 4;
+    dst[0] = g0; dst[1] = g1; dst[2] = g2;
+  } else
   {
     // a wave = (BM / NW points) x (direction slices): rows are 1 KB apart, i.e. 8 banks -- 64 points per wave was 8-way conflicted
     const int pt = (tid % (BM / T::NW)) + (BM / T::NW) * (tid / 64), prt = (tid % 64) / (BM / T::NW);
@@ -805,6 +875,30 @@ __global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 && EP == HD && !oper_x2_a
     const float4 wv4 = make_float4(__uint_as_float(w4[0]), __uint_as_float(w4[1]), __uint_as_float(w4[2]), __uint_as_float(w4[3]));
     ((float4*)part)[tid] = wv4;
   }
+  if constexpr (!WIDE_E && BM == 64) {
+    // lane = point, wave = direction slice (see the PE stage)
+    const int ln = tid & 63, sw = (ln & 15) << 4;
+    const float y0 = xs[ln * 4], y1 = xs[ln * 4 + 1], y2 = xs[ln * 4 + 2];
+    const float b0 = gbs[ln * 4], b1 = gbs[ln * 4 + 1], b2 = gbs[ln * 4 + 2];
+    char* row = X + ln * ROWB;
+    auto put = [&](int feat, float v) { *(spillT*)(row + (((HD + feat) * 2) ^ sw)) = (spillT)v; };
+    if (w == T::NW - 1) {
+      put(0, b0); put(1, b1); put(2, b2);
+      for (int f = L.E; f < EP; ++f) put(f, 0.f);
+    }
+    for (int d = w; d < N_DIRS; d += T::NW) {
+      const float dx = kDirs[0][d], dy = kDirs[1][d], dz = kDirs[2][d];
+      const float proj = y0 * dx + y1 * dy + y2 * dz;
+      const float c = b0 * dx + b1 * dy + b2 * dz;
+      float fr = 1.f;
+      for (int f = 0; f < nf; ++f) {
+        const float xb = proj * fr;
+        put(3 + d * nf + f, __cosf(xb) * fr * c);
+        put(3 + N_DIRS * nf + d * nf + f, __cosf(xb + kHalfPi) * fr * c);
+        fr *= 2.f;
+      }
+    }
+  } else
   {
     // a wave = (BM / NW points) x (direction slices): rows are 1 KB apart, i.e. 8 banks -- 64 points per wave was 8-way conflicted
     const int pt = (tid % (BM / T::NW)) + (BM / T::NW) * (tid / 64), prt = (tid % 64) / (BM / T::NW);
@@ -897,9 +991,9 @@ __global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 && EP == HD && !oper_x2_a
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const float u = acc[fb][pb][8 * qp + e];
-        const float s1 = s1_from_a(a[e]);
+        const float t1 = __builtin_amdgcn_exp2f(-kC1 * a[e]), s1 = 1.f - t1;    // sigma' and 1 - sigma' = exp(-beta a)
         qsum[e] += u * s1;
-        zb[e] = sb * wv[e] * s1 + kBeta * u * pv[e] * (1.f - s1);
+        zb[e] = sb * wv[e] * s1 + kBeta * u * pv[e] * t1;
         bsum[e] += zb[e];
         wsum[e] += sb * a[e];
       }
@@ -938,16 +1032,18 @@ __global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 && EP == HD && !oper_x2_a
 #pragma unroll
     for (int e = 0; e < 8; ++e) bsum[e] = 0.f;
     for_blocks2([&](int fb, int pb, int qp, int row) {
-      float a[8], gq[8], pv[8], zb[8];
-      load_s1(preA, fb, pb, qp, a);   // a[] = sigma'
+      float a[8], t1[8], gq[8], pv[8], zb[8];
+      load_s1t(preA, fb, pb, qp, a, t1);   // a[] = sigma', t1[] = 1 - sigma' = exp(-beta a)
       if (li == L.L - 2) preG.v[fb][qp][pb] = *(const uint4*)(X + park_addr(cidx(fb, pb, qp)));
       load_tile8(preG, fb, pb, qp, gq);
       load_tile8(preP, fb, pb, qp, pv);
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const float s1 = a[e];
-        // injected term; sigma' -> 0 takes u sigma' and q sigma' with it (and a bf16 activation of 0 gives sigma' = 0 exactly)
-        const float inj = s1 > 0.f ? kBeta * gq[e] * pv[e] * (1.f - s1) * __builtin_amdgcn_rcpf(s1) : 0.f;
+        // injected term beta (u sigma') (q sigma') (1 - sigma') / sigma'.  sigma' -> 0 takes u sigma' and q sigma' with it (a stored
+        // activation of 0 gives sigma' = 0 exactly, and GB / P were formed with that same sigma': exact zeros), so a floor under the
+        // divisor is all the guard it needs: 0 * t / 1e-30 = 0 -- one v_max instead of a compare and a select
+        const float inj = (kBeta * gq[e]) * (pv[e] * t1[e]) * __builtin_amdgcn_rcpf(fmaxf(s1, 1e-30f));
         zb[e] = acc[fb][pb][8 * qp + e] * s1 + inj;
         bsum[e] += zb[e];
       }

@@ -165,6 +165,18 @@ def trained_batch(g, prefix):
                 indices_b=ib, indices_h=g[prefix + "indices_h"].astype(np.int64), indices_w=g[prefix + "indices_w"].astype(np.int64))
 
 
+def trained_eval_grads(g, names):
+    """reference gradients of a trained-state fixture's eval batch: stored in full (`trained_default`) or as float16 mantissas on a
+    per-tensor power-of-two scale (`trained_franka`: 3e-4 rel-L2 of storage rounding, make_golden.run_trained_case grads_fp16)"""
+    out = {}
+    for k in names:
+        if "eval/grad/" + k in g:
+            out[k] = g["eval/grad/" + k].astype(np.float64)
+        else:
+            out[k] = g["eval/grad16/" + k].astype(np.float64) * float(g["eval/grad16_scale/" + k][0])
+    return out
+
+
 def trained_adam_state(g, names):
     """the trajectory's start state: AdamW moments stored as bfloat16 bit patterns (they ARE the exact start state: the
     reference run loaded these rounded values, make_golden.run_trained_case)"""

@@ -23,6 +23,7 @@ pytestmark = pytest.mark.gpu
 TOL_SDF = 1e-3
 TOL_LOSS = 1e-3
 TOL_SDF_GRAD = 2e-3
+TOL_SDF_GRAD_TRAINED = 1e-3   # SURVEY 8c's bar on d sdf / d x, met at trained weights in the default mode (measured 4.4e-4)
 TOL_DW = 1e-2
 TOL_DW_BWD16 = 3e-3      # BASELINE-size fixtures, default operand types (fp16 second-order sweeps and dW operands)
 
@@ -1299,7 +1300,7 @@ def test_trained_weights_step_vs_reference(bwd_operand):
     print("  per-tensor rel-L2:", {k: round(v["rel_l2"], 5) for k, v in m["tensors"].items()})
     print("  worst tensor rel-L2:", max((v["rel_l2"], k) for k, v in m["tensors"].items()),
           " worst |signed|:", max((abs(v["signed"]), k) for k, v in m["tensors"].items()))
-    assert m["sdf"] < TOL_SDF and m["sdf_grad"] < TOL_SDF_GRAD, (m["sdf"], m["sdf_grad"])
+    assert m["sdf"] < TOL_SDF and m["sdf_grad"] < TOL_SDF_GRAD_TRAINED, (m["sdf"], m["sdf_grad"])
     for k, e in m["losses"].items():
         assert e < TOL_LOSS, (k, e)
     for k, v in m["tensors"].items():
@@ -1308,6 +1309,92 @@ def test_trained_weights_step_vs_reference(bwd_operand):
         assert v["cos"] > 0.999 and v["rel_l2"] < TOL_DW, (k, v)
         assert abs(v["signed"]) < TOL_SIGNED, (k, v)
     assert m["all"]["rel_l2"] < TOL_DW and abs(m["all"]["signed"]) < TOL_SIGNED_ALL, m["all"]
+
+
+def test_trained_weights_franka_constants_vs_reference():
+    """realsense_franka.json's constants (9 PE octaves, scale_input 0.4, trunc_weight 30) at TRAINED weights --
+    fixture `trained_franka`, 300 unmodified reference steps, then an eval batch with all gradients.  At random initialisation this
+    net's END-TO-END gradient sits 1.6e-2 from the reference's for any 16-bit-operand path (eval_rs_franka: the non-smooth loss turns
+    forward rounding into flipped residual signs, test_realsense_config_nets_match_oracle); at a trained state the bar is 1e-2."""
+    g = gu.load("trained_franka")
+    eng = _engine(g)
+    lc, sc = _cfgs(g)
+    b = gu.trained_batch(g, "eval/")
+    smp = _smp_from_batch(b, int(g["n_frames"][0]))
+    sdf, grad = eng.sdf_eval(_dev(b["pc"].reshape(-1, 3)), want_grad=True)
+    eng.train_step(smp, lc, sc, noise=_dev(b["noise"]))
+    torch.cuda.synchronize()
+    ls = eng.loss_sums().cpu().numpy().astype(np.float64)
+    N = ls[4]
+    e_sdf = gu.rel_err(sdf.cpu().numpy(), g["eval/sdf_nonoise"].reshape(-1))
+    e_grad = gu.rel_err(grad.cpu().numpy(), g["eval/sdf_grad"].reshape(-1, 3))
+    losses = {k: abs(ls[i] / N - g["eval/" + k][0]) / abs(g["eval/" + k][0])
+              for i, k in enumerate(("sdf_loss", "grad_loss", "eikonal_loss", "total_loss"))}
+    names = list(gu.params_of(g))
+    ref = gu.trained_eval_grads(g, names)
+    per = {}
+    allg, allr = [], []
+    for k in names:
+        got = (eng.grad_view(k).cpu().numpy().astype(np.float64) / N).reshape(-1)
+        r = ref[k].reshape(-1)
+        per[k] = (gu.rel_err(got, r), gu.signed_projection(got, r))
+        allg.append(got); allr.append(r)
+    allg, allr = np.concatenate(allg), np.concatenate(allr)
+    worst = max((v[0], k) for k, v in per.items() if k != "out_alpha.bias")
+    print("trained franka constants: sdf %.2e  d sdf/dx %.2e  losses %s" % (e_sdf, e_grad, {k: round(v, 6) for k, v in losses.items()}))
+    print("  per-tensor rel-L2:", {k: round(v[0], 5) for k, v in per.items()})
+    print("  worst tensor %.3e at %s; all parameters rel-L2 %.3e signed %.2e" % (worst[0], worst[1], gu.rel_err(allg, allr), gu.signed_projection(allg, allr)))
+    assert e_sdf < TOL_SDF and e_grad < TOL_SDF_GRAD, (e_sdf, e_grad)
+    for k, e in losses.items():
+        assert e < 2 * TOL_LOSS, (k, e)
+    assert worst[0] < TOL_DW, worst                      # the end-to-end gradient at 1e-2, every tensor (SURVEY 8c)
+    assert gu.rel_err(allg, allr) < TOL_DW and abs(gu.signed_projection(allg, allr)) < TOL_SIGNED_ALL
+
+
+@pytest.mark.parametrize("fwd_operand", ["fp16x2", "fp16", "bf16"])
+def test_pair_tile_forward_kernel_agrees_with_the_one_tile_forward(fwd_operand):
+    """round 5: `sdf_eval` without the input gradient runs on the pair-tile forward kernel (csrc/fwd_pair.hip: two 64-point halves per
+    workgroup, the MFMAs of one half interleaved with the other half's Softplus epilogue); with the input gradient it runs on the
+    one-tile chain kernel.  Same operands, same accumulation order, Softplus on the base-2 image of the pre-activation in the former:
+    the two forward passes agree to a few flipped operand roundings (tools/fwd_pair_check.py has the bit-identity history)."""
+    from isdf_amd.engine import Engine, NetConfig
+    from isdf_amd import synthetic
+    eng = Engine(NetConfig(transform=synthetic.bounds_transform(), fwd_operand=fwd_operand), "cuda")
+    torch.manual_seed(7); eng.params.normal_(0, 0.06); eng.pack()
+    g = torch.Generator(device="cpu"); g.manual_seed(12)
+    x = ((torch.rand(70001, 3, generator=g) - 0.5) * torch.tensor([6.0, 3.0, 5.0])).cuda()
+    bar = {"fp16x2": 5e-5, "fp16": 1e-4, "bf16": 5e-4}[fwd_operand]
+    for n in (1, 63, 64, 65, 127, 128, 129, 70001):      # ragged: half-filled halves and pairs
+        a = eng.sdf_eval(x[:n])
+        b, _ = eng.sdf_eval(x[:n], want_grad=True)
+        d = float((a - b).abs().max())
+        assert torch.isfinite(a).all() and d <= bar, (fwd_operand, n, d)
+    nz = (torch.randn(5000, generator=g) * 0.01).cuda()
+    d = float((eng.sdf_eval(x[:5000], noise=nz) - eng.sdf_eval(x[:5000], noise=nz, want_grad=True)[0]).abs().max())
+    assert d <= bar, d
+
+
+def test_fp16_second_order_sweeps_hold_their_range_under_small_loss_weights():
+    """the second-order sweeps and the dW operands are fp16 by default.  Adjoints scale with the loss weights: with eik /
+    grad weights 1e-3 of the shipped ones the second-order adjoints sink towards the fp16 subnormals (< 6e-5 loses significand bits).
+    The gradient must then still agree with the bf16 sweeps (8 significand bits but fp32 range) to the bf16 sweeps' own accuracy."""
+    g = gu.load("eval_base_480x640_ray")
+    lc, sc = _cfgs(g)
+    import dataclasses
+    lc_small = dataclasses.replace(lc, eik_weight=lc.eik_weight * 1e-3, grad_weight=lc.grad_weight * 1e-3)
+    out = {}
+    for bwd in ("fp16", "bf16"):
+        eng = _engine(g, "fp16x2", bwd)
+        s_ = _sample_hip(eng, g, sc)
+        R = g["depth_sample"].shape[0]
+        noise = g["draw_noise"].reshape(R, -1) * np.float32(g["noise_std"][0])
+        eng.train_step(s_, lc_small, sc, noise=_dev(noise))
+        torch.cuda.synchronize()
+        out[bwd] = eng.reduce_buf[:eng.n_params].cpu().numpy().astype(np.float64)
+        assert np.isfinite(out[bwd]).all()
+    e = gu.rel_err(out["fp16"], out["bf16"])
+    print("loss weights x 1e-3: all-parameter gradient fp16 sweeps vs bf16 sweeps rel-L2 %.2e" % e)
+    assert e < 8e-3, e       # the bf16 sweeps' own error vs the reference is 3e-3 .. 4e-3 (rounds 1-3)
 
 
 @pytest.mark.parametrize("bwd_operand", [None, "bf16"])

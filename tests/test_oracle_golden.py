@@ -300,6 +300,30 @@ def test_oracle_at_trained_weights():
         assert abs(gu.signed_projection(grads[k], ref)) < 1e-4, (k, gu.signed_projection(grads[k], ref))
 
 
+def test_oracle_at_trained_weights_franka_constants():
+    """round 5: realsense_franka.json's network / loss constants (9 PE octaves, scale_input 0.4, trunc_weight 30, trunc_distance 0.1,
+    no bounds transform) at TRAINED weights: 300 unmodified reference steps, then an eval batch with all gradients (stored as float16
+    mantissas on a per-tensor scale: 3e-4 rel-L2 of storage rounding)"""
+    g = gu.load("trained_franka")
+    cfg, lc, params = gu.net_of(g), gu.loss_of(g), gu.params_of(g)
+    assert cfg.n_freqs == 9 and cfg.transform is None and abs(lc.trunc_weight - 30.0) < 1e-6
+    b = gu.trained_batch(g, "eval/")
+    terms, grads = orc.loss_and_grads(params, cfg, lc, b["pc"], b["z_vals"], b["depth_sample"], b["dirs_C_sample"],
+                                      b["T_WC_sample"], b["norm_sample"], noise=b["noise"])
+    for k, tol in (("total_loss", 5e-5), ("sdf_loss", 5e-5), ("grad_loss", 5e-5), ("eikonal_loss", 2e-4)):
+        assert abs(terms[k] - g["eval/" + k][0]) < tol * abs(g["eval/" + k][0]), (k, terms[k], g["eval/" + k][0])
+    sdf, grad = orc.sdf_forward_grad(params, cfg, b["pc"].reshape(-1, 3))
+    assert gu.rel_err(sdf, g["eval/sdf_nonoise"].reshape(-1)) < 5e-5
+    assert gu.rel_err(grad, g["eval/sdf_grad"].reshape(-1, 3)) < 2e-4
+    ref = gu.trained_eval_grads(g, list(params))
+    for k in params:
+        nrm = float(g["eval/grad_norm/" + k][0])      # the exact norm, next to the float16-stored tensor
+        assert abs(np.linalg.norm(grads[k].astype(np.float64)) - nrm) < 2e-3 * nrm, k
+        if k == "out_alpha.bias":
+            continue                                   # one number: a nearly cancelling sum of residual signs at a trained state
+        assert gu.rel_err(grads[k], ref[k]) < 2e-3, (k, gu.rel_err(grads[k], ref[k]))
+
+
 def test_oracle_trajectory_from_trained_state():
     g = gu.load("trained_default")
     cfg, lc, params = gu.net_of(g), gu.loss_of(g), gu.params_of(g)

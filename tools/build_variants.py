@@ -6,7 +6,7 @@ carry no `#if` experiment switches):
     python tools/build_variants.py name1="-DFLAG=1 ..." name2=@tools/variants/some.patch      (base = the tree as it is, always built)
 
 A patch is applied (`patch -p1`, paths as `git diff` writes them) to a scratch copy of isdf_amd/csrc + include/.
-A spec of the form  name=sed:FILE:SCRIPT  runs `sed -E SCRIPT` over csrc/FILE of the scratch copy instead (one-line variants that
+A spec of the form  name=sed:FILE:SCRIPT  runs `sed -E SCRIPT` over csrc/FILE (FILE = * : every file) of the scratch copy instead (one-line variants that
 survive edits of the surrounding code), e.g. the A/B partner of the pair-tile forward kernel:
     onetile='sed:fwd_pair.hip:s/^(bool fwd_pair_supported\(const NetLayout& l\) \{).*$/\1 (void)l; return false; }/'"""
 import os, shutil, subprocess, sys, tempfile
@@ -22,10 +22,12 @@ def patched_sources(patch):
     shutil.copytree(os.path.join(ROOT, "include"), os.path.join(tmp, "include"))
     if patch.startswith("sed:"):
         _, fname, script = patch.split(":", 2)
-        target = os.path.join(tmp, "isdf_amd", "csrc", fname)
-        before = open(target).read()
-        subprocess.check_call(["sed", "-E", "-i", script, target])
-        assert open(target).read() != before, "sed variant changed nothing: " + patch
+        cdir = os.path.join(tmp, "isdf_amd", "csrc")
+        targets = [os.path.join(cdir, f) for f in sorted(os.listdir(cdir))] if fname == "*" else [os.path.join(cdir, fname)]
+        before = [open(t).read() for t in targets]
+        for t in targets:
+            subprocess.check_call(["sed", "-E", "-i", script, t])
+        assert [open(t).read() for t in targets] != before, "sed variant changed nothing: " + patch
     else:
         subprocess.check_call(["patch", "-p1", "-s", "-i", os.path.abspath(patch)], cwd=tmp)
     return os.path.join(tmp, "isdf_amd", "csrc")

@@ -2,6 +2,11 @@
 # Round-5 GPU sessions (one gpurun call each):  tools/r05_session.sh <stage>
 #   fwd1     pair-tile forward kernel: bit-identity against the one-tile kernel (variants/lib_onetile.so), timing at 8 M points,
 #            stage timelines (variants/lib_dbg.so), the GPU suite, inference + step bench lines
+#   chain1   chain-kernel changes (lane = point PE-shaped stages, reverse-epilogue trim) against variants/lib_prev.so: outputs of one
+#            step compared array by array, same-box bench A/B (two repetitions), MODE 2 timeline, the whole GPU suite
+#   gap      VERDICT r4 item 4: is the +0.30 cm of the 16-bit path against the fp32 control real?  PAIRED draws (same initial network and
+#            random streams), seeds 21..120 for the HIP path and the fp32 eager control (five control processes side by side: eager is
+#            launch-bound), and the HIP path with library-accurate transcendentals (variants/lib_libm.so) on seeds 1..60
 #   fwd3     fwd2 + the GPU suite (the Softplus reformulation touches every mode of the chain kernel) + bench lines
 #   fwd2     the same check / timing / timelines after a kernel change (no test suite, no step bench): the quick iteration stage
 # Outputs land in gpurun_out/r05*/ (scratch); what is judged is copied to profiles/ by hand.
@@ -55,4 +60,38 @@ import json, sys
 j = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
 print("bench: %.1f steps/s %.4f ms kernels %s frac %.4f sync %.4f" % (j["value"], j["ms_per_step"], j["kernel_ms"], j["roofline"]["frac"], j["trainer_step_sync_ms"]))
 PY
+fi
+
+if [ "$stage" = gap ]; then
+  A="--paired-draws --keyframes 24 --steps-per-kf 100"
+  for k in 0 1 2 3 4; do
+    lo=$((21 + 20 * k)); hi=$((40 + 20 * k))
+    timeout 1500 python tests/accuracy_experiment.py $A --backend port --device cuda --seeds $(seq $lo $hi) --out $O/paired_control_${lo}_${hi}.json > $O/paired_control_${lo}_${hi}.log 2>&1 &
+  done
+  timeout 1200 python tests/accuracy_experiment.py $A --backend hip --seeds $(seq 21 120) --out $O/paired_hip_21_120.json > $O/paired_hip_21_120.log 2>&1; lap hip 21..120 rc=$?
+  ISDF_HIP_LIB=$PWD/variants/lib_libm.so timeout 1200 python tests/accuracy_experiment.py $A --backend hip --seeds $(seq 1 60) --out $O/paired_hip_libm_1_60.json > $O/paired_hip_libm_1_60.log 2>&1; lap hip libm 1..60 rc=$?
+  wait; lap controls done
+  tail -n 2 $O/*.log
+fi
+
+if [ "$stage" = chain1 ]; then
+  timeout 300 python tools/train_ab_check.py --dump /tmp/ta.npz > $O/ab_dump_new.log 2>&1; lap dump new rc=$?
+  ISDF_HIP_LIB=$PWD/variants/lib_prev.so timeout 300 python tools/train_ab_check.py --dump /tmp/tb.npz > $O/ab_dump_prev.log 2>&1; lap dump prev rc=$?
+  python tools/train_ab_check.py --compare /tmp/ta.npz /tmp/tb.npz > $O/ab_compare.log 2>&1; lap compare
+  for rep in 1 2; do for f in variants/lib_prev.so isdf_amd/libisdf_hip.so; do
+    ISDF_HIP_LIB=$PWD/$f timeout 300 python bench.py --steps 300 --warmup 50 --no-cpu-baseline > $O/ab_$(basename $f .so)_$rep.json 2> /dev/null; lap bench $f $rep
+  done; done
+  timeout 300 python tools/timeline.py > $O/timeline_train.txt 2>&1; lap timeline
+  timeout 900 python -m pytest tests -q -m gpu -s > $O/pytest_gpu.log 2>&1; lap pytest rc=$?
+  cat $O/ab_compare.log
+  for f in $O/ab_*.json; do python - "$f" <<'PY'
+import json, sys
+j = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); fm = j.get("fast_mode_fp16") or {}
+print("%-28s %8.1f steps/s %.4f ms chain %.4f dw %.4f tail %.4f sync %.4f | fp16 %8.1f chain %.4f | loss %.5f" % (
+    sys.argv[1].split("ab_")[1][:-5], j["value"], j["ms_per_step"], *list(j["kernel_ms"].values())[:3], j["trainer_step_sync_ms"],
+    fm.get("steps_per_s", 0), fm.get("chain_ms", 0), j["final_total_loss"]))
+PY
+  done
+  head -n 40 $O/timeline_train.txt; tail -n 3 $O/timeline_train.txt
+  grep -E "passed|failed" $O/pytest_gpu.log | tail -n 3; grep -E "^(trained franka|  worst tensor|loss weights x)" $O/pytest_gpu.log
 fi
