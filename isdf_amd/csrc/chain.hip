@@ -265,8 +265,10 @@ __global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 && EP == HD && !oper_x2_a
   if constexpr (!WIDE_E && BM == 64) {
     // Round 5: a lane is a POINT, a wave takes directions w, w + 8, w + 16: the direction is wave-uniform, so a feature's column is
     // a scalar and its LDS address one v_xad of the lane's row base and swizzle, instead of a handful of per-lane integer operations
-    // per 2-byte store (the 8 points x 8 direction slices mapping below took 12.9 k cycles per tile in the forward kernel, this one
-    // ~7 k: profiles/r05_fwd_pair_v1/v2_timeline_fp16.txt).  Same arithmetic per value, so the same bits.
+    // per 2-byte store.  Same arithmetic per value, so the same bits (sdf, d sdf / d x and the losses of a step came out bit-identical to
+    // the previous library's, tools/train_ab_check.py).  Measured effect on this kernel: none (chain 184.9 -> 184.1 us same-box,
+    // profiles/r05_ab_chain_pe_stages.txt) -- the 14 k cycles in front of the first GEMM are the two DEPENDENT memory round trips of
+    // the prologue (n_valid, then the points), not this stage's instructions; kept because it is the simpler addressing.
     const int ln = tid & 63;
     const int64_t n = n0 + ln;
     float x0 = 0.f, x1 = 0.f, x2 = 0.f;

@@ -34,8 +34,9 @@ struct ChainStamps {
       while (__builtin_amdgcn_s_memtime() - t0 < (unsigned long long)d.stagger * 1000ull) __builtin_amdgcn_s_sleep(64);
     }
   }
-  __device__ void operator()() {   // phase boundary: wave 0 of workgroup 100
+  __device__ void operator()() {   // phase boundary: wave 0 of workgroup 100 (slots 0..127), and its LAST wave (slots 384..511)
     if (d.times && blockIdx.x == 100 && threadIdx.x == 0) d.times[n] = __builtin_amdgcn_s_memtime();
+    if (d.times && blockIdx.x == 100 && threadIdx.x == blockDim.x - 64 && n < 128) d.times[384 + n] = __builtin_amdgcn_s_memtime();
     ++n;
   }
   __device__ void wall(int slot) const {   // wall clock (s_memrealtime, 100 MHz) of every 4th workgroup

@@ -7,7 +7,8 @@ carry no `#if` experiment switches):
 
 A patch is applied (`patch -p1`, paths as `git diff` writes them) to a scratch copy of isdf_amd/csrc + include/.
 A spec of the form  name=sed:FILE:SCRIPT  runs `sed -E SCRIPT` over csrc/FILE (FILE = * : every file) of the scratch copy instead (one-line variants that
-survive edits of the surrounding code), e.g. the A/B partner of the pair-tile forward kernel:
+survive edits of the surrounding code; ISDF_VARIANT_EXTRA_FLAGS adds compiler flags to every variant of the call, e.g. -DISDF_DEBUG_HOOKS=1
+for a source variant with stage stamps), e.g. the A/B partner of the pair-tile forward kernel:
     onetile='sed:fwd_pair.hip:s/^(bool fwd_pair_supported\(const NetLayout& l\) \{).*$/\1 (void)l; return false; }/'"""
 import os, shutil, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -52,7 +53,7 @@ def main():
                 continue
             o = os.path.join(ROOT, "variants", "%s_%s.o" % (name, src[:-4]))
             mine[src] = o
-            jobs.append(subprocess.Popen([b._hipcc()] + b.FLAGS + b.PER_FILE.get(src, []) + flags.split()
+            jobs.append(subprocess.Popen([b._hipcc()] + b.FLAGS + b.PER_FILE.get(src, []) + flags.split() + os.environ.get("ISDF_VARIANT_EXTRA_FLAGS", "").split()
                                          + ["-c", os.path.join(csrc, src), "-o", o]))
         procs.append((name, mine, jobs))
     for name, mine, jobs in procs:

@@ -2,6 +2,7 @@
 # Round-5 GPU sessions (one gpurun call each):  tools/r05_session.sh <stage>
 #   fwd1     pair-tile forward kernel: bit-identity against the one-tile kernel (variants/lib_onetile.so), timing at 8 M points,
 #            stage timelines (variants/lib_dbg.so), the GPU suite, inference + step bench lines
+#   records  the GPU suite and the end-of-round records (tools/round_records.sh 05)
 #   chain1   chain-kernel changes (lane = point PE-shaped stages, reverse-epilogue trim) against variants/lib_prev.so: outputs of one
 #            step compared array by array, same-box bench A/B (two repetitions), MODE 2 timeline, the whole GPU suite
 #   gap      VERDICT r4 item 4: is the +0.30 cm of the 16-bit path against the fp32 control real?  PAIRED draws (same initial network and
@@ -94,4 +95,83 @@ PY
   done
   head -n 40 $O/timeline_train.txt; tail -n 3 $O/timeline_train.txt
   grep -E "passed|failed" $O/pytest_gpu.log | tail -n 3; grep -E "^(trained franka|  worst tensor|loss weights x)" $O/pytest_gpu.log
+fi
+
+if [ "$stage" = records ]; then
+  timeout 900 python -m pytest tests -q -m gpu -s > $O/pytest_gpu.log 2>&1; lap pytest rc=$?
+  grep -E "passed|failed" $O/pytest_gpu.log | tail -n 3; grep -E "^(trained franka|  worst tensor|loss weights x)" $O/pytest_gpu.log
+  bash tools/round_records.sh 05 > $O/round_records.log 2>&1; lap records
+  tail -n 60 $O/round_records.log
+fi
+
+if [ "$stage" = tp1 ]; then      # pair-tile train kernel: outputs of one step against variants/lib_prev.so (one-tile kernel), array by array
+  timeout 300 python tools/train_ab_check.py --dump /tmp/ta.npz > $O/ab_dump_new.log 2>&1; lap dump new rc=$?
+  ISDF_HIP_LIB=$PWD/variants/lib_prev.so timeout 300 python tools/train_ab_check.py --dump /tmp/tb.npz > $O/ab_dump_prev.log 2>&1; lap dump prev rc=$?
+  python tools/train_ab_check.py --compare /tmp/ta.npz /tmp/tb.npz > $O/ab_compare.log 2>&1; lap compare
+  cat $O/ab_compare.log; tail -n 3 $O/ab_dump_new.log
+  for f in variants/lib_prev.so isdf_amd/libisdf_hip.so; do
+    ISDF_HIP_LIB=$PWD/$f timeout 300 python bench.py --steps 300 --warmup 50 --no-cpu-baseline > $O/ab_$(basename $f .so).json 2> $O/ab_$(basename $f .so).err; lap bench $f
+  done
+  for f in $O/ab_lib*.json; do python - "$f" <<'PY'
+import json, sys
+try:
+    j = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); fm = j.get("fast_mode_fp16") or {}
+    print("%-28s %8.1f steps/s %.4f ms chain %.4f dw %.4f tail %.4f sync %.4f | fp16 %8.1f chain %.4f | loss %.5f" % (
+        sys.argv[1].split("ab_")[1][:-5], j["value"], j["ms_per_step"], *list(j["kernel_ms"].values())[:3], j["trainer_step_sync_ms"],
+        fm.get("steps_per_s", 0), fm.get("chain_ms", 0), j["final_total_loss"]))
+except Exception as e:
+    print(sys.argv[1], "ERR", e)
+PY
+  done
+fi
+
+if [ "$stage" = tp2 ]; then      # pair-tile train kernel: stage timeline (variants/lib_dbg.so) + bench
+  timeout 300 python tools/timeline.py > $O/timeline_train.txt 2>&1; lap timeline
+  ISDF_FWD_OPERAND=fp16 timeout 300 python tools/timeline.py > $O/timeline_train_fp16.txt 2>&1; lap timeline fp16
+  timeout 300 python bench.py --steps 300 --warmup 50 --no-cpu-baseline > $O/bench.json 2> $O/bench.err; lap bench
+  cat $O/timeline_train.txt | head -130; tail -n 8 $O/timeline_train.txt
+  python - "$O/bench.json" <<'PY'
+import json, sys
+j = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); fm = j.get("fast_mode_fp16") or {}
+print("bench %8.1f steps/s %.4f ms chain %.4f dw %.4f tail %.4f sync %.4f | fp16 %8.1f chain %.4f" % (j["value"], j["ms_per_step"], *list(j["kernel_ms"].values())[:3], j["trainer_step_sync_ms"], fm.get("steps_per_s", 0), fm.get("chain_ms", 0)))
+PY
+fi
+
+if [ "$stage" = tp3 ]; then      # pair-tile train kernel variants: cache policy of the spill traffic, epilogue groups late in the stage
+  for rep in 1 2; do for f in variants/lib_prev.so isdf_amd/libisdf_hip.so variants/lib_tpdef.so variants/lib_tplate.so; do
+    ISDF_HIP_LIB=$PWD/$f timeout 300 python bench.py --steps 300 --warmup 50 --no-cpu-baseline > $O/ab_$(basename $f .so)_$rep.json 2> /dev/null; lap bench $f $rep
+  done; done
+  for f in $O/ab_lib*.json; do python - "$f" <<'PY'
+import json, sys
+try:
+    j = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); fm = j.get("fast_mode_fp16") or {}
+    print("%-28s %8.1f steps/s %.4f ms chain %.4f dw %.4f tail %.4f sync %.4f | fp16 %8.1f chain %.4f | loss %.5f" % (
+        sys.argv[1].split("ab_")[1][:-5], j["value"], j["ms_per_step"], *list(j["kernel_ms"].values())[:3], j["trainer_step_sync_ms"],
+        fm.get("steps_per_s", 0), fm.get("chain_ms", 0), j["final_total_loss"]))
+except Exception as e:
+    print(sys.argv[1], "ERR", e)
+PY
+  done
+fi
+
+if [ "$stage" = tp4 ]; then      # pair-tile train kernel: check vs prev + bench A/B + timeline
+  timeout 300 python tools/train_ab_check.py --dump /tmp/ta.npz > $O/ab_dump_new.log 2>&1; lap dump new rc=$?
+  ISDF_HIP_LIB=$PWD/variants/lib_prev.so timeout 300 python tools/train_ab_check.py --dump /tmp/tb.npz > $O/ab_dump_prev.log 2>&1; lap dump prev rc=$?
+  python tools/train_ab_check.py --compare /tmp/ta.npz /tmp/tb.npz > $O/ab_compare.log 2>&1; head -n 8 $O/ab_compare.log
+  for rep in 1 2; do for f in variants/lib_prev.so isdf_amd/libisdf_hip.so; do
+    ISDF_HIP_LIB=$PWD/$f timeout 300 python bench.py --steps 300 --warmup 50 --no-cpu-baseline > $O/ab_$(basename $f .so)_$rep.json 2> /dev/null; lap bench $f $rep
+  done; done
+  for f in $O/ab_lib*.json; do python - "$f" <<'PY'
+import json, sys
+try:
+    j = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); fm = j.get("fast_mode_fp16") or {}
+    print("%-28s %8.1f steps/s %.4f ms chain %.4f dw %.4f tail %.4f sync %.4f | fp16 %8.1f chain %.4f | loss %.5f" % (
+        sys.argv[1].split("ab_")[1][:-5], j["value"], j["ms_per_step"], *list(j["kernel_ms"].values())[:3], j["trainer_step_sync_ms"],
+        fm.get("steps_per_s", 0), fm.get("chain_ms", 0), j["final_total_loss"]))
+except Exception as e:
+    print(sys.argv[1], "ERR", e)
+PY
+  done
+  timeout 300 python tools/timeline.py > $O/timeline_train.txt 2>&1; lap timeline
+  grep -v "^  wg" $O/timeline_train.txt | tail -n 108
 fi

@@ -21,6 +21,8 @@ python $R/bench.py --rays-per-frame 5400 --steps 30 --warmup 5 --no-cpu-baseline
 python $R/bench.py --wide --steps 30 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_wide.json
 python $R/bench.py --infer-points 8000000 2>/dev/null | tail -1 > $O/bench_inference_8M.json
 python $R/bench.py --ingest 2>/dev/null | tail -1 > $O/bench_ingest.json
+python $R/bench.py --stream 480x640 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_stream_480x640.json          # the north star's synthetic 640x480 stream
+timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_infer -- python $R/bench.py --infer-points 8000000 > $O/stats_infer.log 2>&1
 timeout 120 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_ingest -- python $R/bench.py --ingest > $O/stats_ingest.log 2>&1
 python - <<'PY'
 import csv, glob, collections, os, json
@@ -30,7 +32,7 @@ def collect(pat):
     for f in sorted(glob.glob(O + "/" + pat + "/**/*counter_collection.csv", recursive=True)):
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"]
-            for tag in ("chain_kernel", "dw_kernel", "step_tail_kernel", "sample_rays_kernel"):
+            for tag in ("chain_kernel", "fwd_pair_kernel", "dw_kernel", "step_tail_kernel", "sample_rays_kernel"):
                 if tag in k:
                     acc[tag][r["Counter_Name"]].append(float(r["Counter_Value"]))
     return {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in acc.items()}

@@ -15,7 +15,7 @@ cam = dict(synthetic.SCANNET_CAM)
 d, n, T = synthetic.keyframes(5, cam, seed=1)
 dev = lambda a: torch.as_tensor(a).cuda()
 d, n, T = dev(d), dev(n), dev(T)
-sc = SampleConfig(n_rays=200, **cam); lc = LossConfig()
+sc = SampleConfig(n_rays=int(os.environ.get("ISDF_TIMELINE_RAYS", "200")), **cam); lc = LossConfig()
 idx = torch.arange(5, dtype=torch.int32, device="cuda")
 s = eng.sample(d, T, n, idx, idx, sc, seed=1, offset=0)
 noise = torch.zeros(s["max_rays"], sc.S, device="cuda")
@@ -29,6 +29,12 @@ print("n stamps", len(ts), "(s_memtime ticks = shader clock cycles)")
 prev = t0
 for i, t in enumerate(ts):
     print("%3d  t=%8d  d=%7d" % (i, t - t0, t - prev)); prev = t
+ts7 = raw[384:512]; ts7 = ts7[ts7 > 0]
+if len(ts7) == len(ts):
+    print("last wave of the workgroup, same stamps (d = its own step; lag = behind wave 0):")
+    prev7 = ts7[0]
+    for i, t in enumerate(ts7):
+        print("%3d  t=%8d  d=%7d  lag=%6d" % (i, t - t0, t - prev7, t - ts[i])); prev7 = t
 # wall-clock start/end (100 MHz s_memrealtime) of every 4th workgroup
 se = raw[128:128 + 2 * 190].reshape(-1, 2)
 se = se[(se[:, 0] > 0) & (se[:, 1] > 0)]
