@@ -17,13 +17,14 @@ struct ChainDebug {
   int32_t alias;              // ISDF_DEBUG_ALIAS_SPILL=n: tiles share n spill regions (timing only, results garbage)
   int32_t stagger;            // ISDF_DEBUG_STAGGER=k: odd tiles start k kilo-cycles late
   int32_t stagger_gen;        // ISDF_DEBUG_STAGGER_GEN=1: ... the SECOND workgroup of every CU (dispatch round) instead of odd tiles
+  int32_t all_waves;          // ISDF_DEBUG_TIMELINE=2: EVERY wave of workgroup 100 stamps, 64 slots each ([64 w + n]; no wall clocks)
   unsigned long long* times;  // ISDF_DEBUG_TIMELINE: [0..127] s_memtime stamps of workgroup 100, [128..] wall clocks
 };
 inline void chain_debug_from_env(ChainDebug& d, void* stamp_area) {
   if (const char* e = getenv("ISDF_DEBUG_ALIAS_SPILL")) d.alias = atoi(e);
   if (const char* e = getenv("ISDF_DEBUG_STAGGER")) d.stagger = atoi(e);
   if (const char* e = getenv("ISDF_DEBUG_STAGGER_GEN")) d.stagger_gen = atoi(e);
-  if (getenv("ISDF_DEBUG_TIMELINE")) d.times = (unsigned long long*)stamp_area;
+  if (const char* e = getenv("ISDF_DEBUG_TIMELINE")) { d.times = (unsigned long long*)stamp_area; d.all_waves = atoi(e) == 2; }
 }
 #if defined(__HIPCC__)
 struct ChainStamps {
@@ -35,12 +36,17 @@ struct ChainStamps {
     }
   }
   __device__ void operator()() {   // phase boundary: wave 0 of workgroup 100 (slots 0..127), and its LAST wave (slots 384..511)
-    if (d.times && blockIdx.x == 100 && threadIdx.x == 0) d.times[n] = __builtin_amdgcn_s_memtime();
+    if (d.times && d.all_waves) {
+      if (blockIdx.x == 100 && (threadIdx.x & 63) == 0 && n < 64) d.times[(threadIdx.x >> 6) * 64 + n] = __builtin_amdgcn_s_memtime();
+      ++n;
+      return;
+    }
+    if (d.times && blockIdx.x == 100 && threadIdx.x == 0 && n < 128) d.times[n] = __builtin_amdgcn_s_memtime();   // (a persistent workgroup: its first pass)
     if (d.times && blockIdx.x == 100 && threadIdx.x == blockDim.x - 64 && n < 128) d.times[384 + n] = __builtin_amdgcn_s_memtime();
     ++n;
   }
   __device__ void wall(int slot) const {   // wall clock (s_memrealtime, 100 MHz) of every 4th workgroup
-    if (d.times && threadIdx.x == 0 && (blockIdx.x & 3) == 0 && blockIdx.x < 4 * 190)
+    if (d.times && !d.all_waves && threadIdx.x == 0 && (blockIdx.x & 3) == 0 && blockIdx.x < 4 * 190)
       d.times[128 + slot + blockIdx.x / 2] = __builtin_amdgcn_s_memrealtime();
   }
   __device__ int64_t spill_tile() const { return d.alias ? (int64_t)(blockIdx.x % d.alias) : (int64_t)blockIdx.x; }

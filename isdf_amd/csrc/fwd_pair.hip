@@ -71,8 +71,8 @@ __global__ __launch_bounds__(FwdPairTile::NW * 64, 2) void fwd_pair_kernel(const
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63, j = lane & 31, hi = lane >> 5, lane16 = lane * 16;
   const int64_t P = p.n_valid ? (int64_t)(*p.n_valid) * p.S : p.n_points_host;
-  const int64_t n0 = (int64_t)blockIdx.x * BM;
-  if (n0 >= P) return;
+  const int64_t nPairs = (P + BM - 1) / BM;
+  if ((int64_t)blockIdx.x >= nPairs) return;
   const float so = L.scale_output;
   ChainStamps TS(p.dbg);
   TS();
@@ -116,25 +116,38 @@ __global__ __launch_bounds__(FwdPairTile::NW * 64, 2) void fwd_pair_kernel(const
         biasL[(li < NL ? li : MAXL) * HD + u] = li < NL ? bvv[i] * kC1 : bvv[i];
     }
   }
-  {
+  // The workgroup is PERSISTENT: it walks pairs blockIdx, blockIdx + gridDim, ... (one workgroup per CU).  Per pair that saves the bias
+  // staging, the first fill of the weight window (the last stage of a pair has already requested layer 0's fragments: the "next unit"
+  // of the last layer IS the next pair's first) and the latency of the coordinate loads (requested one pair ahead).
+  auto load_xyz = [&](int64_t pair, float (&o)[2][3]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int64_t n = pair * BM + h * HB + lane;
+      o[h][0] = 0.f; o[h][1] = 0.f; o[h][2] = 0.f;
+      if (pair < nPairs && n < P) { o[h][0] = p.pts[n * 3]; o[h][1] = p.pts[n * 3 + 1]; o[h][2] = p.pts[n * 3 + 2]; }
+    }
+  };
+  float pxyz[2][3];
+  load_xyz(blockIdx.x, pxyz);
+  const int sw = (lane & 15) << 4;
+  auto pe_stage = [&](const float (&xyz)[2][3]) __attribute__((always_inline)) {
     // PE (embedding.py:95-111).  A lane is a POINT of a half, a wave takes (direction, half) items w, w + 8, ... of the 42: the
     // direction is wave-uniform, so a feature's column is a scalar and its LDS address one v_xad of the lane's row base and swizzle;
     // the octaves are unrolled (NF is a template constant), and octave pairs (1,2), (3,4) of a direction -- 4-byte aligned in the
     // row, never across a 16-byte swizzle slot -- leave as one packed store.  (chain.hip's mapping, 8 points x 8 direction slices
     // per wave with run-time octave loops, took 12.9 k of this workgroup's 70 k cycles: profiles/r05_fwd_pair_v1_timeline_fp16.txt.)
-    // Same arithmetic per value as chain.hip: xb = proj * 2^f, sin(xb), sin(xb + pi/2).
+    // Octaves 0 and 3 of a direction are evaluated as chain.hip does (xb = proj 2^f, sin(xb), sin(xb + pi/2)), the two octaves above
+    // each by angle doubling (s' = 2 s c, c' = 1 - 2 s^2: three plain operations instead of two transcendental ones and their range
+    // scaling; two doublings from an exact start: <= 1e-6 from the direct value, a 250th of the operand's fp16 rounding step).
     float ys[2][3];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      const int64_t n = n0 + h * HB + lane;
-      float x0 = 0.f, x1 = 0.f, x2 = 0.f;
-      if (n < P) { x0 = p.pts[n * 3]; x1 = p.pts[n * 3 + 1]; x2 = p.pts[n * 3 + 2]; }
+      const float x0 = xyz[h][0], x1 = xyz[h][1], x2 = xyz[h][2];
       // transform_3D_grid (transform.py:287-304) then * scale (embedding.py:12-22)
       ys[h][0] = (L.T[0] * x0 + L.T[1] * x1 + L.T[2] * x2 + L.T[3]) * L.scale_input;
       ys[h][1] = (L.T[4] * x0 + L.T[5] * x1 + L.T[6] * x2 + L.T[7]) * L.scale_input;
       ys[h][2] = (L.T[8] * x0 + L.T[9] * x1 + L.T[10] * x2 + L.T[11]) * L.scale_input;
     }
-    const int sw = (lane & 15) << 4;
     auto put1 = [&](int rowb, int feat, float v) __attribute__((always_inline)) { *(opT*)(smem + rowb + (((HD + feat) * 2) ^ sw)) = (opT)v; };
     auto put2 = [&](int rowb, int feat, float v0, float v1) __attribute__((always_inline)) {   // features feat, feat + 1 at a 4-byte aligned column
       typedef opT op2 __attribute__((ext_vector_type(2)));
@@ -159,9 +172,15 @@ __global__ __launch_bounds__(FwdPairTile::NW * 64, 2) void fwd_pair_kernel(const
       float fr = 1.f;
 #pragma unroll
       for (int f = 0; f < NF; ++f) {
-        const float xb = proj * fr;
-        sv[f] = __sinf(xb);
-        cv[f] = __sinf(xb + kHalfPi);
+        if (f % 3 == 0) {
+          const float xb = proj * fr;
+          sv[f] = __sinf(xb);
+          cv[f] = __sinf(xb + kHalfPi);
+        } else {
+          const float t2 = sv[f - 1] + sv[f - 1];
+          sv[f] = t2 * cv[f - 1];
+          cv[f] = __builtin_fmaf(-t2, sv[f - 1], 1.f);
+        }
         fr *= 2.f;
       }
       // column of (d, f) is 3 + d NF + f (+ N_DIRS NF for the shifted block): odd for f = 0 when NF is even, so the pairs start at f = 1
@@ -172,10 +191,7 @@ __global__ __launch_bounds__(FwdPairTile::NW * 64, 2) void fwd_pair_kernel(const
       for (int f = 1; f + 1 < NF; f += 2) { put2(rowb, fs + f, sv[f], sv[f + 1]); put2(rowb, fc + f, cv[f], cv[f + 1]); }
       put1(rowb, fs + NF - 1, sv[NF - 1]); put1(rowb, fc + NF - 1, cv[NF - 1]);
     }
-  }
-  TS();
-  lds_barrier();
-  TS();
+  };
 
   // ------------------------------------------------------------------ the stage
   // LDS byte offsets (within a half) of this lane's operand reads and epilogue writes (chain.hip: gemm() / put_x())
@@ -207,6 +223,7 @@ __global__ __launch_bounds__(FwdPairTile::NW * 64, 2) void fwd_pair_kernel(const
     constexpr int NS = UK == UK_NONE ? NQ : (UK == UK_16 ? 32 : UK == UK_32 ? 64 : 96);   // MFMA slots of the stage's GEMM
     static_assert(NS >= NQ, "at most one phase per MFMA slot");
     float bv[2][8], wv[2][8], z[4], y[4];
+    uint2 hp = make_uint2(0u, 0u);
     f32x2 r2 = {0.f, 0.f};
     auto load_bv = [&](int qp) __attribute__((always_inline)) {   // features 32 w + 16 qp + 4 hi + {0..3, 8..11}
       if constexpr (EK != EK_NONE) {
@@ -222,7 +239,7 @@ __global__ __launch_bounds__(FwdPairTile::NW * 64, 2) void fwd_pair_kernel(const
     };
     load_bv(0);
     if constexpr (EK == EK_LAST) { rawp[0] = 0.f; rawp[1] = 0.f; }
-    (void)wv; (void)r2; (void)z; (void)y; (void)bv;
+    (void)wv; (void)r2; (void)z; (void)y; (void)bv; (void)hp;
     auto phase = [&](int q) __attribute__((always_inline)) {
       if constexpr (EK != EK_NONE) {
         const int g = q / PH, ph = q % PH;
@@ -247,11 +264,18 @@ __global__ __launch_bounds__(FwdPairTile::NW * 64, 2) void fwd_pair_kernel(const
             if (hb == 1) { rawp[pb] += r2[0] + r2[1]; r2 = f32x2{0.f, 0.f}; }
           } else {   // four values -> one 8-byte piece of the tile (features f0 .. f0+3 | f0+8 .. f0+11)
             const int lb = ((xel ^ (32 * qp)) + pb * 32 * ROWB) ^ (hb ? 16 : 0);
-            *(uint2*)(smem + lb) = pack4<EK == EK_HILO ? true : F16>(z[0], z[1], z[2], z[3]);
+            hp = pack4<EK == EK_HILO ? true : F16>(z[0], z[1], z[2], z[3]);
+            *(uint2*)(smem + lb) = hp;
           }
-        } else {     // fp16x2: region 2 <- fp16(a - fp16(a)), the second operand of the next layer's compensated GEMM
+        } else {     // fp16x2: region 2 <- fp16(a - fp16(a)), the second operand of the next layer's compensated GEMM.
+          // The residual is formed against the STORED halves (hp), not against a second conversion of a: the compiler contracts the
+          // k ln2 / beta product into whichever conversion it meets (v_fma_mix*: one rounding) or not (two), and a residual formed
+          // against the other kind of half is off by an fp16 ulp of a whenever the two roundings disagree (2^-13 of the elements;
+          // 1.5e-5 of sdf at the worst of 300 k points between two builds of this file: profiles/r05_fwd_pair_v5_ab.txt).
           const int lb = ((xel ^ (32 * qp)) + pb * 32 * ROWB) ^ (hb ? 16 : 0);
-          *(uint2*)(smem + lb + HD * 2) = pack4<true>(f16_residual(z[0]), f16_residual(z[1]), f16_residual(z[2]), f16_residual(z[3]));
+          typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+          const h4 hv = __builtin_bit_cast(h4, hp);
+          *(uint2*)(smem + lb + HD * 2) = pack4<true>(z[0] - (float)hv[0], z[1] - (float)hv[1], z[2] - (float)hv[2], z[3] - (float)hv[3]);
         }
       }
     };
@@ -346,6 +370,11 @@ __global__ __launch_bounds__(FwdPairTile::NW * 64, 2) void fwd_pair_kernel(const
   char* const XA = smem;
   char* const XB = smem + T::HALFB;
   auto soff0_of = [&](int li) __attribute__((always_inline)) { return (int)((L.setFwdA + L.fwdMat[li]) * 2) + w * ((li == 0 ? EP : (li == CAT ? HD + EP : HD)) / 16) * 1024; };
+  // The loop over pairs is ROTATED by one stage: the epilogue of half B's last layer (no GEMM of its own pair left to hide behind) runs
+  // behind the NEXT pair's first GEMM (half A, layer 0), whose operand -- the embedding -- the next pair's PE writes once the
+  // last GEMM of this pair has read its own.  A pair is then 12 two-sided stages and the PE; only the first pair of a workgroup
+  // pays a one-sided stage (before the rotation: every pair two of them -- 2.6 k + 3.2 k cycles of a pair's 27 k,
+  // profiles/r05_fwd_pair_v4_timeline_fp16.txt).
   auto layer = [&](auto lic) __attribute__((always_inline)) {
     constexpr int li = decltype(lic)::value;
     constexpr bool comp = X2 && li >= CAT;
@@ -353,23 +382,43 @@ __global__ __launch_bounds__(FwdPairTile::NW * 64, 2) void fwd_pair_kernel(const
     constexpr int EKprev = li == 0 ? EK_NONE : (X2 && li > CAT ? EK_HILO : EK_HID);                   // epilogue of layer li - 1 (never the last)
     constexpr int EKcur = li == NL - 1 ? EK_LAST : (X2 && li + 1 > CAT ? EK_HILO : EK_HID);
     const FwdUnit u = unit_of(li);
-    const int nxt = soff0_of(li + 1 < NL ? li + 1 : 0);   // (past the last layer: a harmless re-request of layer 0)
-    // stage 2 li + 1: GEMM of half A, layer li || epilogue of half B, layer li - 1
-    stage(std::integral_constant<int, UK>{}, std::integral_constant<int, EKprev>{}, std::false_type{}, accA, accB, u, nxt, XA, XB, li - 1, 1);
-    TS();
-    lds_barrier();
-    TS();
-    // stage 2 li + 2: GEMM of half B, layer li || epilogue of half A, layer li
+    const int nxt = soff0_of(li + 1 < NL ? li + 1 : 0);   // (past the last layer: layer 0 again, for the next pair)
+    if constexpr (li > 0) {
+      // GEMM of half A, layer li || epilogue of half B, layer li - 1   (layer 0's: the last stage of the previous pair / the prologue)
+      stage(std::integral_constant<int, UK>{}, std::integral_constant<int, EKprev>{}, std::false_type{}, accA, accB, u, nxt, XA, XB, li - 1, 1);
+      TS();
+      lds_barrier();
+      TS();
+    }
+    // GEMM of half B, layer li || epilogue of half A, layer li
     stage(std::integral_constant<int, UK>{}, std::integral_constant<int, EKcur>{}, std::true_type{}, accB, accA, u, nxt, XB, XA, li, 0);
     TS();
     lds_barrier();
     TS();
   };
+  static_assert(CAT != 0, "layer 0 is a one-operand 16-fragment unit here");
+  const FwdUnit u0 = unit_of(0);
+  pe_stage(pxyz);
+  TS();
+  lds_barrier();
+  TS();
+  stage(std::integral_constant<int, UK_16>{}, std::integral_constant<int, EK_NONE>{}, std::false_type{}, accA, accB, u0, soff0_of(1), XA, XB, -1, 1);
+  TS();
+  lds_barrier();
+  TS();
+  for (int64_t pair = blockIdx.x; pair < nPairs; pair += gridDim.x) {
+  const int64_t n0 = pair * BM;
+  const bool has_next = pair + gridDim.x < nPairs;
+  load_xyz(pair + gridDim.x, pxyz);   // the next pair's coordinates: in flight behind this pair's stages
   static_layers(layer, std::make_integer_sequence<int, NL>{});
-  {   // epilogue of half B, last layer
-    const FwdUnit u = unit_of(0);
-    stage(std::integral_constant<int, UK_NONE>{}, std::integral_constant<int, EK_LAST>{}, std::false_type{}, accA, accB, u, u.soff0, XA, XB, NL - 1, 1);
-  }
+  if (has_next) pe_stage(pxyz);
+  TS();
+  lds_barrier();
+  TS();
+  // GEMM of half A, layer 0 of the NEXT pair (after the last pair: of stale operands, into an accumulator nobody reads) || epilogue of
+  // half B, last layer
+  stage(std::integral_constant<int, UK_16>{}, std::integral_constant<int, EK_LAST>{}, std::false_type{}, accA, accB, u0, soff0_of(1), XA, XB, NL - 1, 1);
+  TS();
   lds_barrier();
   TS();
 
@@ -388,6 +437,8 @@ __global__ __launch_bounds__(FwdPairTile::NW * 64, 2) void fwd_pair_kernel(const
     }
     if (p.sdf && n < P) p.sdf[n] = r * so;
   }
+  // (rawL is rewritten eleven barriers from here)
+  }
   TS.wall(1);
 }
 
@@ -395,7 +446,9 @@ template <int OPER>
 static int launch_fwd_pair_oper(const ChainParams& p, int64_t nPairs, hipStream_t st) {
   auto k = fwd_pair_kernel<OPER, 6, 3, 6>;
   if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, FwdPairTile::LDS_BYTES) != hipSuccess) return ISDF_EHIP;
-  hipLaunchKernelGGL(k, dim3((unsigned)nPairs), dim3(FwdPairTile::NW * 64), FwdPairTile::LDS_BYTES, st, p);
+  // one persistent workgroup per CU (152 KB of LDS each)
+  const int64_t grid = p.n_cu > 0 && nPairs > p.n_cu ? p.n_cu : nPairs;
+  hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(FwdPairTile::NW * 64), FwdPairTile::LDS_BYTES, st, p);
   return isdf_launch_status();
 }
 

@@ -1388,7 +1388,9 @@ def test_pair_tile_forward_kernel_agrees_with_the_one_tile_forward(fwd_operand):
     g = torch.Generator(device="cpu"); g.manual_seed(12)
     x = ((torch.rand(70001, 3, generator=g) - 0.5) * torch.tensor([6.0, 3.0, 5.0])).cuda()
     bar = {"fp16x2": 5e-5, "fp16": 1e-4, "bf16": 5e-4}[fwd_operand]
-    for n in (1, 63, 64, 65, 127, 128, 129, 70001):      # ragged: half-filled halves and pairs
+    # ragged: half-filled halves and pairs; workgroups are persistent (one per CU, pairs b, b + grid, ...: the epilogue of a pair's last
+    # layer runs behind the next pair's first GEMM): 32897 points = 257 pairs + 1 point is the first size one of 256 takes a second pair at
+    for n in (1, 63, 64, 65, 127, 128, 129, 32897, 70001):
         a = eng.sdf_eval(x[:n])
         b, _ = eng.sdf_eval(x[:n], want_grad=True)
         d = float((a - b).abs().max())
@@ -1396,6 +1398,25 @@ def test_pair_tile_forward_kernel_agrees_with_the_one_tile_forward(fwd_operand):
     nz = (torch.randn(5000, generator=g) * 0.01).cuda()
     d = float((eng.sdf_eval(x[:5000], noise=nz) - eng.sdf_eval(x[:5000], noise=nz, want_grad=True)[0]).abs().max())
     assert d <= bar, d
+
+
+@pytest.mark.parametrize("fwd_operand", ["fp16x2", "fp16", "bf16"])
+def test_pair_tile_forward_is_as_close_to_the_oracle_as_the_one_tile_forward(fwd_operand):
+    """The two forward kernels differ from each other by operand roundings; neither may be the worse one against the fp32 oracle
+    (oracle/: the reference's MLP, restated): max and rms error of sdf over 27 000 points at the reference fixture's weights."""
+    g = gu.load("eval_full_ray")
+    eng = _engine(g, fwd_operand)
+    rng = np.random.RandomState(5)
+    x = rng.uniform(-3, 3, (27000, 3)).astype(np.float32)
+    ref, _ = orc.sdf_forward_grad(gu.params_of(g), gu.net_of(g), x)
+    pair = eng.sdf_eval(_dev(x)).cpu().numpy().astype(np.float64)
+    one = eng.sdf_eval(_dev(x), want_grad=True)[0].cpu().numpy().astype(np.float64)
+    ref = np.asarray(ref, np.float64).reshape(-1)
+    ep, eo = np.abs(pair - ref), np.abs(one - ref)
+    print("%s: |sdf - oracle| pair-tile max %.3e rms %.3e   one-tile max %.3e rms %.3e" % (fwd_operand, ep.max(), np.sqrt((ep ** 2).mean()),
+                                                                                          eo.max(), np.sqrt((eo ** 2).mean())))
+    assert np.sqrt((ep ** 2).mean()) <= 1.1 * np.sqrt((eo ** 2).mean()) + 1e-7
+    assert ep.max() <= 1.5 * eo.max() + 1e-6
 
 
 def test_fp16_second_order_sweeps_hold_their_range_under_small_loss_weights():

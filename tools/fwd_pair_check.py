@@ -27,7 +27,7 @@ def dump(path, time_n):
         for hidden in (256, 200):
             eng = Engine(NetConfig(hidden=hidden, transform=synthetic.bounds_transform(), fwd_operand=op), "cuda")
             torch.manual_seed(3); eng.params.normal_(0, 0.06); eng.pack()
-            for n in (1, 63, 64, 65, 127, 128, 129, 1000, 27000, 300000):
+            for n in (1, 63, 64, 65, 127, 128, 129, 1000, 27000, 32897, 300000):   # (256 CUs: 32897 points = 257 pairs + 1 point, the first size a persistent workgroup takes a second pair at)
                 out["%s_h%d_n%d" % (op, hidden, n)] = eng.sdf_eval(big[:n]).cpu().numpy()
             out["%s_h%d_noise" % (op, hidden)] = eng.sdf_eval(big[:5000], noise=nz[:5000]).cpu().numpy()
             if time_n and hidden == 256:

@@ -38,6 +38,11 @@ fi
 if [ "$stage" = fwd2 ]; then
   timeout 600 python tools/fwd_pair_check.py --dump /tmp/a.npz --time 8000000 > $O/check_pair.log 2>&1; lap pair dump rc=$?
   ISDF_HIP_LIB=$PWD/variants/lib_onetile.so timeout 600 python tools/fwd_pair_check.py --dump /tmp/b.npz --time 8000000 > $O/check_onetile.log 2>&1; lap onetile dump rc=$?
+  if [ -f variants/lib_prevpair.so ]; then   # the pair kernel before the change under test, on the same box
+    ISDF_HIP_LIB=$PWD/variants/lib_prevpair.so timeout 600 python tools/fwd_pair_check.py --dump /tmp/c.npz --time 8000000 > $O/check_prevpair.log 2>&1; lap prevpair dump rc=$?
+    timeout 600 python tools/fwd_pair_check.py --dump /tmp/a2.npz --time 8000000 > $O/check_pair_again.log 2>&1; lap pair again rc=$?
+    tail -n 4 $O/check_prevpair.log $O/check_pair_again.log
+  fi
   python tools/fwd_pair_check.py --compare /tmp/a.npz /tmp/b.npz > $O/compare.log 2>&1; lap compare rc=$?
   ISDF_FWD_OPERAND=fp16 timeout 300 python tools/timeline_fwd.py > $O/timeline_fp16.txt 2>&1; lap timeline fp16
   ISDF_FWD_OPERAND=fp16x2 timeout 300 python tools/timeline_fwd.py > $O/timeline_fp16x2.txt 2>&1; lap timeline fp16x2
@@ -94,12 +99,12 @@ print("%-28s %8.1f steps/s %.4f ms chain %.4f dw %.4f tail %.4f sync %.4f | fp16
 PY
   done
   head -n 40 $O/timeline_train.txt; tail -n 3 $O/timeline_train.txt
-  grep -E "passed|failed" $O/pytest_gpu.log | tail -n 3; grep -E "^(trained franka|  worst tensor|loss weights x)" $O/pytest_gpu.log
+  grep -E "passed|failed" $O/pytest_gpu.log | tail -n 3; grep -E "^(trained franka|  worst tensor|loss weights x|fp16x2: .sdf|fp16: .sdf|bf16: .sdf)" $O/pytest_gpu.log
 fi
 
 if [ "$stage" = records ]; then
   timeout 900 python -m pytest tests -q -m gpu -s > $O/pytest_gpu.log 2>&1; lap pytest rc=$?
-  grep -E "passed|failed" $O/pytest_gpu.log | tail -n 3; grep -E "^(trained franka|  worst tensor|loss weights x)" $O/pytest_gpu.log
+  grep -E "passed|failed" $O/pytest_gpu.log | tail -n 3; grep -E "^(trained franka|  worst tensor|loss weights x|fp16x2: .sdf|fp16: .sdf|bf16: .sdf)" $O/pytest_gpu.log
   bash tools/round_records.sh 05 > $O/round_records.log 2>&1; lap records
   tail -n 60 $O/round_records.log
 fi
@@ -174,4 +179,12 @@ PY
   done
   timeout 300 python tools/timeline.py > $O/timeline_train.txt 2>&1; lap timeline
   grep -v "^  wg" $O/timeline_train.txt | tail -n 108
+fi
+
+if [ "$stage" = det ]; then    # is the pair-tile forward kernel deterministic (run to run), and do the variants named in ISDF_DET_VARIANTS compute the same bits?
+  for v in base ${ISDF_DET_VARIANTS:-}; do
+    ISDF_HIP_LIB=$PWD/variants/lib_$v.so timeout 300 python tools/fwd_pair_check.py --dump /tmp/$v.npz > $O/check_$v.log 2>&1; lap $v rc=$?
+  done
+  ISDF_HIP_LIB=$PWD/variants/lib_base.so timeout 300 python tools/fwd_pair_check.py --dump /tmp/base2.npz > $O/check_base2.log 2>&1; lap base2 rc=$?
+  for v in base2 ${ISDF_DET_VARIANTS:-}; do echo "== base vs $v"; python tools/fwd_pair_check.py --compare /tmp/base.npz /tmp/$v.npz > $O/compare_$v.log 2>&1; grep -v "bit-identical" $O/compare_$v.log | head -n 40; done
 fi

@@ -2,7 +2,7 @@
     python tools/build_variants.py dbg="-DISDF_DEBUG_HOOKS=1"   ->  variants/lib_dbg.so   (used automatically)
 Prints the s_memtime stamps of wave 0 of workgroup 100 (fwd_pair.hip: stage ends before / after each barrier)."""
 import os, sys
-os.environ["ISDF_DEBUG_TIMELINE"] = "1"
+os.environ.setdefault("ISDF_DEBUG_TIMELINE", "1")   # "2": every wave of the workgroup (64 stamps each) instead of wave 0 + wall clocks
 _root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 _dbg = os.path.join(_root, "variants", "lib_dbg.so")
 if not os.environ.get("ISDF_HIP_LIB") and os.path.exists(_dbg):
@@ -24,6 +24,15 @@ for _ in range(3):
                                      _ffi.ptr(ws), ws.numel(), _stream(eng.device)), "isdf_sdf_eval")
     torch.cuda.synchronize()
 raw = ws[-4096:].view(torch.int64).cpu().numpy()
+if os.environ["ISDF_DEBUG_TIMELINE"] == "2":
+    t = raw.reshape(8, 64)
+    n = int((t > 0).all(axis=0).sum())
+    t0 = t[:, 0].min()
+    print("every wave of workgroup 100, %d stamps each (cycles since the first wave's first stamp), operand %s" % (n, eng.net.fwd_operand))
+    print("  n " + "".join("   wave %d" % w for w in range(8)) + "   spread")
+    for i in range(n):
+        print("%3d " % i + "".join("%9d" % (t[w, i] - t0) for w in range(8)) + "%9d" % (t[:, i].max() - t[:, i].min()))
+    sys.exit(0)
 ts = raw[:128]; ts = ts[ts > 0]
 print("n stamps", len(ts), "(s_memtime ticks = shader clock cycles), operand", eng.net.fwd_operand)
 prev = ts[0]
