@@ -93,7 +93,7 @@ class StepLosses(dict):
             self["grad_loss"] = ls[_ffi.LS_GRAD] / n
         if has_eik:
             self["eikonal_loss"] = ls[_ffi.LS_EIK] / n
-        self["total_loss"] = torch.tensor(ls[_ffi.LS_TOTAL] / n)
+        self["total_loss"] = torch.scalar_tensor(ls[_ffi.LS_TOTAL] / n)   # (0-d fp32 like torch.tensor(float), at half its cost)
 
 
 class _LazyCut(dict):
@@ -327,9 +327,11 @@ class HotPath:
         return time.perf_counter(), None
 
     def _timing_end(self, st, start, end):
-        """metrics.end_timing (metrics.py:25-38), milliseconds"""
+        """metrics.end_timing (metrics.py:25-38), milliseconds.  The reference synchronises, records `end`, synchronises again;
+        here `end` is recorded IN STREAM ORDER behind the step's last launch and the stream is synchronised once: the same
+        interval on the device (start of the step's first kernel's queue slot to the end of its last kernel) without the host's
+        wake-up latency of the first synchronisation inside it, and one device round trip less per step."""
         if st is not None:
-            st.synchronize()
             end.record(st)
             st.synchronize()
             return start.elapsed_time(end)
@@ -364,7 +366,7 @@ class HotPath:
         # the host every step once K > window_size, and a device copy per step (two H2D copies + new call plans) cost ~80 us of
         # the synchronised step in that regime.  Longer windows (non-incremental runs over many frames) use cached device tensors.
         if hip.inline_window and len(idxs) <= _ffi.MAX_INLINE_FRAMES:
-            fidx = tuple(int(i) for i in idxs)
+            fidx = tuple(idxs.tolist()) if isinstance(idxs, np.ndarray) else tuple(int(i) for i in idxs)   # (ndarray.tolist(): Python ints, 0.2 us)
             # reference quirk q4: normals are read from the UN-windowed normal_batch with
             # window-local indices (trainer.py:956,969); fix_normal_window=True uses idxs.
             nidx = fidx if hip.fix_normal_window else tuple(range(len(fidx)))
@@ -428,7 +430,7 @@ class HotPath:
             clock_ms = float(mailbox[8:8 + hip.clock_slots].max()) if mailbox.numel() >= 8 + hip.clock_slots else \
                 float(eng.reduce_buf[eng.reduce_floats:].max())
             hip.prev_step_ms = float(np.float32(step_time))
-        losses = StepLosses(mailbox[:8], self.grad_weight != 0, self.eik_weight != 0)
+        losses = StepLosses(mailbox, self.grad_weight != 0, self.eik_weight != 0)   # (reads the first 8 floats; a slice is 1.7 us)
         hip.step_count += 1
         self.tot_step_time += (1 / self.frac_time_perception) * (clock_ms / 1000.0)
         self.steps_since_frame += 1
