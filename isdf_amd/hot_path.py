@@ -619,6 +619,10 @@ def graft(trainer, rng="philox", seed=1, dist_group=None, fix_normal_window=Fals
     if engine_factory is None:
         engine_factory = ENGINE_FACTORY
     dev = torch.device(trainer.device)
+    if dev.type == "cuda" and dev.index is None and torch.cuda.is_available():
+        # "cuda" names the current device; tensors on it report "cuda:N", and `frames.frame_avg_losses.device == hip.device` decides
+        # whether the step's closing launch writes the keyframe losses in place (else: a separate launch and a blocking index_put)
+        dev = torch.device("cuda", torch.cuda.current_device())
     if engine_factory is None and dev.type != "cuda":
         raise _ffi.IsdfError(UNSUPPORTED_HINT % ("device %r is not a HIP device" % (trainer.device,)))
     if trainer.bounds_method not in ("ray", "pc"):

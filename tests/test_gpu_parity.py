@@ -458,6 +458,7 @@ def test_hip_trainer_step_contract():
             assert isinstance(losses["sdf_loss"], float) and torch.is_tensor(losses["total_loss"])
             "{:.6f}".format(losses["total_loss"])
             first = first or losses["total_loss"].item()
+        assert tr._hip.device.index is not None   # "cuda" is resolved to "cuda:N": `frame_avg_losses.device == hip.device` selects the in-place path
         assert len(tr.active_idxs) == 5 and list(tr.active_idxs[-2:]) == [5, 6]
         assert tr.active_pixels["indices_b"].dtype == torch.int64
         assert ms > 0 and tr.tot_step_time > 0 and tr.steps_since_frame == 25
