@@ -1,28 +1,36 @@
-// Pair-tile forward kernel (K2, MODE 0, <HD = 256, EP = 256>): positional encoding -> SDF MLP forward for TWO 64-point
-// tiles ("halves") per workgroup, ONE workgroup per CU, software-pipelined so that inside every wave the MFMAs of one half's
-// GEMM issue between the Softplus / pack / LDS-write instructions of the other half's epilogue.  Replaces, for 128 points,
+// Pair-tile forward kernel (K2, MODE 0, <HD = 256, EP = 256>): positional encoding -> SDF MLP forward for pairs of 64-point
+// tiles ("halves"), ONE persistent workgroup per CU walking pairs b, b + grid, ..., software-pipelined so that inside every wave the
+// MFMAs of one half's GEMM issue between the Softplus / pack / LDS-write instructions of the other half's epilogue.  Replaces, per
+// 128 points,
 //   embedding.PostionalEncoding.forward   isdf/modules/embedding.py:95-111
 //   SDFMap.forward                        isdf/modules/fc_map.py:94-111
 // (the same operand types and accumulation order as chain_kernel<256, 256, OPER, 0>; Softplus as chain_dev.h's softplus_x(): the first
 // two versions of this kernel, with softplus_f(), were bit-identical to the one-tile kernel on every ragged size and operand mode --
-// profiles/r05_fwd_pair_v1_ab.txt -- this one sits <= 3e-5 of the output scale from it, fp32 rounding of the reformulated epilogue).
+// profiles/r05_fwd_pair_v1_ab.txt -- this one sits <= 3e-5 of the output scale from it, fp32 rounding of the reformulated epilogue, and
+// as close to the fp32 oracle as the one-tile kernel: tests/test_gpu_parity.py.)
 //
 // Why: chain.hip gets its MFMA / VALU overlap only from the hardware scheduler picking between two independent
 // workgroups per CU; all eight waves of a workgroup are in a GEMM or in an epilogue at the same time, every GEMM starts with an
 // exposed L2 round trip for its weight fragments and every tile streams its own copy of every matrix through the CU's 64 B/clk
-// vector-memory path (as busy as the matrix pipe would be at 100 %).  Here, per wave (256 VGPRs):
+// vector-memory path (as busy as the matrix pipe would be at 100 %).  Here, per wave (229 of 256 VGPRs):
 //
-//      stage 2l+1 :  GEMM of half A, layer l      interleaved with   epilogue of half B, layer l-1        (barrier)
-//      stage 2l+2 :  GEMM of half B, layer l      interleaved with   epilogue of half A, layer l          (barrier)
+//      stage 2l   :  GEMM of half B, layer l      interleaved with   epilogue of half A, layer l          (barrier)
+//      stage 2l+1 :  GEMM of half A, layer l+1    interleaved with   epilogue of half B, layer l          (barrier)
+//      (past the last layer: GEMM of half A, layer 0 of the NEXT pair beside the epilogue of half B's last layer -- the loop over
+//       pairs is rotated by one stage, so only a workgroup's first and last stage are one-sided)
 //
 //   * "interleaved" is by construction, not by the scheduler's choice: the stage is one unrolled instruction stream of
-//     [LDS operand read, MFMA, one epilogue element, MFMA, one epilogue element, weight request] groups separated by
-//     sched_barriers, so VALU and matrix pipe are busy in the same cycles of the same wave;
+//     [LDS operand read, MFMA, one epilogue PHASE (one Softplus step of four elements), MFMA, phase, weight request] groups separated
+//     by sched_barriers, so VALU and matrix pipe are busy in the same cycles of the same wave;
 //   * the weight fragments of a layer sit in a 16-fragment window (64 VGPRs) and serve BOTH halves: half B re-requests every
 //     register with the next layer's fragment right after its last use, a full stage before half A needs it -- no GEMM waits for
 //     L2, and a K = 256 layer is fetched once per 128 points (K = 512 and the compensated layers stream through the window once
-//     per half);
-//   * one barrier per GEMM (the stage's GEMM reads one half of the tile, its epilogue writes the other).
+//     per half); past the last layer the "next" fragments are layer 0's, for the next pair;
+//   * one barrier per GEMM (the stage's GEMM reads one half of the tile, its epilogue writes the other);
+//   * per workgroup, not per pair: the biases / w_out staged in LDS, the first fill of the window; a pair's coordinates are
+//     requested a pair ahead.
+// What bounds it: the SIMD issue port (0.80 utilised: a Softplus element is 38 issue cycles, a K = 256 stage has four per MFMA), not
+// the matrix pipe (0.44); packed fp32 instructions are no way around it (they occupy the matrix pipe), nor is wave priority.
 #include "chain_dev.h"
 
 namespace isdf {
