@@ -29,8 +29,8 @@
 //   * one barrier per GEMM (the stage's GEMM reads one half of the tile, its epilogue writes the other);
 //   * per workgroup, not per pair: the biases / w_out staged in LDS, the first fill of the window; a pair's coordinates are
 //     requested a pair ahead.
-// What bounds it: the SIMD issue port (0.80 utilised: a Softplus element is 38 issue cycles, a K = 256 stage has four per MFMA), not
-// the matrix pipe (0.44); packed fp32 instructions are no way around it (they occupy the matrix pipe), nor is wave priority.
+// What bounds it: the SIMD issue port (0.88 utilised: a Softplus element is 38 issue cycles, a K = 256 stage has four per MFMA), not
+// the matrix pipe (0.50); packed fp32 instructions are no way around it (they occupy the matrix pipe), nor is wave priority.
 #include "chain_dev.h"
 
 namespace isdf {
