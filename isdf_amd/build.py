@@ -22,7 +22,10 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-com
 # VALU next to MFMAs measures slower than two scalar operations on this chip)
 # The stages are fully unrolled streams of up to 48 k-steps, each with its share of the epilogue: beyond the default size limit of
 # `#pragma unroll` (a rolled stage would index the weight window dynamically, i.e. put it in scratch memory).
-PER_FILE = {"fwd_pair.hip": ["-fno-slp-vectorize", "-mllvm", "-pragma-unroll-threshold=1000000"]}
+# dw.hip: the embedding-rebuilding units evaluate two adjacent columns per thread; SLP-vectorised, their shared point operand becomes the
+# broadcast half of a v_pk_fma_f32 -- the op_sel form isa_lint.py refuses (and packed fp32 VALU beside MFMAs is slower anyway).
+PER_FILE = {"fwd_pair.hip": ["-fno-slp-vectorize", "-mllvm", "-pragma-unroll-threshold=1000000"],
+            "dw.hip": ["-fno-slp-vectorize"]}
 
 
 def _hipcc():

@@ -189,6 +189,7 @@ static int train_step_impl(const isdf_net_cfg* net, const isdf_loss_cfg* loss, c
   p.sdf = o->sdf; p.sdf_grad = o->sdf_grad; p.tot_loss_mat = o->tot_loss_mat;
   p.tot_ws = totLoss; p.wg_loss = wgLoss; p.vec_part = vecPart; p.vecStride = w.vecStride;
   p.spill = (uint16_t*)(ws + w.offSpill); p.sp = w.sp;
+  p.pe_aux = (float*)(ws + w.offPeAux);
   chain_debug_from_env(p.dbg, ws + w.totalBytes - 4096);   // no-op in the shipped build (chain_debug.h)
   hipEvent_t* ev = (hipEvent_t*)o->prof_events;
   if (ev && hipEventRecord(ev[0], st) != hipSuccess) return ISDF_EHIP;
@@ -197,7 +198,7 @@ static int train_step_impl(const isdf_net_cfg* net, const isdf_loss_cfg* loss, c
   if (ev && hipEventRecord(ev[1], st) != hipSuccess) return ISDF_EHIP;
 
   DwParams d = {};
-  d.lay = l; d.sp = w.sp; d.spill = p.spill; d.n_valid = a->n_valid; d.S = a->S; d.dwPart = dwPart;
+  d.lay = l; d.sp = w.sp; d.spill = p.spill; d.pe_aux = p.pe_aux; d.n_valid = a->n_valid; d.S = a->S; d.dwPart = dwPart;
   rc = launch_dw(d, st);
   if (rc) return rc;
   if (ev && hipEventRecord(ev[2], st) != hipSuccess) return ISDF_EHIP;

@@ -260,8 +260,8 @@ __global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 && EP == HD && !oper_x2_a
 
   // ------------------------------------------------------------------ PE stage
   // thread (pt, part): embedding.py:95-111.  Region 2 of X (cols HD..) gets the
-  // embedding in the forward operand type; region 1 a bf16 copy staged for the
-  // spill (dW operand A_0).
+  // embedding in the forward operand type.  (Until round 5 region 1 also took a copy in the spill type, staged for the spill
+  // of the dW operand A_0: the dW kernel now rebuilds the embedding from x' itself, `pe_aux` below.)
   if constexpr (!WIDE_E && BM == 64) {
     // Round 5: a lane is a POINT, a wave takes directions w, w + 8, w + 16: the direction is wave-uniform, so a feature's column is
     // a scalar and its LDS address one v_xad of the lane's row base and swizzle, instead of a handful of per-lane integer operations
@@ -283,7 +283,6 @@ __global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 && EP == HD && !oper_x2_a
     auto put = [&](int feat, float v) {
       *(opT*)(row + (((HD + feat) * 2) ^ sw)) = (opT)v;
       if (X2ALL) *(opT*)(row + (((LO + HD + feat) * 2) ^ sw)) = (opT)(v - (float)(opT)v);   // emb_lo
-      if (MODE == 2) *(spillT*)(row + ((feat * 2) ^ sw)) = (spillT)v;   // copy in the spill type, staged for the spill
     };
     if (w == T::NW - 1) {   // (the wave with the fewest directions)
       xs[ln * 4] = y0; xs[ln * 4 + 1] = y1; xs[ln * 4 + 2] = y2;
@@ -317,7 +316,6 @@ __global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 && EP == HD && !oper_x2_a
     auto put = [&](int feat, float v) {
       *(opT*)(row + swz(pt, (HD + feat) * 2)) = (opT)v;
       if (X2ALL) *(opT*)(row + swz(pt, (LO + HD + feat) * 2)) = (opT)(v - (float)(opT)v);   // emb_lo
-      if (MODE == 2 && !WIDE_E) *(spillT*)(row + swz(pt, feat * 2)) = (spillT)v;   // copy in the spill type, staged for the spill
     };
     if (prt == 0) {
       xs[pt * 4] = y0; xs[pt * 4 + 1] = y1; xs[pt * 4 + 2] = y2;
@@ -336,36 +334,7 @@ __global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 && EP == HD && !oper_x2_a
     }
   }
   lds_barrier();
-  auto spill_region = [&](int colElemBase, int64_t tensorOff, auto cvt) {
-    // copy a [BM][HD] 16-bit region of X to global in frag16 order (16 B per lane); cvt: the region holds fp16
-    // operands and the spill tensors are bf16 (dW operand type of the BW = false instantiations)
-#pragma unroll
-    for (int fb = 0; fb < FB; ++fb)
-#pragma unroll
-      for (int pb = 0; pb < PB; ++pb)
-#pragma unroll
-        for (int qp = 0; qp < 2; ++qp) {
-          const int lb = (xw ^ (64 * fb + 32 * qp)) + colElemBase * 2 + pb * 32 * ROWB;
-          uint2 lo = *(const uint2*)(X + lb);
-          uint2 hi2 = *(const uint2*)(X + (lb ^ 16));
-          if (decltype(cvt)::value) {
-            const f16x4 a = __builtin_bit_cast(f16x4, lo), b = __builtin_bit_cast(f16x4, hi2);
-            lo = pack4<false>((float)a[0], (float)a[1], (float)a[2], (float)a[3]);
-            hi2 = pack4<false>((float)b[0], (float)b[1], (float)b[2], (float)b[3]);
-          }
-          bstore16_nt<true>(make_uint4(lo.x, lo.y, hi2.x, hi2.y), srdS, lane16, sbase(tensorOff), cidx(fb, pb, qp));
-        }
-  };
   refresh();
-  if (MODE == 2) {
-    if (!WIDE_E) {
-      spill_region(0, p.sp.A[0], std::false_type{});
-      lds_barrier();
-    } else {   // no room for a staged copy: spill the embedding halves straight from region 2
-      spill_region(HD, p.sp.A[0], std::integral_constant<bool, F16 && !BW>{});
-      spill_region(2 * HD, p.sp.A[0] + p.sp.tensorElems, std::integral_constant<bool, F16 && !BW>{});
-    }
-  }
 
   // ------------------------------------------------------------------ forward
   f32x16 acc[FB][PB];
@@ -844,6 +813,11 @@ __global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 && EP == HD && !oper_x2_a
       gbs[tid * 4 + 1] = si * (L.T[4] * bx + L.T[5] * by + L.T[6] * bz);
       gbs[tid * 4 + 2] = si * (L.T[8] * bx + L.T[9] * by + L.T[10] * bz);
       gbs[tid * 4 + 3] = sbar * so;
+      // what the dW kernel rebuilds its two embedding-shaped operands from (the embedding and Ebar = J_pe gbar): 6 floats per point
+      // instead of 2 x EP 16-bit values.  Every row of the tile is written (rows past the last point: x' of the origin, gbar = 0).
+      float4* aux = (float4*)(p.pe_aux + (n0 + tid) * 8);
+      aux[0] = make_float4(xs[tid * 4], xs[tid * 4 + 1], xs[tid * 4 + 2], 0.f);
+      aux[1] = make_float4(gbs[tid * 4], gbs[tid * 4 + 1], gbs[tid * 4 + 2], 0.f);
     }
   }
   if (MODE != 2) return;
@@ -928,9 +902,7 @@ __global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 && EP == HD && !oper_x2_a
   }
   lds_barrier();
   TS();   // (Ebar in region 2)
-  spill_region(HD, p.sp.GB[0], std::false_type{});
-  if (WIDE_E) spill_region(2 * HD, p.sp.GB[0] + p.sp.tensorElems, std::false_type{});
-  TS();   // (Ebar spilled)
+  TS();   // (development build: the stamp that closed the Ebar spill until round 5 -- the dW kernel rebuilds Ebar from pe_aux)
 
   // ------------------------------------------------------------------ adjoint of the first reverse sweep (upward)
   // The top layer's epilogue also IS the top of the ordinary reverse sweep (zbar_L needs only a_L, the

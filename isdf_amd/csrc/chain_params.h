@@ -26,6 +26,8 @@ struct ChainParams {
   float* vec_part;            // [nTiles][vecStride] bias / out-layer gradient partials (no atomics)
   int32_t vecStride;
   uint16_t* spill; SpillLayout sp;
+  float* pe_aux;              // [nTiles*TILE_PTS][8] (train): x' (3), pad, gbar in x' space (3), pad -- what the dW kernel rebuilds the two
+                              // embedding-shaped operands (the embedding itself and Ebar = J_pe gbar) from instead of reading them back
   int32_t n_cu;               // compute units of the device the launch goes to (set by launch_chain): dispatch round of a workgroup = blockIdx / n_cu
   ChainDebug dbg;             // empty in the shipped build (chain_debug.h)
 };
@@ -34,8 +36,9 @@ struct DwParams {
   NetLayout lay;
   SpillLayout sp;
   const uint16_t* spill;
+  const float* pe_aux;   // [nTiles*TILE_PTS][8], written by the chain kernel (ChainParams::pe_aux)
   const int32_t* n_valid; int64_t n_points_host; int32_t S;
-  float* dwPart;   // [units][DW_SPLITK][HD*HD]
+  float* dwPart;   // [dw_total_slabs][256*256] (isdf_common.h)
 };
 
 

@@ -26,7 +26,8 @@ template <int HD> struct DwTile {
   static constexpr int BM = DW_PTS;
   static constexpr int ROWB = DW_BLK * 2 + 64;    // padded LDS row (bytes) of a 256-column operand slice
   static constexpr int TEN = BM * ROWB;           // one operand slice in LDS
-  static constexpr int LDS_BYTES = 4 * TEN;       // two operand slices x two stage buffers
+  static constexpr int AUXB = BM * 32;            // one tile's pe_aux rows (8 floats per point)
+  static constexpr int LDS_BYTES = 4 * TEN + 2 * AUXB;   // two operand slices x two stage buffers + two tiles of pe_aux
   static constexpr int CH = (BM * DW_BLK * 2) / (512 * 16);  // uint4 per thread per tensor
 };
 
@@ -47,23 +48,34 @@ __device__ __forceinline__ int frag16_piece(int c, int half, int sl, int& pt, in
 
 // F16: the spilled operands are fp16 (NetLayout::bwd_f16) instead of bf16 -- the same bits through the same transpose reads,
 // v_mfma_f32_32x32x16_f16 instead of _bf16.
+//
+// Units whose input-side operand is embedding-shaped (layer 0, and the embedding columns of the cat layer) do not READ it
+// (round 6): both operands of such a unit's input side -- the embedding of stage q = 0 and Ebar = J_pe gbar of stage q = 1 -- are
+// functions of six floats per point (x' and gbar in x' space, `pe_aux`, written by the chain kernel's loss stage), so the
+// workgroup rebuilds the 64 x 256 slice in LDS: a thread owns two adjacent columns (its direction, octave and phase are
+// fixed for the whole kernel) and walks 16 points.  The arithmetic is the chain kernel's PE / Ebar stage value for value
+// (same expression shapes, `fr` a power of two), so the operand bits equal what that kernel used to spill.  4 of the 28 tensor
+// reads of a step and 2 of the chain kernel's 25 tensor stores are gone (82 MB of 1.245 GB per 27 k-point step).
 template <int HD, bool F16>
 __global__ __launch_bounds__(512, 2) void dw_kernel(const DwParams p) {
   typedef DwTile<HD> T;
   constexpr int BM = T::BM, ROWB = T::ROWB, CH = T::CH;
+  static_assert(TILE_PTS == DW_PTS, "pe_aux staging below assumes one dW stage pair per chain tile");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const NetLayout& L = p.lay;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int wo = w >> 1, wi = w & 1;
-  const int unit = blockIdx.x / DW_SPLITK, split = blockIdx.x % DW_SPLITK;
+  // block -> (unit, K-split): units have 32 or 48 splits (isdf_common.h)
+  int unit = 0, split = blockIdx.x;
+  for (int n; split >= (n = dw_unit_splits(L, unit)); ++unit) split -= n;
+  const int DW_SPLITK = dw_unit_splits(L, unit);
   const DwUnit du = dw_unit(L, unit);
   const int li = du.li;
   // input-side operand: columns [256*ib, +256) of the padded layer input.  Layer 0 reads the
   // embedding; the cat layer reads [a | emb]; the rest read the previous activation.
-  const bool fromEmb = li == 0 || (li == L.cat && du.ib * DW_BLK >= HD);
+  const bool fromEmb = dw_unit_from_emb(L, du);
   const int slBfull = (li == L.cat && fromEmb) ? du.ib - HD / DW_BLK : du.ib;   // 256-column slice of the operand
-  // an embedding-shaped operand is stored as EP/HD consecutive HD-wide tensors of HD/256 slices each
-  const int slT = slBfull / (HD / DW_BLK), slB = slBfull % (HD / DW_BLK);
+  const int slB = slBfull % (HD / DW_BLK);
   const int slA = du.ob;
 
   const int64_t P = p.n_valid ? (int64_t)(*p.n_valid) * p.S : p.n_points_host;
@@ -72,8 +84,8 @@ __global__ __launch_bounds__(512, 2) void dw_kernel(const DwParams p) {
 
   // stage q of tile t: q=0 -> (ZB[li], I), q=1 -> (P[li], GB)
   const int64_t offZ = p.sp.ZB[li], offP = p.sp.P[li];
-  const int64_t offI = fromEmb ? p.sp.A[0] + slT * p.sp.tensorElems : p.sp.A[li];
-  const int64_t offG = fromEmb ? p.sp.GB[0] + slT * p.sp.tensorElems : p.sp.GB[li];
+  const int64_t offI = fromEmb ? 0 : p.sp.A[li];
+  const int64_t offG = fromEmb ? 0 : p.sp.GB[li];
 
   f32x16 acc[2][4];
 #pragma unroll
@@ -84,43 +96,6 @@ __global__ __launch_bounds__(512, 2) void dw_kernel(const DwParams p) {
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
   const int nStages = split < nTiles ? 2 * ((nTiles - split + DW_SPLITK - 1) / DW_SPLITK) : 0;
-  // Two register sets so TWO stages of global loads are in flight while one is computed
-  // (HBM-bound kernel: 64 KB per stage and CU; one stage in flight left ~40 % of the bandwidth unused).
-  uint4 regA0[CH], regB0[CH], regA1[CH], regB1[CH];
-  auto issue = [&](int st, uint4 (&ra)[CH], uint4 (&rb)[CH]) {
-    const int u = split + (st >> 1) * DW_SPLITK;      // half-tile index
-    const int t = u / HALVES, half = u % HALVES;
-    const uint4* ta = (const uint4*)(p.spill + ((st & 1) ? offP : offZ) + (int64_t)t * p.sp.tileStride);
-    const uint4* tb = (const uint4*)(p.spill + ((st & 1) ? offG : offI) + (int64_t)t * p.sp.tileStride);
-#pragma unroll
-    for (int c = 0; c < CH; ++c) {
-      int pt, f0;
-      typedef unsigned int u32x4n __attribute__((ext_vector_type(4)));
-      const u32x4n va = __builtin_nontemporal_load((const u32x4n*)(ta + frag16_piece(c * 512 + tid, half, slA, pt, f0)));
-      const u32x4n vb = __builtin_nontemporal_load((const u32x4n*)(tb + frag16_piece(c * 512 + tid, half, slB, pt, f0)));
-      ra[c] = make_uint4(va[0], va[1], va[2], va[3]); rb[c] = make_uint4(vb[0], vb[1], vb[2], vb[3]);
-    }
-  };
-  auto commit = [&](const uint4 (&ra)[CH], const uint4 (&rb)[CH], int buf) {
-    char* sb = smem + buf * 2 * T::TEN;
-#pragma unroll
-    for (int c = 0; c < CH; ++c) {
-      int pt, f0;
-      frag16_piece(c * 512 + tid, 0, 0, pt, f0);
-      char* pa = sb + pt * ROWB + f0 * 2;
-      *(uint2*)(pa) = make_uint2(ra[c].x, ra[c].y);
-      *(uint2*)(pa + 16) = make_uint2(ra[c].z, ra[c].w);
-      char* pb = sb + T::TEN + pt * ROWB + f0 * 2;
-      *(uint2*)(pb) = make_uint2(rb[c].x, rb[c].y);
-      *(uint2*)(pb + 16) = make_uint2(rb[c].z, rb[c].w);
-    }
-  };
-
-  if (nStages > 0) { issue(0, regA0, regB0); }
-  if (nStages > 1) { issue(1, regA1, regB1); }
-  if (nStages > 0) commit(regA0, regB0, 0);
-  if (nStages > 2) issue(2, regA0, regB0);
-  __syncthreads();
 
   // per-lane transpose-read addressing: in each 16-lane group source lane s
   // supplies row (s>>2), 4-element column chunk (s&3); destination lane i gets
@@ -156,22 +131,179 @@ __global__ __launch_bounds__(512, 2) void dw_kernel(const DwParams p) {
     }
   };
 
-  // Stage st sits in LDS buffer (st&1).  Each iteration first writes stage st+1 (loads issued two
-  // stages ago) into the OTHER LDS buffer, re-issues that register set for stage st+3, then runs the
-  // MFMAs of stage st: the LDS commit of one wave overlaps the MFMAs of the others, one barrier per stage.
-  for (int st = 0; st < nStages; st += 2) {
-    if (st + 1 < nStages) { commit(regA1, regB1, 1); if (st + 3 < nStages) issue(st + 3, regA1, regB1); }
-    compute(0);
-    __syncthreads();
-    if (st + 1 < nStages) {
-      if (st + 2 < nStages) { commit(regA0, regB0, 0); if (st + 4 < nStages) issue(st + 4, regA0, regB0); }
-      compute(1);
-      __syncthreads();
+  // The stage pipeline, once per kind of unit (PE: the input-side operand is rebuilt from pe_aux, not loaded).
+  auto run = [&](auto pe_tag) {
+    constexpr bool PE = decltype(pe_tag)::value;
+    // Two register sets so TWO stages of global loads are in flight while one is computed
+    // (HBM-bound kernel: 64 KB per stage and CU; one stage in flight left ~40 % of the bandwidth unused).
+    uint4 regA0[CH], regB0[CH], regA1[CH], regB1[CH];
+    typedef unsigned int u32x4n __attribute__((ext_vector_type(4)));
+    auto issue = [&](int st, uint4 (&ra)[CH], uint4 (&rb)[CH]) {
+      const int u = split + (st >> 1) * DW_SPLITK;      // half-tile index
+      const int t = u / HALVES, half = u % HALVES;
+      const uint4* ta = (const uint4*)(p.spill + ((st & 1) ? offP : offZ) + (int64_t)t * p.sp.tileStride);
+      const uint4* tb = (const uint4*)(p.spill + ((st & 1) ? offG : offI) + (int64_t)t * p.sp.tileStride);
+#pragma unroll
+      for (int c = 0; c < CH; ++c) {
+        int pt, f0;
+        const u32x4n va = __builtin_nontemporal_load((const u32x4n*)(ta + frag16_piece(c * 512 + tid, half, slA, pt, f0)));
+        ra[c] = make_uint4(va[0], va[1], va[2], va[3]);
+        if constexpr (!PE) {
+          const u32x4n vb = __builtin_nontemporal_load((const u32x4n*)(tb + frag16_piece(c * 512 + tid, half, slB, pt, f0)));
+          rb[c] = make_uint4(vb[0], vb[1], vb[2], vb[3]);
+        }
+      }
+    };
+    // ---- PE units: a thread owns up to three (point, direction) ITEMS of a 64-point tile -- item = tid + 512 r, point = item / 21,
+    // direction = item % 21, the same for every stage -- and writes the direction's 2 n_freqs columns: sin / cos of octave 0 from the
+    // hardware (in revolutions: the 1 / 2 pi lives in the direction constants), the higher octaves by angle doubling
+    // (s' = 2 s c, c' = 1 - 2 s^2: 4 plain VALU operations per octave and pair instead of two projections and two transcendentals;
+    // <= 3e-6 from the direct value after 11 doublings, against an fp16 ulp of 5e-4).  Threads 320..383 of round r = 2 (which has
+    // only 320 items) write x' / gbar (features 0..2) and the zero padding of their point.
+    constexpr float kInv2Pi = 0.15915494309189535f, k2Pi = 6.283185307179586f;
+    float drx[3] = {0.f, 0.f, 0.f}, dry[3] = {0.f, 0.f, 0.f}, drz[3] = {0.f, 0.f, 0.f};
+    float4 auxr = make_float4(0.f, 0.f, 0.f, 0.f);
+    if constexpr (PE) {
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const int item = tid + 512 * r;
+        const int d = item < BM * N_DIRS ? item % N_DIRS : 0;
+        drx[r] = kDirs[0][d] * kInv2Pi; dry[r] = kDirs[1][d] * kInv2Pi; drz[r] = kDirs[2][d] * kInv2Pi;
+      }
     }
-  }
+    // pe_aux of the k-th tile of this workgroup: 64 points x 2 float4, one float4 per thread of the first two waves
+    auto load_aux = [&](int k) {
+      if (tid < 128 && 2 * k < nStages)
+        auxr = ((const float4*)p.pe_aux)[((int64_t)(split + k * DW_SPLITK)) * (BM * 2) + tid];
+    };
+    auto store_aux = [&](int k) {
+      if (tid < 128) *(float4*)(smem + 4 * T::TEN + (k & 1) * T::AUXB + tid * 16) = auxr;
+    };
+    auto commit = [&](int st, const uint4 (&ra)[CH], const uint4 (&rb)[CH], int buf) {
+      char* sb = smem + buf * 2 * T::TEN;
+#pragma unroll
+      for (int c = 0; c < CH; ++c) {
+        int pt, f0;
+        frag16_piece(c * 512 + tid, 0, 0, pt, f0);
+        char* pa = sb + pt * ROWB + f0 * 2;
+        *(uint2*)(pa) = make_uint2(ra[c].x, ra[c].y);
+        *(uint2*)(pa + 16) = make_uint2(ra[c].z, ra[c].w);
+        if constexpr (!PE) {
+          char* pb = sb + T::TEN + pt * ROWB + f0 * 2;
+          *(uint2*)(pb) = make_uint2(rb[c].x, rb[c].y);
+          *(uint2*)(pb + 16) = make_uint2(rb[c].z, rb[c].w);
+        }
+      }
+      if constexpr (PE) {
+        // q = 0: the embedding (embedding.py:95-111): [x' | sin(xb_df) | cos(xb_df)], xb_df = (x' . dir_d) 2^f
+        // q = 1: Ebar = J_pe gbar (chain.hip's Ebar stage): [gbar | cos(xb_df) k_df | -sin(xb_df) k_df], k_df = (gbar . dir_d) 2^f
+        const char* auxl = smem + 4 * T::TEN + ((st >> 1) & 1) * T::AUXB;
+        char* tb = sb + T::TEN;
+        const bool q1 = st & 1;
+        const int nf = L.n_freqs, halfE = N_DIRS * nf, colBase = slBfull * DW_BLK;
+        typedef typename Op<F16>::e eT;
+        typedef eT e2 __attribute__((ext_vector_type(2)));
+        auto st1 = [&](char* row, int col, float v) {            // one column; `col` relative to this unit's 256-column slice
+          if ((unsigned)col < (unsigned)DW_BLK) *(eT*)(row + col * 2) = (eT)v;
+        };
+        auto fill = [&](auto nfc, auto q1c) {
+          constexpr int NFT = decltype(nfc)::value;               // n_freqs at compile time (0: run-time loop, 2-byte stores)
+          constexpr bool Q1 = decltype(q1c)::value;
+          const int nfl = NFT ? NFT : nf;
+          // opaque to the optimiser: the items' points, rows and columns are the same in every stage, and hoisted out of the stage loop
+          // they would sit in ~20 registers next to the 128 of the accumulator for the whole kernel (and spill)
+          int tq = tid;
+          asm volatile("" : "+v"(tq));
+#pragma unroll
+          for (int r = 0; r < 3; ++r) {
+            const int item = tq + 512 * r;
+            if (item < BM * N_DIRS) {
+              const int pt = item / N_DIRS, d = item - pt * N_DIRS;
+              char* row = tb + pt * ROWB;
+              const float4 y = *(const float4*)(auxl + pt * 32);
+              const float r0 = y.x * drx[r] + y.y * dry[r] + y.z * drz[r];
+              float sn = __builtin_amdgcn_sinf(r0), cs = __builtin_amdgcn_cosf(r0), kf = 0.f;
+              if constexpr (Q1) {
+                const float4 g = *(const float4*)(auxl + pt * 32 + 16);
+                kf = (g.x * drx[r] + g.y * dry[r] + g.z * drz[r]) * k2Pi;
+              }
+              const int cS = 3 + d * nfl - colBase, cC = cS + halfE;     // first column of the sine / cosine group
+              auto vals = [&](float& a, float& b) {        // this octave's two values, then on to the next octave
+                a = Q1 ? cs * kf : sn; b = Q1 ? -sn * kf : cs;
+                const float t = sn * cs;
+                cs = __builtin_fmaf(-2.f * sn, sn, 1.f); sn = t + t; kf += kf;
+              };
+              if constexpr (NFT == 0) {
+                for (int f = 0; f < nfl; ++f) { float a, b; vals(a, b); st1(row, cS + f, a); st1(row, cC + f, b); }
+              } else {
+                // n_freqs even: column 3 + d n_freqs (+ 21 n_freqs) is odd, so octaves (1,2), (3,4), ... are 4-byte aligned pairs;
+                // the slice holds the whole embedding (E = 42 n_freqs + 3 <= 256), no range checks.  Values leave as they are made:
+                // the kernel sits at the 256-register limit (a 256 x 256 fp32 accumulator per workgroup)
+                static_assert(NFT % 2 == 0, "paired stores assume an even octave count");
+                // (volatile: left alone, the compiler fuses a group's 2 + 4 + 4 + 2 bytes into ONE ds_write_b96 at an address that is
+                // 2 mod 4 -- legal in the LDS's unaligned mode and several times slower than the four aligned stores)
+                float a, b, a2, b2;
+                vals(a, b);
+                *(volatile eT*)(row + cS * 2) = (eT)a; *(volatile eT*)(row + cC * 2) = (eT)b;
+#pragma unroll
+                for (int f = 1; f + 1 < NFT; f += 2) {
+                  vals(a, b); vals(a2, b2);
+                  e2 ps, pc; ps[0] = (eT)a; ps[1] = (eT)a2; pc[0] = (eT)b; pc[1] = (eT)b2;
+                  *(volatile uint32_t*)(row + (cS + f) * 2) = __builtin_bit_cast(uint32_t, ps);
+                  *(volatile uint32_t*)(row + (cC + f) * 2) = __builtin_bit_cast(uint32_t, pc);
+                }
+                vals(a, b);
+                *(volatile eT*)(row + (cS + NFT - 1) * 2) = (eT)a; *(volatile eT*)(row + (cC + NFT - 1) * 2) = (eT)b;
+              }
+            } else if (item - BM * N_DIRS < BM) {
+              const int pt = item - BM * N_DIRS;
+              char* row = tb + pt * ROWB;
+              const float4 v = *(const float4*)(auxl + pt * 32 + (Q1 ? 16 : 0));
+              st1(row, 0 - colBase, v.x); st1(row, 1 - colBase, v.y); st1(row, 2 - colBase, v.z);
+              for (int f = L.E; f < L.EP; ++f) st1(row, f - colBase, 0.f);
+            }
+            __builtin_amdgcn_sched_barrier(0);      // one item at a time: interleaved, three items' temporaries do not fit the register file
+          }
+        };
+        const bool whole6 = nf == 6 && L.EP == DW_BLK;     // replicaCAD.json / scanNet.json
+        if (whole6) { if (q1) fill(std::integral_constant<int, 6>{}, std::true_type{}); else fill(std::integral_constant<int, 6>{}, std::false_type{}); }
+        else { if (q1) fill(std::integral_constant<int, 0>{}, std::true_type{}); else fill(std::integral_constant<int, 0>{}, std::false_type{}); }
+      }
+    };
+
+    if constexpr (PE) {
+      load_aux(0); store_aux(0); load_aux(1);
+    }
+    if (nStages > 0) { issue(0, regA0, regB0); }
+    if (nStages > 1) { issue(1, regA1, regB1); }
+    if constexpr (PE) __syncthreads();          // tile 0's pe_aux rows are in LDS
+    if (nStages > 0) commit(0, regA0, regB0, 0);
+    if (nStages > 2) issue(2, regA0, regB0);
+    __syncthreads();
+
+    // Stage st sits in LDS buffer (st&1).  Each iteration first writes stage st+1 (loads issued two
+    // stages ago) into the OTHER LDS buffer, re-issues that register set for stage st+3, then runs the
+    // MFMAs of stage st: the LDS commit of one wave overlaps the MFMAs of the others, one barrier per stage.
+    // (PE units: the pe_aux rows of the NEXT tile go to LDS in the first half, a barrier ahead of the commit that reads them.)
+    for (int st = 0; st < nStages; st += 2) {
+      if (st + 1 < nStages) {
+        commit(st + 1, regA1, regB1, 1);
+        if constexpr (PE) { store_aux((st >> 1) + 1); load_aux((st >> 1) + 2); }
+        if (st + 3 < nStages) issue(st + 3, regA1, regB1);
+      }
+      compute(0);
+      __syncthreads();
+      if (st + 1 < nStages) {
+        if (st + 2 < nStages) { commit(st + 2, regA0, regB0, 0); if (st + 4 < nStages) issue(st + 4, regA0, regB0); }
+        compute(1);
+        __syncthreads();
+      }
+    }
+  };
+  if (fromEmb) run(std::true_type{}); else run(std::false_type{});
 
   // partial slab [o][i]
-  slab_t* slab = (slab_t*)p.dwPart + ((int64_t)unit * DW_SPLITK + split) * DW_BLK * DW_BLK;
+  slab_t* slab = (slab_t*)p.dwPart + ((int64_t)dw_slab_base(L, unit) + split) * DW_BLK * DW_BLK;
 #pragma unroll
   for (int ob = 0; ob < 2; ++ob)
 #pragma unroll
@@ -189,7 +321,7 @@ __global__ __launch_bounds__(512, 2) void dw_kernel(const DwParams p) {
 int launch_dw(const DwParams& p, hipStream_t st) {
   if (!layout_supported(p.lay)) return ISDF_EUNSUPPORTED;
   typedef DwTile<256> T;
-  const dim3 grid(dw_units(p.lay) * DW_SPLITK), block(512);
+  const dim3 grid(dw_total_slabs(p.lay)), block(512);
   auto go = [&](auto k) {
     if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES) != hipSuccess) return (int)ISDF_EHIP;
     hipLaunchKernelGGL(k, grid, block, T::LDS_BYTES, st, p);

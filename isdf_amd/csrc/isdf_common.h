@@ -13,7 +13,10 @@ constexpr int TILE_PTS = 64;   // points per chain-kernel workgroup (two workgro
 constexpr int DW_PTS = 64;     // points per dW-kernel stage
 constexpr int CHAIN_NW = 8;    // waves per chain-kernel workgroup (each owns HD/CHAIN_NW features)
 constexpr int CHAIN_CHUNK_FRAGS = 8;   // weight fragments a wave requests at once (32 VGPRs at the 128-VGPR budget)
-constexpr int DW_SPLITK = 36;  // K-splits per dW unit (7 units x 36 = 252 workgroups)
+// K-splits per dW unit.  A unit whose input-side operand is embedding-shaped REBUILDS it from six floats per point (dw.hip) instead
+// of reading it: half the bytes per stage, but ~300 VALU instructions per thread and stage next to the MFMAs -- its stages are the
+// longer ones, so it gets more, shorter K-splits.  Default net: 5 x 32 + 2 x 48 = 256 workgroups = one per CU.
+constexpr int DW_SPLIT_REG = 32, DW_SPLIT_PE = 48, DW_SPLIT_MAX = 48;
 typedef float slab_t;          // K-split partial slabs (bf16 slabs measured: parity unchanged, -2 us only)
 
 // Vector types for the 16-bit MFMA operands.
@@ -61,9 +64,11 @@ struct NetLayout {
 struct SpillLayout {
   int64_t tensorElems;   // per tensor per tile (TILE_PTS * HD); the buffer is [tile][tensor][tensorElems]
   int64_t tileStride;    // elements between consecutive tiles (= tensor count * tensorElems)
-  int64_t A[MAXL + 1];   // A[0] = embedding (EP/HD consecutive HD-wide tensors), A[li+1] = activation after layer li
+  int64_t A[MAXL + 1];   // A[li+1] = activation after layer li.  A[0] (the embedding) is NOT stored: -1 (round 6; see GB)
   int64_t P[MAXL];       // d sdf / d z_li
-  int64_t GB[MAXL];      // GB[0] = Ebar (EP/HD tensors), GB[li] = adjoint entering layer li (li >= 1)
+  int64_t GB[MAXL];      // GB[li] = adjoint entering layer li (li >= 1).  GB[0] (Ebar = J_pe gbar) is NOT stored: -1.  The two
+                         // embedding-shaped dW operands are functions of 6 floats per point (x' and gbar, WorkspaceLayout::offPeAux): the dW
+                         // kernel rebuilds them in LDS instead of reading 2 x 512 B per point back (twice: layer 0 and the cat layer)
   int64_t ZB[MAXL];      // d loss / d z_li
   int64_t totalElems;
 };
@@ -73,9 +78,10 @@ struct WorkspaceLayout {
   SpillLayout sp;
   int64_t offSpill;      // bytes
   int64_t offWgLoss;     // float [nTiles][8]
-  int64_t offDwPart;     // float [units][DW_SPLITK][HD*HD]
+  int64_t offDwPart;     // float [dw_total_slabs][256*256]: unit u's dw_unit_splits(u) K-split slabs start at slab dw_slab_base(u)
   int64_t offVecPart;    // float [nTiles][vecStride]: per-workgroup bias / out-layer gradient partials
   int64_t offTotLoss;    // float [maxPts] per-point total loss
+  int64_t offPeAux;      // float [nTiles*TILE_PTS][8]: x' (3), 0, gbar in x' space (3), 0 per point -- chain -> dW
   int32_t vecStride;
   int64_t totalBytes;
 };
@@ -172,16 +178,30 @@ __host__ __device__ inline DwUnit dw_unit(const NetLayout& l, int u) {
   return DwUnit{0, 0, 0};
 }
 
+__host__ __device__ inline bool dw_unit_from_emb(const NetLayout& l, const DwUnit& du) {
+  return du.li == 0 || (du.li == l.cat && du.ib * DW_BLK >= l.HD);
+}
+__host__ __device__ inline int dw_unit_splits(const NetLayout& l, int u) {
+  return dw_unit_from_emb(l, dw_unit(l, u)) ? DW_SPLIT_PE : DW_SPLIT_REG;
+}
+__host__ __device__ inline int dw_slab_base(const NetLayout& l, int u) {   // K-split slabs in front of unit u's ([slab][256 x 256] fp32)
+  int n = 0;
+  for (int v = 0; v < u; ++v) n += dw_unit_splits(l, v);
+  return n;
+}
+__host__ __device__ inline int dw_total_slabs(const NetLayout& l) { return dw_slab_base(l, dw_units(l)); }
+
 inline void make_workspace(const NetLayout& l, int64_t maxPts, int64_t maxRays, bool train, WorkspaceLayout* w) {
   w->nTiles = (maxPts + TILE_PTS - 1) / TILE_PTS;
   SpillLayout& s = w->sp;
   s.tensorElems = TILE_PTS * (int64_t)l.HD;   // offsets below are WITHIN a tile's block
   int64_t o = 0;
-  const int embT = l.EP / l.HD;               // HD-wide tensors per embedding-shaped operand
-  for (int i = 0; i <= l.L; ++i) { s.A[i] = o; o += s.tensorElems * (i == 0 ? embT : 1); }
+  s.A[0] = -1;                                // embedding-shaped operands are rebuilt by the dW kernel (offPeAux), not stored
+  for (int i = 1; i <= l.L; ++i) { s.A[i] = o; o += s.tensorElems; }
   if (train) {
     for (int i = 0; i < l.L; ++i) { s.P[i] = o; o += s.tensorElems; }
-    for (int i = 0; i < l.L; ++i) { s.GB[i] = o; o += s.tensorElems * (i == 0 ? embT : 1); }
+    s.GB[0] = -1;
+    for (int i = 1; i < l.L; ++i) { s.GB[i] = o; o += s.tensorElems; }
     for (int i = 0; i < l.L; ++i) { s.ZB[i] = o; o += s.tensorElems; }
   }
   s.tileStride = o;
@@ -191,10 +211,11 @@ inline void make_workspace(const NetLayout& l, int64_t maxPts, int64_t maxRays, 
   w->offSpill = b; b += o * 2; b = (b + 255) / 256 * 256;
   (void)maxRays;
   w->offWgLoss = b; b += (train ? w->nTiles * 8 : 0) * 4; b = (b + 255) / 256 * 256;
-  w->offDwPart = b; b += train ? (int64_t)dw_units(l) * DW_SPLITK * DW_BLK * DW_BLK * 4 : 0; b = (b + 255) / 256 * 256;
+  w->offDwPart = b; b += train ? (int64_t)dw_total_slabs(l) * DW_BLK * DW_BLK * 4 : 0; b = (b + 255) / 256 * 256;
   w->vecStride = round_up(l.L * l.HD + 2 * l.HD + 8, 64);   // [db_0..db_{L-1} | dwout(adjoint) | dwout(reverse) | dbout]
   w->offVecPart = b; b += train ? w->nTiles * (int64_t)w->vecStride * 4 : 0; b = (b + 255) / 256 * 256;
   w->offTotLoss = b; b += train ? maxPts * 4 : 0; b = (b + 255) / 256 * 256;
+  w->offPeAux = b; b += train ? w->nTiles * TILE_PTS * 8 * 4 : 0; b = (b + 255) / 256 * 256;
   w->totalBytes = b + 256 + 4096;   // last 4 KB: timeline stamps of the -DISDF_DEBUG_HOOKS=1 development build
 }
 
