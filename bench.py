@@ -355,6 +355,8 @@ def main():
     ap.add_argument("--fwd-operand", default="fp16x2", choices=["fp16x2", "fp16", "bf16", "fp16x2_full"])
     ap.add_argument("--bwd-operand", default=None, choices=["fp16", "bf16"],
                     help="operand / spill type of the second-order sweeps and the dW contraction (default: fp16 with an fp16-family forward)")
+    ap.add_argument("--spill-operand", default=None, choices=["auto", "16bit", "e4m3", "e4m3_gb"],
+                    help="storage of the spilled P / GB tensors (default auto: e4m3 bytes for nets of up to six octaves with fp16 sweeps)")
     ap.add_argument("--ramp-seconds", type=float, default=0.4,
                     help="untimed clock-ramp phase before the W warm-up steps (a fresh box runs the first ~100 ms at idle "
                          "clocks: 25 cold steps measured 13 %% slower than steady state in round 1); reported in the JSON line")
@@ -422,7 +424,7 @@ def main():
     np.random.seed(1)
     tr = HipTrainer("cuda:%d" % local, cfg, incremental=True, inv_bounds_transform=synthetic.bounds_transform(),
                     rng="philox", seed=1, dist_group=group, fwd_operand=args.fwd_operand, bwd_operand=args.bwd_operand,
-                    overlap_allreduce=args.overlap_allreduce)
+                    overlap_allreduce=args.overlap_allreduce, spill_operand=args.spill_operand)
     dev = tr.device       # (replicated weights: graft() broadcasts rank 0's at construction)
     tr.frames = FrameData(frame_id=np.arange(F), depth_batch=torch.from_numpy(depth).to(dev),
                           T_WC_batch=torch.from_numpy(T).to(dev), normal_batch=torch.from_numpy(normal).to(dev),

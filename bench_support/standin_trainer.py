@@ -30,7 +30,7 @@ from isdf_amd.modules import PositionalEncodingHIP, SDFMapHIP
 
 class StandinTrainer:
     def __init__(self, device, config_file, chkpt_load_file=None, incremental=True, grid_dim=200, *,
-                 inv_bounds_transform=None, fwd_operand="fp16x2", engine_factory=None, bwd_operand=None):
+                 inv_bounds_transform=None, fwd_operand="fp16x2", engine_factory=None, bwd_operand=None, spill_operand=None):
         """Positional signature of the reference constructor (trainer.py:35-42).  config_file: path to / dict
         with the reference's JSON schema.  The reference derives `inv_bounds_transform` from the GT mesh
         (trainer.py:76-87, 102-123); with no mesh IO here it is an argument (None = live modes)."""
@@ -51,7 +51,7 @@ class StandinTrainer:
         self.inv_bounds_transform = inv_bounds_transform
         self.active_idxs = None
         self.active_pixels = None
-        self._net_opts = dict(fwd_operand=fwd_operand, engine_factory=engine_factory, bwd_operand=bwd_operand)
+        self._net_opts = dict(fwd_operand=fwd_operand, engine_factory=engine_factory, bwd_operand=bwd_operand, spill_operand=spill_operand)
         self.load_networks()
         if chkpt_load_file is not None:
             self.load_checkpoint(chkpt_load_file)
@@ -175,16 +175,16 @@ class StandinTrainer:
 class HipTrainer(HotPath, StandinTrainer):
     def __init__(self, device, config, incremental=True, inv_bounds_transform=None, rng="philox",
                  seed=1, dist_group=None, fix_normal_window=False, fwd_operand="fp16x2", virtual_step_ms=None,
-                 engine_factory=None, overlap_allreduce=False, bwd_operand=None):
+                 engine_factory=None, overlap_allreduce=False, bwd_operand=None, spill_operand=None):
         """config: path to / dict with the reference's JSON schema (replicaCAD.json).
         rng: "philox" (in-kernel, no host sync) or "torch" (draw with torch in the
         reference's order and shapes -- parity mode, one host sync per step)."""
         self._hip = None
         StandinTrainer.__init__(self, device, config, None, incremental, inv_bounds_transform=inv_bounds_transform,
-                                fwd_operand=fwd_operand, engine_factory=engine_factory, bwd_operand=bwd_operand)
+                                fwd_operand=fwd_operand, engine_factory=engine_factory, bwd_operand=bwd_operand, spill_operand=spill_operand)
         graft(self, rng=rng, seed=seed, dist_group=dist_group, fix_normal_window=fix_normal_window,
               fwd_operand=fwd_operand, virtual_step_ms=virtual_step_ms, engine_factory=engine_factory,
-              overlap_allreduce=overlap_allreduce, bwd_operand=bwd_operand)
+              overlap_allreduce=overlap_allreduce, bwd_operand=bwd_operand, spill_operand=spill_operand)
 
     # aliases kept for checkpoint files / callers of round 1
     def state_dict(self):

@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # ISDF_HIP_LIB: development override (A/B variants and the instrumented build of tools/build_variants.py)
 LIB_PATH = os.environ.get("ISDF_HIP_LIB") or os.path.join(HERE, "libisdf_hip.so")
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 # every symbol include/isdf_hip.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
@@ -29,7 +29,7 @@ class NetCfg(C.Structure):
     _fields_ = [("hidden", C.c_int32), ("blocks", C.c_int32), ("n_freqs", C.c_int32),
                 ("has_transform", C.c_int32), ("scale_input", C.c_float),
                 ("scale_output", C.c_float), ("bounds_T", C.c_float * 12),
-                ("fwd_operand", C.c_int32), ("bwd_operand", C.c_int32)]
+                ("fwd_operand", C.c_int32), ("bwd_operand", C.c_int32), ("spill_operand", C.c_int32)]
 
 
 class SampleArgs(C.Structure):

@@ -164,11 +164,14 @@ __device__ __forceinline__ int frag16_off(int w, int fb, int pb, int qp, int lan
 // BW: operand type of the SECOND-order sweeps (adjoint, reverse) and of every spilled tensor (the dW kernel's operands) in train mode:
 // false = bf16 (rounds 1-3: range-safe whatever the loss adjoints' magnitude), true = fp16 (NetLayout::bwd_f16: the same packed weight
 // copies as the forward / first reverse sweeps, 11 instead of 8 significand bits in every dW operand -- DESIGN 5, round 4).
-template <int HD, int EP, int OPER, int MODE, bool BW = false>
+// SP8 (train mode with BW): P below the top layer and GB are spilled as e4m3 bytes instead of 16-bit values (NetLayout::sp8, SpillLayout).
+template <int HD, int EP, int OPER, int MODE, bool BW = false, int SP8 = 0>
 __global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 && EP == HD && !oper_x2_all(OPER) ? 4 : 2)) void chain_kernel(const ChainParams p) {
   typedef Tile<HD, EP, oper_x2_all(OPER)> T;
   constexpr bool F16 = oper_f16(OPER), X2 = oper_x2(OPER), X2ALL = oper_x2_all(OPER);
   static_assert(!BW || (F16 && MODE == 2), "fp16 second-order sweeps go with fp16 forward operands, train mode only");
+  static_assert(!SP8 || BW, "the e4m3 spill format is instantiated for the fp16 second-order sweeps");
+  constexpr bool G8 = SP8 & 1, P8 = SP8 & 2;     // GB / P (below the top layer) spilled as e4m3
   typedef typename Op<BW>::e spillT;   // element type of the spilled tensors
   static_assert(!X2ALL || (HD == 256 && EP == 256), "fp16x2_full: four operand regions only fit the <256, 256> tile");
   constexpr int LO = X2ALL ? (HD + EP) : HD;   // first column of the residual of the running activation (a_lo)
@@ -206,6 +209,11 @@ __global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 && EP == HD && !oper_x2_a
   const float so = L.scale_output;
   ChainStamps TS(p.dbg);   // phase time stamps of the -DISDF_DEBUG_HOOKS=1 build; empty inlines in the shipped kernel
   TS();
+  // MODE.FP16_OVFL (hwreg 1, bit 23): float -> e4m3 / fp16 conversions SATURATE instead of producing NaN / inf.  Without it
+  // v_cvt_scalef32_pk_fp8_f32 turns anything above 464 into NaN (tools/probes/fp8_cvt.hip); the e4m3 spill of P and GB below is
+  // scaled so that this does not happen at any magnitude measured (isdf_common.h), and an outlier then clips instead of poisoning
+  // the step.
+  if (SP8) __builtin_amdgcn_s_setreg(1 | (23 << 6), 1);
   // Issue priority between the two workgroups of a CU: with equal priority the OLDER workgroup's waves win
   // VALU/MFMA arbitration all the way, finish ~33 us early and leave the younger one to run the rest alone at the poor
   // single-workgroup rate.  The second workgroup of a CU (dispatch round blockIdx / #CUs odd -- the CU count of the device the
@@ -396,6 +404,38 @@ __global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 && EP == HD && !oper_x2_a
     const uint2 a = pack4<BW>(v[0], v[1], v[2], v[3]), b = pack4<BW>(v[4], v[5], v[6], v[7]);
     bstore16_nt<false>(make_uint4(a.x, a.y, b.x, b.y), srdS, lane16, sbase(tensorOff), cidx(fb, pb, qp));
   };
+  // ---- e4m3 spills of P and GB (SpillLayout): 16 bytes per lane = its 8 values of point block 0, then of point block 1.  Encode
+  // divides by `scale`, decode multiplies (v_cvt_scalef32_pk_fp8_f32 / _f32_fp8: one instruction per two values, the scale is free).
+  static_assert(PB == 2, "a frag8 piece holds the two point blocks of a tile");
+  struct Pre8 { uint4 v[FB][2]; };
+  auto sbase8 = [&](int64_t tensorOff) { return (int)(tensorOff * 2) + w * (FB * 2) * 1024; };
+  auto prefetch8 = [&](int64_t tensorOff, Pre8& pr) {
+    const int sb = sbase8(tensorOff);
+#pragma unroll
+    for (int fb = 0; fb < FB; ++fb)
+#pragma unroll
+      for (int qp = 0; qp < 2; ++qp)
+        pr.v[fb][qp] = bload16<kAuxNT>(rsS, lane16 + ((fb * 2 + qp) & 3) * 1024, sb + ((fb * 2 + qp) >> 2) * 4096);
+  };
+  auto load_f8 = [&](const Pre8& pr, int fb, int pb, int qp, float scale, float (&o)[8]) {
+    const uint4 u = pr.v[fb][qp];
+    const int lo = (int)(pb ? u.z : u.x), hi2 = (int)(pb ? u.w : u.y);
+    const f32x2 a = __builtin_amdgcn_cvt_scalef32_pk_f32_fp8(lo, scale, false), b = __builtin_amdgcn_cvt_scalef32_pk_f32_fp8(lo, scale, true);
+    const f32x2 c = __builtin_amdgcn_cvt_scalef32_pk_f32_fp8(hi2, scale, false), d = __builtin_amdgcn_cvt_scalef32_pk_f32_fp8(hi2, scale, true);
+    o[0] = a[0]; o[1] = a[1]; o[2] = b[0]; o[3] = b[1]; o[4] = c[0]; o[5] = c[1]; o[6] = d[0]; o[7] = d[1];
+  };
+  uint2 held8 = make_uint2(0u, 0u);   // point block 0's bytes of the piece being built (for_blocks visits pb = 0, 1 back to back)
+  auto store_f8 = [&](int64_t tensorOff, int fb, int pb, int qp, const float (&v)[8], float scale, auto nt) {
+    typedef short s16x2 __attribute__((ext_vector_type(2)));
+    s16x2 w0 = {0, 0}, w1 = {0, 0};
+    w0 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(w0, v[0], v[1], scale, false);
+    w0 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(w0, v[2], v[3], scale, true);
+    w1 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(w1, v[4], v[5], scale, false);
+    w1 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(w1, v[6], v[7], scale, true);
+    const uint32_t u0 = __builtin_bit_cast(uint32_t, w0), u1 = __builtin_bit_cast(uint32_t, w1);
+    if (pb == 0) held8 = make_uint2(u0, u1);
+    else bstore16_nt<decltype(nt)::value>(make_uint4(held8.x, held8.y, u0, u1), srdS, lane16, sbase8(tensorOff), fb * 2 + qp);
+  };
   // sigma'(z) of a layer for the backward epilogues, re-derived from the bf16 activation tile (no sigma' tensor is stored)
   auto load_s1 = [&](const Pre& pr, int fb, int pb, int qp, float (&o)[8]) {
     load_tile8(pr, fb, pb, qp, o);
@@ -519,7 +559,7 @@ __global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 && EP == HD && !oper_x2_a
         if (MODE >= 1) {
           store_tile8(p.sp.A[li + 1], fb, pb, qp, a);
           put_x(F16, fb, pb, qp, pl, 0);
-          if (MODE == 2) store_tile8(p.sp.P[li], fb, pb, qp, pl);
+          if (MODE == 2) store_tile8(p.sp.P[li], fb, pb, qp, pl);   // (the top layer's P stays 16-bit in either spill format: SpillLayout)
         }
       });
     }
@@ -572,7 +612,10 @@ __global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 && EP == HD && !oper_x2_a
       for (int e = 0; e < 8; ++e) pv[e] = acc[fb][pb][8 * qp + e] * a[e];
       put_x(F16, fb, pb, qp, pv, 0);
       if (toR2) put_x(F16, fb, pb, qp, pv, HD);
-      if (MODE == 2) store_tile8(p.sp.P[li - 1], fb, pb, qp, pv);
+      if (MODE == 2) {
+        if constexpr (P8) store_f8(p.sp.P[li - 1], fb, pb, qp, pv, kSpillPScale, std::true_type{});
+        else store_tile8(p.sp.P[li - 1], fb, pb, qp, pv);
+      }
     });
     TS();
     lds_barrier();
@@ -815,9 +858,17 @@ __global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 && EP == HD && !oper_x2_a
       gbs[tid * 4 + 3] = sbar * so;
       // what the dW kernel rebuilds its two embedding-shaped operands from (the embedding and Ebar = J_pe gbar): 6 floats per point
       // instead of 2 x EP 16-bit values.  Every row of the tile is written (rows past the last point: x' of the origin, gbar = 0).
+      // ... and the point's GB spill scale s_G = 2^k * (power of two above |gbar'|_inf) (SpillLayout): the adjoint sweep below
+      // encodes with it, the reverse sweep and the dW kernel decode with it
+      const float gmax = fmaxf(fmaxf(fabsf(gbs[tid * 4]), fabsf(gbs[tid * 4 + 1])), fabsf(gbs[tid * 4 + 2]));
+      const uint32_t ge = __float_as_uint(gmax) & 0x7f800000u;
+      // gbar = 0 (no eikonal / normal term at this point, or a padding row): GB is exactly 0 whatever the scale; subnormal or
+      // non-finite maxima get a harmless one as well
+      const float sG = (ge < (27u << 23) || ge >= (200u << 23)) ? 1.f : __uint_as_float(ge + ((uint32_t)(1 + spill_gb_shift(nf)) << 23));
+      xs[tid * 4 + 3] = sG;
       float4* aux = (float4*)(p.pe_aux + (n0 + tid) * 8);
       aux[0] = make_float4(xs[tid * 4], xs[tid * 4 + 1], xs[tid * 4 + 2], 0.f);
-      aux[1] = make_float4(gbs[tid * 4], gbs[tid * 4 + 1], gbs[tid * 4 + 2], 0.f);
+      aux[1] = make_float4(gbs[tid * 4], gbs[tid * 4 + 1], gbs[tid * 4 + 2], sG);
     }
   }
   if (MODE != 2) return;
@@ -934,7 +985,8 @@ __global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 && EP == HD && !oper_x2_a
 #pragma unroll
       for (int e = 0; e < 8; ++e) qb[e] = acc[fb][pb][8 * qp + e] * a[e];
       put_x(BW, fb, pb, qp, qb, 0);
-      store_tile8_dw(p.sp.GB[li + 1], fb, pb, qp, qb);
+      if constexpr (G8) store_f8(p.sp.GB[li + 1], fb, pb, qp, qb, xs[row * 4 + 3], std::false_type{});
+      else store_tile8_dw(p.sp.GB[li + 1], fb, pb, qp, qb);
       if (li == L.L - 2) park_tile8(fb, pb, qp, qb);   // the reverse sweep's FIRST unit needs it back three units from here
     });
     TS();
@@ -943,8 +995,8 @@ __global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 && EP == HD && !oper_x2_a
   }
   {   // top layer (peeled: its three partial-sum streams must not raise the register pressure of the loop above)
     const int li = L.L - 1;
-    Pre preA, preP;
-    adj_gemm(li, [&] { prefetch(p.sp.A[li + 1], preA); prefetch(p.sp.P[li], preP); });
+    Pre preA;
+    adj_gemm(li, [&] { prefetch(p.sp.A[li + 1], preA); });
     TS();
     lds_barrier();
     TS();
@@ -958,16 +1010,16 @@ __global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 && EP == HD && !oper_x2_a
         const float4 w0 = *(const float4*)(part + f0), w1 = *(const float4*)(part + f0 + 8);
         wv[0] = w0.x; wv[1] = w0.y; wv[2] = w0.z; wv[3] = w0.w; wv[4] = w1.x; wv[5] = w1.y; wv[6] = w1.z; wv[7] = w1.w;
       }
-      float a[8], pv[8], zb[8];
+      float a[8], zb[8];
       load_tile8(preA, fb, pb, qp, a);
-      load_tile8(preP, fb, pb, qp, pv);
       const float sb = gbs[row * 4 + 3];
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const float u = acc[fb][pb][8 * qp + e];
         const float t1 = __builtin_amdgcn_exp2f(-kC1 * a[e]), s1 = 1.f - t1;    // sigma' and 1 - sigma' = exp(-beta a)
         qsum[e] += u * s1;
-        zb[e] = sb * wv[e] * s1 + kBeta * u * pv[e] * t1;
+        // p_L = q_L sigma' = so w_out sigma' rebuilt here (until round 5 it was re-read: it is an e4m3 tensor now, and this is exact)
+        zb[e] = sb * wv[e] * s1 + kBeta * u * (so * wv[e] * s1) * t1;
         bsum[e] += zb[e];
         wsum[e] += sb * a[e];
       }
@@ -990,13 +1042,17 @@ __global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 && EP == HD && !oper_x2_a
   // ------------------------------------------------------------------ ordinary reverse sweep with injection
   PRIO(3);
   for (int li = L.L - 2; li >= 0; --li) {
-    Pre preA, preG, preP;
+    Pre preA;
+    typename std::conditional<G8, Pre8, Pre>::type preG;
+    typename std::conditional<P8, Pre8, Pre>::type preP;
     refresh();
     gemm<BW, HD / 16, FB, PB, ROWB, T::CKF, true>(acc, wq, rsW, wptr(BW ? setBwdA : setBwdB, L.bwdMat[li + 1], HD), X, 0, lane,
                                                [&] {
                                                  prefetch(p.sp.A[li + 1], preA);
-                                                 if (li != L.L - 2) prefetch(p.sp.GB[li + 1], preG);   // the top one is parked in the tile
-                                                 prefetch(p.sp.P[li], preP);
+                                                 if (li != L.L - 2) {                     // the top one is parked in the tile
+                                                   if constexpr (G8) prefetch8(p.sp.GB[li + 1], preG); else prefetch(p.sp.GB[li + 1], preG);
+                                                 }
+                                                 if constexpr (P8) prefetch8(p.sp.P[li], preP); else prefetch(p.sp.P[li], preP);
                                                });
     TS();
     lds_barrier();
@@ -1008,9 +1064,19 @@ __global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 && EP == HD && !oper_x2_a
     for_blocks2([&](int fb, int pb, int qp, int row) {
       float a[8], t1[8], gq[8], pv[8], zb[8];
       load_s1t(preA, fb, pb, qp, a, t1);   // a[] = sigma', t1[] = 1 - sigma' = exp(-beta a)
-      if (li == L.L - 2) preG.v[fb][qp][pb] = *(const uint4*)(X + park_addr(cidx(fb, pb, qp)));
-      load_tile8(preG, fb, pb, qp, gq);
-      load_tile8(preP, fb, pb, qp, pv);
+      if constexpr (G8) {
+        if (li == L.L - 2) {               // parked by the adjoint sweep in the 16-bit spill type
+          Pre pk;
+          pk.v[fb][qp][pb] = *(const uint4*)(X + park_addr(cidx(fb, pb, qp)));
+          load_tile8(pk, fb, pb, qp, gq);
+        } else {
+          load_f8(preG, fb, pb, qp, xs[row * 4 + 3], gq);
+        }
+      } else {
+        if (li == L.L - 2) preG.v[fb][qp][pb] = *(const uint4*)(X + park_addr(cidx(fb, pb, qp)));
+        load_tile8(preG, fb, pb, qp, gq);
+      }
+      if constexpr (P8) load_f8(preP, fb, pb, qp, kSpillPScale, pv); else load_tile8(preP, fb, pb, qp, pv);
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const float s1 = a[e];
@@ -1036,12 +1102,17 @@ __global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 && EP == HD && !oper_x2_a
 }
 
 // ---------------------------------------------------------------------------
-template <int HD, int EP, int OPER, int MODE, bool BW = false>
+template <int HD, int EP, int OPER, int MODE, bool BW = false, int SP8 = 0>
 static int launch_one(const ChainParams& p, int64_t nTiles, hipStream_t st) {
   typedef Tile<HD, EP, oper_x2_all(OPER)> T;
   if constexpr (!BW && MODE == 2 && oper_f16(OPER))
     if (p.lay.bwd_f16) return launch_one<HD, EP, OPER, MODE, true>(p, nTiles, st);
-  auto k = chain_kernel<HD, EP, OPER, MODE, BW>;
+  if constexpr (BW && !SP8) {
+    if (p.lay.sp8 == 3) return launch_one<HD, EP, OPER, MODE, true, 3>(p, nTiles, st);
+    if (p.lay.sp8 == 1) return launch_one<HD, EP, OPER, MODE, true, 1>(p, nTiles, st);
+  }
+  if (MODE == 2 && p.lay.sp8 != SP8) return ISDF_EUNSUPPORTED;
+  auto k = chain_kernel<HD, EP, OPER, MODE, BW, SP8>;
   if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES) != hipSuccess) return ISDF_EHIP;
   hipLaunchKernelGGL(k, dim3((unsigned)nTiles), dim3(T::NW * 64), T::LDS_BYTES, st, p);
   return isdf_launch_status();

@@ -56,7 +56,9 @@ __device__ __forceinline__ int frag16_piece(int c, int half, int sl, int& pt, in
 // fixed for the whole kernel) and walks 16 points.  The arithmetic is the chain kernel's PE / Ebar stage value for value
 // (same expression shapes, `fr` a power of two), so the operand bits equal what that kernel used to spill.  4 of the 28 tensor
 // reads of a step and 2 of the chain kernel's 25 tensor stores are gone (82 MB of 1.245 GB per 27 k-point step).
-template <int HD, bool F16>
+// SP8: NetLayout::sp8 (bit 0: GB spilled as e4m3, bit 1: P below the top layer) -- a launch constant, so the format of every stage is
+// known at compile time and the register sets are sized for it (the kernel sits at the 256-register limit).
+template <int HD, bool F16, int SP8>
 __global__ __launch_bounds__(512, 2) void dw_kernel(const DwParams p) {
   typedef DwTile<HD> T;
   constexpr int BM = T::BM, ROWB = T::ROWB, CH = T::CH;
@@ -82,10 +84,13 @@ __global__ __launch_bounds__(512, 2) void dw_kernel(const DwParams p) {
   constexpr int HALVES = TILE_PTS / DW_PTS;
   const int nTiles = (int)((P + TILE_PTS - 1) / TILE_PTS) * HALVES;   // 64-point half tiles
 
-  // stage q of tile t: q=0 -> (ZB[li], I), q=1 -> (P[li], GB)
+  // stage q of tile t: q=0 -> (ZB[li], I), q=1 -> (P[li], GB).  Stage parity = q = register set = LDS buffer: the even stages'
+  // operands are 16-bit tiles (4 x 16 B per thread and tensor), the odd stages' are e4m3 (2 x 16 B; SpillLayout), converted to the
+  // 16-bit MFMA operand type on their way into LDS -- P times 2^-10, GB times the point's scale s_G (pe_aux[7]).
   const int64_t offZ = p.sp.ZB[li], offP = p.sp.P[li];
   const int64_t offI = fromEmb ? 0 : p.sp.A[li];
   const int64_t offG = fromEmb ? 0 : p.sp.GB[li];
+  constexpr int CH8 = CH / 2;
 
   f32x16 acc[2][4];
 #pragma unroll
@@ -132,27 +137,57 @@ __global__ __launch_bounds__(512, 2) void dw_kernel(const DwParams p) {
   };
 
   // The stage pipeline, once per kind of unit (PE: the input-side operand is rebuilt from pe_aux, not loaded).
-  auto run = [&](auto pe_tag) {
+  auto run = [&](auto pe_tag, auto p8_tag) {
     constexpr bool PE = decltype(pe_tag)::value;
+    constexpr bool p8 = decltype(p8_tag)::value, g8 = SP8 & 1;     // this unit's P / GB are e4m3 tensors
+    constexpr int CHA1 = p8 ? CH8 : CH, CHB1 = g8 ? CH8 : CH;
     // Two register sets so TWO stages of global loads are in flight while one is computed
     // (HBM-bound kernel: 64 KB per stage and CU; one stage in flight left ~40 % of the bandwidth unused).
-    uint4 regA0[CH], regB0[CH], regA1[CH], regB1[CH];
+    uint4 regA0[CH], regB0[CH], regA1[CHA1], regB1[CHB1];
+    float sG1[2] = {1.f, 1.f};        // s_G of this thread's two points (rows lane & 31 and 32 + (lane & 31)) of the odd stage in flight
     typedef unsigned int u32x4n __attribute__((ext_vector_type(4)));
-    auto issue = [&](int st, uint4 (&ra)[CH], uint4 (&rb)[CH]) {
-      const int u = split + (st >> 1) * DW_SPLITK;      // half-tile index
-      const int t = u / HALVES, half = u % HALVES;
-      const uint4* ta = (const uint4*)(p.spill + ((st & 1) ? offP : offZ) + (int64_t)t * p.sp.tileStride);
-      const uint4* tb = (const uint4*)(p.spill + ((st & 1) ? offG : offI) + (int64_t)t * p.sp.tileStride);
+    auto ntload = [](const uint4* q) {
+      const u32x4n v = __builtin_nontemporal_load((const u32x4n*)q);
+      return make_uint4(v[0], v[1], v[2], v[3]);
+    };
+    auto issue0 = [&](int st) {        // even stage: ZB and the layer input, 16-bit
+      const int t = split + (st >> 1) * DW_SPLITK;
+      const uint4* ta = (const uint4*)(p.spill + offZ + (int64_t)t * p.sp.tileStride);
+      const uint4* tb = (const uint4*)(p.spill + offI + (int64_t)t * p.sp.tileStride);
 #pragma unroll
       for (int c = 0; c < CH; ++c) {
         int pt, f0;
-        const u32x4n va = __builtin_nontemporal_load((const u32x4n*)(ta + frag16_piece(c * 512 + tid, half, slA, pt, f0)));
-        ra[c] = make_uint4(va[0], va[1], va[2], va[3]);
-        if constexpr (!PE) {
-          const u32x4n vb = __builtin_nontemporal_load((const u32x4n*)(tb + frag16_piece(c * 512 + tid, half, slB, pt, f0)));
-          rb[c] = make_uint4(vb[0], vb[1], vb[2], vb[3]);
+        regA0[c] = ntload(ta + frag16_piece(c * 512 + tid, 0, slA, pt, f0));
+        if constexpr (!PE) regB0[c] = ntload(tb + frag16_piece(c * 512 + tid, 0, slB, pt, f0));
+      }
+    };
+    auto issue1 = [&](int st) {        // odd stage: P and GB -- e4m3 (frag8 pieces: 16 B = a lane's 8 values of both point blocks) or 16-bit
+      const int t = split + (st >> 1) * DW_SPLITK;
+      const uint4* ta = (const uint4*)(p.spill + offP + (int64_t)t * p.sp.tileStride);
+      const uint4* tb = (const uint4*)(p.spill + offG + (int64_t)t * p.sp.tileStride);
+      if constexpr (p8) {
+#pragma unroll
+        for (int c = 0; c < CH8; ++c) regA1[c] = ntload(ta + (slA * 16 + ((c * 512 + tid) >> 6)) * 64 + (tid & 63));
+      } else {
+#pragma unroll
+        for (int c = 0; c < CH; ++c) { int pt, f0; regA1[c] = ntload(ta + frag16_piece(c * 512 + tid, 0, slA, pt, f0)); }
+      }
+      if constexpr (!PE) {
+        if constexpr (g8) {
+#pragma unroll
+          for (int c = 0; c < CH8; ++c) regB1[c] = ntload(tb + (slB * 16 + ((c * 512 + tid) >> 6)) * 64 + (tid & 63));
+          const float* aux = p.pe_aux + ((int64_t)t * BM + (tid & 31)) * 8 + 7;
+          sG1[0] = aux[0]; sG1[1] = aux[32 * 8];
+        } else {
+#pragma unroll
+          for (int c = 0; c < CH; ++c) { int pt, f0; regB1[c] = ntload(tb + frag16_piece(c * 512 + tid, 0, slB, pt, f0)); }
         }
       }
+    };
+    // two e4m3 values of a dword -> two 16-bit operand values, times `scale`
+    auto cvt2 = [](uint32_t w8, float scale, auto hiTag) -> uint32_t {
+      if constexpr (F16) return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp8((int)w8, scale, decltype(hiTag)::value));
+      else return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8((int)w8, scale, decltype(hiTag)::value));
     };
     // ---- PE units: a thread owns up to three (point, direction) ITEMS of a 64-point tile -- item = tid + 512 r, point = item / 21,
     // direction = item % 21, the same for every stage -- and writes the direction's 2 n_freqs columns: sin / cos of octave 0 from the
@@ -179,20 +214,37 @@ __global__ __launch_bounds__(512, 2) void dw_kernel(const DwParams p) {
     auto store_aux = [&](int k) {
       if (tid < 128) *(float4*)(smem + 4 * T::TEN + (k & 1) * T::AUXB + tid * 16) = auxr;
     };
-    auto commit = [&](int st, const uint4 (&ra)[CH], const uint4 (&rb)[CH], int buf) {
-      char* sb = smem + buf * 2 * T::TEN;
+    auto put16 = [&](char* tile, const auto& r) {      // a 16-bit operand slice: frag16 pieces -> row-major LDS tile
 #pragma unroll
       for (int c = 0; c < CH; ++c) {
         int pt, f0;
         frag16_piece(c * 512 + tid, 0, 0, pt, f0);
-        char* pa = sb + pt * ROWB + f0 * 2;
-        *(uint2*)(pa) = make_uint2(ra[c].x, ra[c].y);
-        *(uint2*)(pa + 16) = make_uint2(ra[c].z, ra[c].w);
-        if constexpr (!PE) {
-          char* pb = sb + T::TEN + pt * ROWB + f0 * 2;
-          *(uint2*)(pb) = make_uint2(rb[c].x, rb[c].y);
-          *(uint2*)(pb + 16) = make_uint2(rb[c].z, rb[c].w);
-        }
+        char* pa = tile + pt * ROWB + f0 * 2;
+        *(uint2*)(pa) = make_uint2(r[c].x, r[c].y);
+        *(uint2*)(pa + 16) = make_uint2(r[c].z, r[c].w);
+      }
+    };
+    auto put8 = [&](char* tile, const auto& r, float s0, float s1) {   // an e4m3 slice, converted; s0 / s1: the scales of the lane's two points
+#pragma unroll
+      for (int c = 0; c < CH8; ++c) {
+        const int idx = c * 512 + tid, ln = idx & 63, rr = idx >> 6;
+        const int f0 = (rr >> 1) * 32 + 16 * (rr & 1) + 4 * (ln >> 5);       // elems 0..3 at features f0.., 4..7 at f0 + 8..
+        char* pa = tile + (ln & 31) * ROWB + f0 * 2;
+        const uint4 a = r[c];
+        *(uint2*)(pa) = make_uint2(cvt2(a.x, s0, std::false_type{}), cvt2(a.x, s0, std::true_type{}));
+        *(uint2*)(pa + 16) = make_uint2(cvt2(a.y, s0, std::false_type{}), cvt2(a.y, s0, std::true_type{}));
+        *(uint2*)(pa + 32 * ROWB) = make_uint2(cvt2(a.z, s1, std::false_type{}), cvt2(a.z, s1, std::true_type{}));
+        *(uint2*)(pa + 32 * ROWB + 16) = make_uint2(cvt2(a.w, s1, std::false_type{}), cvt2(a.w, s1, std::true_type{}));
+      }
+    };
+    auto commit = [&](int st, int buf) {
+      char* sb = smem + buf * 2 * T::TEN;
+      if ((st & 1) == 0) {
+        put16(sb, regA0);
+        if constexpr (!PE) put16(sb + T::TEN, regB0);
+      } else {
+        if constexpr (p8) put8(sb, regA1, kSpillPScale, kSpillPScale); else put16(sb, regA1);
+        if constexpr (!PE) { if constexpr (g8) put8(sb + T::TEN, regB1, sG1[0], sG1[1]); else put16(sb + T::TEN, regB1); }
       }
       if constexpr (PE) {
         // q = 0: the embedding (embedding.py:95-111): [x' | sin(xb_df) | cos(xb_df)], xb_df = (x' . dir_d) 2^f
@@ -274,11 +326,11 @@ __global__ __launch_bounds__(512, 2) void dw_kernel(const DwParams p) {
     if constexpr (PE) {
       load_aux(0); store_aux(0); load_aux(1);
     }
-    if (nStages > 0) { issue(0, regA0, regB0); }
-    if (nStages > 1) { issue(1, regA1, regB1); }
+    if (nStages > 0) { issue0(0); }
+    if (nStages > 1) { issue1(1); }
     if constexpr (PE) __syncthreads();          // tile 0's pe_aux rows are in LDS
-    if (nStages > 0) commit(0, regA0, regB0, 0);
-    if (nStages > 2) issue(2, regA0, regB0);
+    if (nStages > 0) commit(0, 0);
+    if (nStages > 2) issue0(2);
     __syncthreads();
 
     // Stage st sits in LDS buffer (st&1).  Each iteration first writes stage st+1 (loads issued two
@@ -287,20 +339,23 @@ __global__ __launch_bounds__(512, 2) void dw_kernel(const DwParams p) {
     // (PE units: the pe_aux rows of the NEXT tile go to LDS in the first half, a barrier ahead of the commit that reads them.)
     for (int st = 0; st < nStages; st += 2) {
       if (st + 1 < nStages) {
-        commit(st + 1, regA1, regB1, 1);
+        commit(st + 1, 1);
         if constexpr (PE) { store_aux((st >> 1) + 1); load_aux((st >> 1) + 2); }
-        if (st + 3 < nStages) issue(st + 3, regA1, regB1);
+        if (st + 3 < nStages) issue1(st + 3);
       }
       compute(0);
       __syncthreads();
       if (st + 1 < nStages) {
-        if (st + 2 < nStages) { commit(st + 2, regA0, regB0, 0); if (st + 4 < nStages) issue(st + 4, regA0, regB0); }
+        if (st + 2 < nStages) { commit(st + 2, 0); if (st + 4 < nStages) issue0(st + 4); }
         compute(1);
         __syncthreads();
       }
     }
   };
-  if (fromEmb) run(std::true_type{}); else run(std::false_type{});
+  typedef std::integral_constant<bool, (SP8 & 2) != 0> P8T;
+  if (fromEmb) run(std::true_type{}, P8T{});
+  else if ((SP8 & 2) && li == L.L - 1) run(std::false_type{}, std::false_type{});      // the top layer's P stays 16-bit (SpillLayout)
+  else run(std::false_type{}, P8T{});
 
   // partial slab [o][i]
   slab_t* slab = (slab_t*)p.dwPart + ((int64_t)dw_slab_base(L, unit) + split) * DW_BLK * DW_BLK;
@@ -327,8 +382,15 @@ int launch_dw(const DwParams& p, hipStream_t st) {
     hipLaunchKernelGGL(k, grid, block, T::LDS_BYTES, st, p);
     return isdf_launch_status();
   };
-  if (p.lay.HD == 256) return p.lay.bwd_f16 ? go(dw_kernel<256, true>) : go(dw_kernel<256, false>);
-  return p.lay.bwd_f16 ? go(dw_kernel<512, true>) : go(dw_kernel<512, false>);
+  if (p.lay.sp8 && !p.lay.bwd_f16) return ISDF_EUNSUPPORTED;
+  if (p.lay.HD == 256) {
+    if (p.lay.sp8 == 3) return go(dw_kernel<256, true, 3>);
+    if (p.lay.sp8 == 1) return go(dw_kernel<256, true, 1>);
+    return p.lay.bwd_f16 ? go(dw_kernel<256, true, 0>) : go(dw_kernel<256, false, 0>);
+  }
+  if (p.lay.sp8 == 3) return go(dw_kernel<512, true, 3>);
+  if (p.lay.sp8 == 1) return go(dw_kernel<512, true, 1>);
+  return p.lay.bwd_f16 ? go(dw_kernel<512, true, 0>) : go(dw_kernel<512, false, 0>);
 }
 
 }  // namespace isdf

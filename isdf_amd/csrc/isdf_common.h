@@ -41,6 +41,7 @@ struct NetLayout {
   int fwd_x2_all;             // 1: "fp16x2_full" -- EVERY forward layer is compensated (weights and inputs, embedding included): the
                                //    exact-forward instrument, sdf ~1e-6 of the fp32 reference; <256, 256> nets only
   int bwd_f16;                // 1: the second-order sweeps and every spilled dW operand in fp16 instead of bf16 (needs fwd_f16)
+  int sp8;                    // e4m3 spills (isdf_net_cfg.spill_operand; SpillLayout): bit 0 = GB, bit 1 = P below the top layer
   int has_transform;
   float scale_input, scale_output;
   float T[12];
@@ -58,9 +59,17 @@ struct NetLayout {
   int64_t shadowElems;
 };
 
-// Spill tensors written by the chain kernel and read by the dW kernel.  One
-// tensor = nTiles * TILE_PTS * HD 16-bit elements in "frag16" order (see
-// chain.hip): bf16, or fp16 with NetLayout::bwd_f16.
+// Spill tensors written by the chain kernel and read by the dW kernel.  A[] and ZB[]: nTiles * TILE_PTS * HD 16-bit elements
+// each in "frag16" order (see chain.hip): bf16, or fp16 with NetLayout::bwd_f16.  P[] (below the top layer) and GB[] likewise, or --
+// with NetLayout::sp8, round 6 -- ONE BYTE per element, OCP e4m3: P / 2^-10, and GB / s_G[point] with s_G = 2^k * (the power of two above the point's |gbar|_inf in x' space),
+// k = spill_gb_shift(): GB is linear in the point's loss adjoint gbar, so the per-point scale takes the loss's magnitude out of the
+// format and what is left is bounded by the network (measured: |GB| / 2^ceil(log2 |gbar|) <= 153 at six octaves, 1 230 at eleven).
+// A tile's e4m3 tensor is TILE_PTS * HD bytes in "frag8" order: piece ((w * FB + fb) * 2 + qp) * 64 + lane = 16 bytes = the lane's
+// 8 values of point block 0, then of point block 1.  The second-order product P^T GB carries the eikonal / normal terms' share of the
+// gradient (weights 0.268 / 0.018 upstream): e4m3's 2^-4 on it moves the worst weight gradient from 1.29e-3 to 1.46e-3 of the
+// reference's (tools/studies/spill_format_study.py), whereas A or ZB in e4m3 would cost 3.4e-3 / 3.9e-3.  All offsets below are in
+// 16-bit units (an e4m3 tensor takes tensorElems / 2 of them).
+constexpr float kSpillPScale = 1.f / 1024.f;      // P is stored as e4m3(P / kSpillPScale): |P| <= 0.2 measured (trained nets), e4m3 holds 448
 struct SpillLayout {
   int64_t tensorElems;   // per tensor per tile (TILE_PTS * HD); the buffer is [tile][tensor][tensorElems]
   int64_t tileStride;    // elements between consecutive tiles (= tensor count * tensorElems)
@@ -104,6 +113,12 @@ inline int isdf_launch_status() {
 
 inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
+// k of the GB spill scale s_G = 2^k * pow2ceil(|gbar'|_inf): the positional encoding amplifies the adjoint by up to 2^(n_freqs - 1).
+// Measured |GB| / pow2ceil(|gbar'|_inf): <= 40 (random init) .. 153 (trained) at six octaves, 1 230 at eleven: k puts that at ~300 of
+// e4m3's 448 -- the large entries carry the contraction, and every binade of unused headroom pushes the small ones into e4m3's
+// subnormals (the first version ran three binades lower and perturbed the gradients 2.4 x more than the format has to).
+__host__ __device__ inline int spill_gb_shift(int n_freqs) { return n_freqs > 6 ? n_freqs - 7 : -1; }
+
 inline int make_layout(const isdf_net_cfg* c, NetLayout* l) {
   if (!c || !l) return ISDF_EINVAL;
   if (c->blocks < 1 || 2 * c->blocks + 2 > MAXL || c->n_freqs < 1 || c->hidden < 1) return ISDF_EINVAL;
@@ -120,6 +135,10 @@ inline int make_layout(const isdf_net_cfg* c, NetLayout* l) {
   l->fwd_x2_all = c->fwd_operand == 3 ? 1 : 0;
   if (c->bwd_operand < 0 || c->bwd_operand > 1 || (c->bwd_operand == 1 && !l->fwd_f16)) return ISDF_EINVAL;
   l->bwd_f16 = c->bwd_operand;
+  if (c->spill_operand < 0 || c->spill_operand > 3 || (c->spill_operand >= 2 && !l->bwd_f16)) return ISDF_EINVAL;
+  // auto: e4m3 where it is (nearly) free -- up to six octaves the second-order product P^T GB is a small share of every layer's
+  // gradient; the positional encoding amplifies it by 2^(n_freqs - 1), and from nine octaves on e4m3's 2^-4 shows
+  l->sp8 = c->spill_operand == 2 ? 3 : c->spill_operand == 3 ? 1 : (c->spill_operand == 0 && l->bwd_f16 && c->n_freqs <= 6) ? 3 : 0;
   l->has_transform = c->has_transform;
   l->scale_input = c->scale_input; l->scale_output = c->scale_output;
   for (int i = 0; i < 12; ++i) l->T[i] = c->has_transform ? c->bounds_T[i] : (i % 5 == 0 ? 1.f : 0.f);
@@ -199,9 +218,11 @@ inline void make_workspace(const NetLayout& l, int64_t maxPts, int64_t maxRays, 
   s.A[0] = -1;                                // embedding-shaped operands are rebuilt by the dW kernel (offPeAux), not stored
   for (int i = 1; i <= l.L; ++i) { s.A[i] = o; o += s.tensorElems; }
   if (train) {
-    for (int i = 0; i < l.L; ++i) { s.P[i] = o; o += s.tensorElems; }
+    // e4m3 (NetLayout::sp8): one byte per element; the TOP layer's P stays 16-bit (p_L = so w_out[o] sigma' is a per-column constant
+    // times sigma': its e4m3 rounding error is the same for every saturated point and does not average out over the batch)
+    for (int i = 0; i < l.L; ++i) { s.P[i] = o; o += ((l.sp8 & 2) && i < l.L - 1) ? s.tensorElems / 2 : s.tensorElems; }
     s.GB[0] = -1;
-    for (int i = 1; i < l.L; ++i) { s.GB[i] = o; o += s.tensorElems; }
+    for (int i = 1; i < l.L; ++i) { s.GB[i] = o; o += (l.sp8 & 1) ? s.tensorElems / 2 : s.tensorElems; }
     for (int i = 0; i < l.L; ++i) { s.ZB[i] = o; o += s.tensorElems; }
   }
   s.tileStride = o;

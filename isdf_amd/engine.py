@@ -39,6 +39,9 @@ class NetConfig:
     #   "fp16" (default with an fp16-family forward) or "bf16" (range-safe for any loss-adjoint magnitude; the only choice with
     #   fwd_operand "bf16").  None = the default for the forward mode.
     bwd_operand: Optional[str] = None
+    # storage of the spilled P / GB tensors (include/isdf_hip.h `spill_operand`): None = auto (e4m3 bytes when n_freqs <= 6 with fp16
+    # second-order sweeps, i.e. replicaCAD.json / scanNet.json; 16-bit otherwise), "16bit", or "e4m3" (forced)
+    spill_operand: Optional[str] = None
 
     @property
     def emb(self):
@@ -74,6 +77,9 @@ class NetConfig:
         if bwd not in ("bf16", "fp16") or (bwd == "fp16" and self.fwd_operand == "bf16"):
             raise ValueError("bwd_operand must be 'bf16' or 'fp16' (fp16 needs an fp16-family fwd_operand)")
         c.bwd_operand = 1 if bwd == "fp16" else 0
+        if self.spill_operand not in (None, "auto", "16bit", "e4m3", "e4m3_gb"):
+            raise ValueError("spill_operand must be None / 'auto', '16bit', 'e4m3' or 'e4m3_gb'")
+        c.spill_operand = {None: 0, "auto": 0, "16bit": 1, "e4m3": 2, "e4m3_gb": 3}[self.spill_operand]
         return c
 
 

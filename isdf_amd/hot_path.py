@@ -600,7 +600,7 @@ def can_graft(trainer):
 
 
 def graft(trainer, rng="philox", seed=1, dist_group=None, fix_normal_window=False, fwd_operand="fp16x2",
-          fuse_optimiser=True, virtual_step_ms=None, engine_factory=None, overlap_allreduce=False, bwd_operand=None):
+          fuse_optimiser=True, virtual_step_ms=None, engine_factory=None, overlap_allreduce=False, bwd_operand=None, spill_operand=None):
     """Re-bind the hot path of `trainer` (an `isdf.modules.trainer.Trainer` or a `StandinTrainer`) to the HIP
     kernels, IN PLACE, and return it.
 
@@ -611,6 +611,7 @@ def graft(trainer, rng="philox", seed=1, dist_group=None, fix_normal_window=Fals
     virtual_step_ms: if set, the virtual clock advances by this much per step instead of the measured step time
          (the frame schedule is a function of measured time, trainer.py:100-101,1011-1013; pin it to compare runs).
     bwd_operand: "fp16" | "bf16" | None (default for the forward mode): operand / spill type of the second-order sweeps and dW.
+    spill_operand: None (auto) | "16bit" | "e4m3": storage of the spilled P / GB tensors (engine.NetConfig.spill_operand).
     overlap_allreduce: data parallel only -- the closing reduction in two launches and the all-reduce in two parts, the first
          one on a side stream beside the second launch (dp.allreduce_split_); two collectives per step instead of one.
     engine_factory: tests only (a stand-in engine for hosts without a GPU)."""
@@ -642,7 +643,7 @@ def graft(trainer, rng="philox", seed=1, dist_group=None, fix_normal_window=Fals
         with torch.random.fork_rng(devices=[]):    # grafting mid-run must not advance the caller's generator: the initial
             new = SDFMapHIP(pe, hidden_size=hidden, hidden_layers_block=n_block, scale_output=old.scale_output,   # weights
                             device=dev, fwd_operand=fwd_operand, engine_factory=engine_factory,    # are overwritten below
-                            bwd_operand=bwd_operand)
+                            bwd_operand=bwd_operand, spill_operand=spill_operand)
         new.load_state_dict({k: v.detach() for k, v in old.state_dict().items()})
         new.train(old.training)
         trainer.sdf_map = new

@@ -35,7 +35,7 @@ def _fc_block(in_f, out_f):
 
 class SDFMapHIP(nn.Module):
     def __init__(self, positional_encoding, hidden_size=256, hidden_layers_block=1, scale_output=1.0,
-                 device="cuda", fwd_operand="fp16x2", engine_factory=None, bwd_operand=None):
+                 device="cuda", fwd_operand="fp16x2", engine_factory=None, bwd_operand=None, spill_operand=None):
         super().__init__()
         object.__setattr__(self, "_engine_factory", engine_factory)
         self.scale_output = scale_output
@@ -61,7 +61,7 @@ class SDFMapHIP(nn.Module):
         net = NetConfig(hidden=hidden_size, blocks=hidden_layers_block, n_freqs=positional_encoding.n_freqs,
                         scale_input=positional_encoding.scale, scale_output=scale_output,
                         transform=None if T is None else np.asarray(T, np.float32), fwd_operand=fwd_operand,
-                        bwd_operand=bwd_operand)
+                        bwd_operand=bwd_operand, spill_operand=spill_operand)
         make = Engine if engine_factory is None else engine_factory          # engine_factory: host-logic tests only
         object.__setattr__(self, "engine", make(net, device))   # not a submodule / not in state_dict
         self._bind()
@@ -98,7 +98,7 @@ class SDFMapHIP(nn.Module):
         with torch.random.fork_rng(devices=[]):    # the throw-away initial weights must not advance the caller's generator
             new = SDFMapHIP(pe, self.engine.net.hidden, self.engine.net.blocks, self.scale_output,   # (upstream's deepcopy
                             device=self.engine.device, fwd_operand=self.engine.net.fwd_operand,      # draws nothing)
-                            bwd_operand=self.engine.net.bwd_operand,
+                            bwd_operand=self.engine.net.bwd_operand, spill_operand=getattr(self.engine.net, "spill_operand", None),
                             engine_factory=self._engine_factory)
         new.engine.params.copy_(self.engine.params)
         new.engine.pack()

@@ -98,7 +98,7 @@ def test_ctypes_structs_match_the_header_layout(tmp_path):
     structs = {"isdf_net_cfg": _ffi.NetCfg, "isdf_sample_args": _ffi.SampleArgs, "isdf_sample_out": _ffi.SampleOut,
                "isdf_loss_cfg": _ffi.LossCfg, "isdf_step_args": _ffi.StepArgs, "isdf_step_out": _ffi.StepOut,
                "isdf_optim_args": _ffi.OptimArgs}
-    last = {"isdf_net_cfg": "bwd_operand", "isdf_sample_args": "n_inline", "isdf_sample_out": "pc", "isdf_loss_cfg": "orien_loss",
+    last = {"isdf_net_cfg": "spill_operand", "isdf_sample_args": "n_inline", "isdf_sample_out": "pc", "isdf_loss_cfg": "orien_loss",
             "isdf_step_args": "extra_value", "isdf_step_out": "split_event", "isdf_optim_args": "frame_avg_inline_n"}
     src = ['#include <stdio.h>', '#include <stddef.h>', '#include "isdf_hip.h"', 'int main(void) {']
     for name in structs:

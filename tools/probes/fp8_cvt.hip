@@ -8,7 +8,10 @@
 #include <cmath>
 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 typedef float f2 __attribute__((ext_vector_type(2)));
+template <bool OVFL>
 __global__ void k(const float* in, int* out, float* back, float* hb, float* encs, float* decs, float sc, int n) {
+  // MODE.FP16_OVFL (bit 23 of hwreg 1): does it turn the conversions' overflow -> NaN into saturation?
+  if (OVFL) __builtin_amdgcn_s_setreg(1 | (23 << 6) | (0 << 11), 1);
   int i = threadIdx.x;
   if (i >= n) return;
   int w = __builtin_amdgcn_cvt_pk_fp8_f32(in[2 * i], in[2 * i + 1], 0, false);
@@ -33,11 +36,15 @@ int main() {
   float *din, *dback, *dhb, *denc, *ddec; int* dout;
   hipMalloc(&din, n2 * 4); hipMalloc(&dback, n2 * 4); hipMalloc(&dhb, n2 * 4); hipMalloc(&dout, n * 4); hipMalloc(&denc, n2 * 4); hipMalloc(&ddec, n2 * 4);
   hipMemcpy(din, vals, n2 * 4, hipMemcpyHostToDevice);
-  hipLaunchKernelGGL(k, dim3(1), dim3(64), 0, 0, din, dout, dback, dhb, denc, ddec, 0.25f, n);
+  for (int pass = 0; pass < 2; ++pass) {
+  printf("---- MODE.FP16_OVFL = %d\n", pass);
+  if (pass == 0) hipLaunchKernelGGL(k<false>, dim3(1), dim3(64), 0, 0, din, dout, dback, dhb, denc, ddec, 0.25f, n);
+  else hipLaunchKernelGGL(k<true>, dim3(1), dim3(64), 0, 0, din, dout, dback, dhb, denc, ddec, 0.25f, n);
   float back[64], hb[64], encs[64], decs[64]; int out[32];
   hipMemcpy(encs, denc, n2 * 4, hipMemcpyDeviceToHost); hipMemcpy(decs, ddec, n2 * 4, hipMemcpyDeviceToHost);
   hipMemcpy(back, dback, n2 * 4, hipMemcpyDeviceToHost); hipMemcpy(hb, dhb, n2 * 4, hipMemcpyDeviceToHost); hipMemcpy(out, dout, n * 4, hipMemcpyDeviceToHost);
   printf("%14s %6s %14s %18s %22s %22s\n", "input", "byte", "cvt_pk_f32_fp8", "scalef32_f16(sc=.25)", "scaled-encode(sc=.25)", "scaled-decode(sc=.25)");
   for (int i = 0; i < n2; ++i) printf("%14.6g   0x%02x %14.6g %18.6g %22.6g %22.6g\n", vals[i], (out[i / 2] >> (8 * (i & 1))) & 0xff, back[i], hb[i], encs[i], decs[i]);
+  }
   return 0;
 }

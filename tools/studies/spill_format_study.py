@@ -64,14 +64,26 @@ def tile_scaled(fn, x, rows=64):
     return out
 
 
+def row_normalised(fn, sc):          # GB is linear in the point's loss adjoint gbar: one scale per POINT (row) takes its magnitude out
+    def f(v):
+        v = np.asarray(v, np.float32)
+        m = np.abs(v).max(axis=1, keepdims=True)
+        rs = np.where(m > 0, np.exp2(-np.floor(np.log2(np.maximum(m, 1e-30)))), 1.0).astype(np.float32)   # row max -> [1, 2)
+        return fn(v * rs, sc) / rs
+    return f
+
+
 def emul(params, cfg, lc, pc, z_vals, depth_sample, dirs_C_sample, T_WC_sample, norm_sample, noise, dw=None, own=None):
     """The shipped kernel's numerics (fp16 operands everywhere, fp32 accumulate, s' re-derived from the fp16 activation, injected
     term rebuilt from GB and P) with per-family formats:
       dw[fam]  : rounding applied to family fam in {'A','P','GB','ZB'} before the dW contraction (default fp16)
       own[fam] : rounding of what the chain's own sweeps re-read: 'S1' (the s' source: None = from the fp16 activation, else a
                  function applied to s' itself, i.e. a stored s' side tensor), 'P', 'GB' (operands of the injected term)"""
-    dw = dict(dict(A=f16, P=f16, GB=f16, ZB=f16), **(dw or {}))
+    dw = dict(dict(A=f16, P=f16, GB=f16, ZB=f16, keep={}), **(dw or {}))
     own = dict(dict(S1=None, P=f16, GB=f16), **(own or {}))
+    keep = dw['keep']          # {'P': {layers}, 'GB': {layers}}: layers whose tensor of that family stays fp16 (dW operand and own re-read)
+    fP = lambda li, v, d: f16(v) if li in keep.get('P', ()) else d['P'](v)
+    fG = lambda li, v, d: f16(v) if li in keep.get('GB', ()) else d['GB'](v)
     hp = f16
     R, S = z_vals.shape
     x = pc.reshape(-1, 3).astype(np.float32)
@@ -118,9 +130,10 @@ def emul(params, cfg, lc, pc, z_vals, depth_sample, dirs_C_sample, T_WC_sample, 
     GBf = [None] * (L + 1)     # GB[li+1] = u_li s'_li in fp32, GB[0] = Ebar
     for li, n in enumerate(cfg.names):
         Gb = Eb if li == 0 else (np.concatenate([qb, Eb], -1) if li == cfg.cat else qb)
-        Gb_dw = dw['GB'](Ebf) if li == 0 else (np.concatenate([dw['GB'](qbf), dw['GB'](Ebf)], -1) if li == cfg.cat else dw['GB'](qbf))
+        # (Ebar is rebuilt by the dW kernel from gbar since round 6: always the 16-bit value)
+        Gb_dw = f16(Ebf) if li == 0 else (np.concatenate([fG(li, qbf, dw), f16(Ebf)], -1) if li == cfg.cat else fG(li, qbf, dw))
         u = Gb @ Wb[n].T
-        grads[n + '.weight'] = dw['P'](Pf[li]).T @ Gb_dw
+        grads[n + '.weight'] = fP(li, Pf[li], dw).T @ Gb_dw
         qbf = u * s1(li)
         GBf[li + 1] = qbf
         qb = hp(qbf)
@@ -134,7 +147,7 @@ def emul(params, cfg, lc, pc, z_vals, depth_sample, dirs_C_sample, T_WC_sample, 
         if li == L - 1:
             inj = np.float32(100) * GBf[li + 1] * Pf[li] * (1 - s) / np.maximum(s, 1e-30)
         else:
-            inj = np.float32(100) * own['GB'](GBf[li + 1]) * own['P'](Pf[li]) * (1 - s) / np.maximum(s, 1e-30)
+            inj = np.float32(100) * fG(li + 1, GBf[li + 1], own) * fP(li, Pf[li], own) * (1 - s) / np.maximum(s, 1e-30)
         inj = np.where(Z[li] * 100 < 20, inj, 0)
         zb = ab * s + inj
         zbb = hp(zb)
@@ -180,15 +193,26 @@ if __name__ == '__main__':
     report('P, GB e4m3, per-tile scale (dW and own)', dw=dict(P=ts(e4m3), GB=ts(e4m3)), own=dict(P=ts(e4m3), GB=ts(e4m3)))
     report('P e4m3 x 2^8, GB e5m2 unscaled (dW and own)', dw=dict(P=fx(e4m3, 256.), GB=e5m2), own=dict(P=fx(e4m3, 256.), GB=e5m2))
 
-    def row_normalised(fn, sc):          # GB is linear in the point's loss adjoint gbar: one scale per POINT (row) takes its magnitude out
-        def f(v):
-            v = np.asarray(v, np.float32)
-            m = np.abs(v).max(axis=1, keepdims=True)
-            rs = np.where(m > 0, np.exp2(-np.floor(np.log2(np.maximum(m, 1e-30)))), 1.0).astype(np.float32)   # row max -> [1, 2)
-            return fn(v * rs, sc) / rs
-        return f
     report('P e4m3 x 2^8, GB e4m3 per-point normalised x 2^6 (dW and own)', dw=dict(P=fx(e4m3, 256.), GB=row_normalised(e4m3, 64.)),
            own=dict(P=fx(e4m3, 256.), GB=row_normalised(e4m3, 64.)))
+    if '--layers' in sys.argv:
+        Lh = len(cfg.names); cat = cfg.cat
+        e = fx(e4m3, 256.); gn = row_normalised(e4m3, 64.)
+        def per_tensor(label, **kw):
+            t, sdf, sg, gr = emul(params, cfg, lc, *args, noise, **kw)
+            print('%-60s ' % label + ' '.join('%s %.1e' % (k.split('.weight')[0][-8:], gu.rel_err(gr[k], g0[k])) for k in g0 if k.endswith('weight')), flush=True)
+        per_tensor('fp16')
+        per_tensor('P, GB e4m3 all layers', dw=dict(P=e, GB=gn), own=dict(P=e, GB=gn))
+        per_tensor('P fp16, GB e4m3', dw=dict(GB=gn), own=dict(GB=gn))
+        per_tensor('P e4m3, GB fp16', dw=dict(P=e), own=dict(P=e))
+        per_tensor('P e4m3 except layers 0 and cat; GB e4m3', dw=dict(P=e, GB=gn, keep=dict(P={0, cat})), own=dict(P=e, GB=gn))
+        per_tensor('P e4m3 except 0, cat; GB e4m3 except 1, cat+1', dw=dict(P=e, GB=gn, keep=dict(P={0, cat}, GB={1, cat + 1})), own=dict(P=e, GB=gn))
+        per_tensor('dW ONLY: P, GB e4m3 (chain re-reads fp16 / a stored 16-bit INJ)', dw=dict(P=e, GB=gn))
+        per_tensor('dW ONLY: GB e4m3, P fp16', dw=dict(GB=gn))
+        per_tensor('own ONLY: P, GB e4m3 (dW operands fp16)', own=dict(P=e, GB=gn))
+        per_tensor('P, GB bf16', dw=dict(P=bf16, GB=bf16), own=dict(P=bf16, GB=bf16))
+        per_tensor('P, GB fp12', dw=dict(P=fp12, GB=fp12), own=dict(P=fp12, GB=fp12))
+        sys.exit(0)
     if not quick:
         report('dW operands all bf16', dw=dict(A=bf16, P=bf16, GB=bf16, ZB=bf16))
         report('dW operands all fp12 (1-5-6)', dw=dict(A=fp12, P=fp12, GB=fp12, ZB=fp12))

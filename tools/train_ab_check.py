@@ -21,8 +21,12 @@ def dump(path):
     d, n, T = synthetic.keyframes(5, cam, seed=1)
     dev = lambda a: torch.as_tensor(a).cuda()
     d, n, T = dev(d), dev(n), dev(T)
-    for tag, kw in (("default", {}), ("fp16", dict(fwd_operand="fp16")), ("bf16", dict(fwd_operand="bf16")),
-                    ("wide", dict(hidden=512, blocks=3, n_freqs=10))):
+    cases = [("default", {}), ("fp16", dict(fwd_operand="fp16")), ("bf16", dict(fwd_operand="bf16")),
+             ("wide", dict(hidden=512, blocks=3, n_freqs=10))]
+    if "spill_operand" in NetConfig.__dataclass_fields__:      # the spill formats of the default net, side by side
+        cases += [("spill16", dict(spill_operand="16bit")), ("spill_e4m3", dict(spill_operand="e4m3")),
+                  ("spill_e4m3_gb", dict(spill_operand="e4m3_gb"))]
+    for tag, kw in cases:
         eng = Engine(NetConfig(transform=synthetic.bounds_transform(), **kw), "cuda")
         torch.manual_seed(0); eng.params.normal_(0, 0.06 if tag != "wide" else 0.04); eng.pack()
         sc = SampleConfig(n_rays=200, **cam); lc = LossConfig()
@@ -49,11 +53,23 @@ def compare(a, b):
         print("%-20s %s  rel-L2 %.3e  max|d| %.3e  (n %d, nan %d)" % (k, "bit-identical" if same else "different    ", rel, float(np.abs(x - y).max()), x.size, int(np.isnan(x).sum())))
 
 
+def modes(a):
+    A = np.load(a)
+    ref = A["spill16/grad"].astype(np.float64)
+    for tag in ("spill_e4m3", "spill_e4m3_gb", "default"):
+        x = A[tag + "/grad"].astype(np.float64)
+        print("%-16s vs spill16: grad rel-L2 %.3e  sign differs %.4f %%  | sdf identical %s" % (
+            tag, np.linalg.norm(x - ref) / np.linalg.norm(ref), 100 * np.mean(np.sign(x) != np.sign(ref)),
+            np.array_equal(A[tag + "/sdf"], A["spill16/sdf"])))
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("--dump"); ap.add_argument("--compare", nargs=2)
+    ap.add_argument("--dump"); ap.add_argument("--compare", nargs=2); ap.add_argument("--modes")
     a = ap.parse_args()
     if a.dump:
         dump(a.dump)
     if a.compare:
         compare(*a.compare)
+    if a.modes:
+        modes(a.modes)
