@@ -78,9 +78,9 @@ typedef struct isdf_net_cfg {
                             the dW contraction -- P = d sdf / d z (below the top layer) and GB = the adjoint entering each layer in
                             the upward sweep, i.e. the operands of the SECOND-order product of total_loss.backward() (the eikonal /
                             normal terms' share of the gradient, trainer.py:814-830,981):
-                            0 auto: e4m3 when n_freqs <= 6 and bwd_operand is fp16 (replicaCAD.json / scanNet.json), else 16-bit;
-                            1 the 16-bit bwd_operand type (rounds 1-5); 2 OCP e4m3, one byte per element: P / 2^-10, GB / s_G with a
-                            per-POINT scale s_G (GB is linear in the point's loss adjoint).  e4m3 halves 11 of the 23 tensors a step
+                            0 auto: e4m3 when n_freqs <= 6, hidden <= 256 and bwd_operand is fp16 (replicaCAD.json / scanNet.json), else 16-bit;
+                            1 the 16-bit bwd_operand type (rounds 1-5); 2 OCP e4m3 (hidden <= 256 only), one byte per element: P / 2^-10, GB / s_G with a
+                            per-POINT scale s_G (GB is linear in the point's loss adjoint); 3 e4m3 for GB only.  e4m3 halves 11 of the 23 tensors a step
                             stores and 21 of the 50 it reads back; at six octaves it moves the worst weight gradient by 2e-4 of the
                             reference's, with nine or more octaves the second-order term carries most of the first layers' gradient
                             and e4m3 costs ~1e-2 there -- which is why `auto` keeps those nets on 16 bits.            */

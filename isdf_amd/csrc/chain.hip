@@ -1107,7 +1107,7 @@ static int launch_one(const ChainParams& p, int64_t nTiles, hipStream_t st) {
   typedef Tile<HD, EP, oper_x2_all(OPER)> T;
   if constexpr (!BW && MODE == 2 && oper_f16(OPER))
     if (p.lay.bwd_f16) return launch_one<HD, EP, OPER, MODE, true>(p, nTiles, st);
-  if constexpr (BW && !SP8) {
+  if constexpr (BW && !SP8 && HD == 256) {       // (make_layout: e4m3 spills with the 256-wide tiles only)
     if (p.lay.sp8 == 3) return launch_one<HD, EP, OPER, MODE, true, 3>(p, nTiles, st);
     if (p.lay.sp8 == 1) return launch_one<HD, EP, OPER, MODE, true, 1>(p, nTiles, st);
   }

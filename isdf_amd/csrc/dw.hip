@@ -101,6 +101,8 @@ __global__ __launch_bounds__(512, 2) void dw_kernel(const DwParams p) {
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
   const int nStages = split < nTiles ? 2 * ((nTiles - split + DW_SPLITK - 1) / DW_SPLITK) : 0;
+  // a PE unit of a six-octave net builds its operand in the ALIGNED column order (see run()); others in the reference's order
+  const bool peAligned = fromEmb && L.EP == DW_BLK && L.n_freqs == 6;
 
   // per-lane transpose-read addressing: in each 16-lane group source lane s
   // supplies row (s>>2), 4-element column chunk (s&3); destination lane i gets
@@ -195,15 +197,27 @@ __global__ __launch_bounds__(512, 2) void dw_kernel(const DwParams p) {
     // (s' = 2 s c, c' = 1 - 2 s^2: 4 plain VALU operations per octave and pair instead of two projections and two transcendentals;
     // <= 3e-6 from the direct value after 11 doublings, against an fp16 ulp of 5e-4).  Threads 320..383 of round r = 2 (which has
     // only 320 items) write x' / gbar (features 0..2) and the zero padding of their point.
+    //
+    // Column order of the rebuilt operand.  ALIGNED (the embedding fits one 256-column slice and n_freqs is even: replicaCAD.json /
+    // scanNet.json): [sin groups | cos groups | x' | padding] -- direction d's n_freqs sines start at column d n_freqs, a 4-byte
+    // boundary, so a group leaves as n_freqs / 2 aligned 4-byte stores (in the reference's order, [x' | sin | cos], every group starts
+    // 2 mod 4: twelve 2-byte stores per item and direction).  The dW columns come out in that order too; the slab store below puts
+    // column i where the reference's column lives.  Otherwise (EP = 512: nine to eleven octaves) the reference's order, 2-byte stores.
     constexpr float kInv2Pi = 0.15915494309189535f, k2Pi = 6.283185307179586f;
     float drx[3] = {0.f, 0.f, 0.f}, dry[3] = {0.f, 0.f, 0.f}, drz[3] = {0.f, 0.f, 0.f};
+    int itemOff[3] = {0, 0, 0};       // aligned order: (point * 32) << 16 | byte offset of the item's first column in the operand tile;
+                                      // reference order: point << 16 | (first column relative to the unit's slice) + 1024
     float4 auxr = make_float4(0.f, 0.f, 0.f, 0.f);
     if constexpr (PE) {
+      const int nf = L.n_freqs;
 #pragma unroll
       for (int r = 0; r < 3; ++r) {
         const int item = tid + 512 * r;
-        const int d = item < BM * N_DIRS ? item % N_DIRS : 0;
+        const bool dirItem = item < BM * N_DIRS;
+        const int pt = dirItem ? item / N_DIRS : (item - BM * N_DIRS) & (BM - 1), d = dirItem ? item - pt * N_DIRS : 0;
         drx[r] = kDirs[0][d] * kInv2Pi; dry[r] = kDirs[1][d] * kInv2Pi; drz[r] = kDirs[2][d] * kInv2Pi;
+        itemOff[r] = peAligned ? ((pt * 32) << 16) | (pt * ROWB + (dirItem ? d * nf * 2 : 0))
+                               : (pt << 16) | ((dirItem ? 3 + d * nf - slBfull * DW_BLK : 0) + 1024);
       }
     }
     // pe_aux of the k-th tile of this workgroup: 64 points x 2 float4, one float4 per thread of the first two waves
@@ -251,7 +265,6 @@ __global__ __launch_bounds__(512, 2) void dw_kernel(const DwParams p) {
         // q = 1: Ebar = J_pe gbar (chain.hip's Ebar stage): [gbar | cos(xb_df) k_df | -sin(xb_df) k_df], k_df = (gbar . dir_d) 2^f
         const char* auxl = smem + 4 * T::TEN + ((st >> 1) & 1) * T::AUXB;
         char* tb = sb + T::TEN;
-        const bool q1 = st & 1;
         const int nf = L.n_freqs, halfE = N_DIRS * nf, colBase = slBfull * DW_BLK;
         typedef typename Op<F16>::e eT;
         typedef eT e2 __attribute__((ext_vector_type(2)));
@@ -259,66 +272,60 @@ __global__ __launch_bounds__(512, 2) void dw_kernel(const DwParams p) {
           if ((unsigned)col < (unsigned)DW_BLK) *(eT*)(row + col * 2) = (eT)v;
         };
         auto fill = [&](auto nfc, auto q1c) {
-          constexpr int NFT = decltype(nfc)::value;               // n_freqs at compile time (0: run-time loop, 2-byte stores)
+          constexpr int NFT = decltype(nfc)::value;               // n_freqs at compile time: the ALIGNED column order (0: run-time loop, 2-byte stores)
           constexpr bool Q1 = decltype(q1c)::value;
-          const int nfl = NFT ? NFT : nf;
-          // opaque to the optimiser: the items' points, rows and columns are the same in every stage, and hoisted out of the stage loop
-          // they would sit in ~20 registers next to the 128 of the accumulator for the whole kernel (and spill)
-          int tq = tid;
-          asm volatile("" : "+v"(tq));
 #pragma unroll
           for (int r = 0; r < 3; ++r) {
-            const int item = tq + 512 * r;
-            if (item < BM * N_DIRS) {
-              const int pt = item / N_DIRS, d = item - pt * N_DIRS;
-              char* row = tb + pt * ROWB;
-              const float4 y = *(const float4*)(auxl + pt * 32);
+            // (opaque to the optimiser: derived per-item addresses hoisted out of the stage loop would sit in registers next to the
+            // 128 of the accumulator for the whole kernel -- one packed word per round does)
+            int io = itemOff[r];
+            asm volatile("" : "+v"(io));
+            const char* ax = auxl + (NFT ? (io >> 16) : (io >> 16) * 32);
+            if (r < 2 || tid < BM * N_DIRS - 1024) {
+              const float4 y = *(const float4*)ax;
               const float r0 = y.x * drx[r] + y.y * dry[r] + y.z * drz[r];
               float sn = __builtin_amdgcn_sinf(r0), cs = __builtin_amdgcn_cosf(r0), kf = 0.f;
               if constexpr (Q1) {
-                const float4 g = *(const float4*)(auxl + pt * 32 + 16);
+                const float4 g = *(const float4*)(ax + 16);
                 kf = (g.x * drx[r] + g.y * dry[r] + g.z * drz[r]) * k2Pi;
               }
-              const int cS = 3 + d * nfl - colBase, cC = cS + halfE;     // first column of the sine / cosine group
               auto vals = [&](float& a, float& b) {        // this octave's two values, then on to the next octave
                 a = Q1 ? cs * kf : sn; b = Q1 ? -sn * kf : cs;
                 const float t = sn * cs;
                 cs = __builtin_fmaf(-2.f * sn, sn, 1.f); sn = t + t; kf += kf;
               };
               if constexpr (NFT == 0) {
-                for (int f = 0; f < nfl; ++f) { float a, b; vals(a, b); st1(row, cS + f, a); st1(row, cC + f, b); }
+                char* row = tb + (io >> 16) * ROWB;
+                const int cS = (io & 0xffff) - 1024, cC = cS + halfE;      // first column of the sine / cosine group in this slice
+                for (int f = 0; f < nf; ++f) { float a, b; vals(a, b); st1(row, cS + f, a); st1(row, cC + f, b); }
               } else {
-                // n_freqs even: column 3 + d n_freqs (+ 21 n_freqs) is odd, so octaves (1,2), (3,4), ... are 4-byte aligned pairs;
-                // the slice holds the whole embedding (E = 42 n_freqs + 3 <= 256), no range checks.  Values leave as they are made:
-                // the kernel sits at the 256-register limit (a 256 x 256 fp32 accumulator per workgroup)
                 static_assert(NFT % 2 == 0, "paired stores assume an even octave count");
-                // (volatile: left alone, the compiler fuses a group's 2 + 4 + 4 + 2 bytes into ONE ds_write_b96 at an address that is
-                // 2 mod 4 -- legal in the LDS's unaligned mode and several times slower than the four aligned stores)
-                float a, b, a2, b2;
-                vals(a, b);
-                *(volatile eT*)(row + cS * 2) = (eT)a; *(volatile eT*)(row + cC * 2) = (eT)b;
+                char* ps = tb + (io & 0xffff);                       // 4-byte aligned: column d * NFT of row pt
+                char* pc = ps + N_DIRS * NFT * 2;
 #pragma unroll
-                for (int f = 1; f + 1 < NFT; f += 2) {
+                for (int f = 0; f < NFT; f += 2) {
+                  float a, b, a2, b2;
                   vals(a, b); vals(a2, b2);
-                  e2 ps, pc; ps[0] = (eT)a; ps[1] = (eT)a2; pc[0] = (eT)b; pc[1] = (eT)b2;
-                  *(volatile uint32_t*)(row + (cS + f) * 2) = __builtin_bit_cast(uint32_t, ps);
-                  *(volatile uint32_t*)(row + (cC + f) * 2) = __builtin_bit_cast(uint32_t, pc);
+                  e2 vs, vc; vs[0] = (eT)a; vs[1] = (eT)a2; vc[0] = (eT)b; vc[1] = (eT)b2;
+                  *(e2*)(ps + f * 2) = vs; *(e2*)(pc + f * 2) = vc;
                 }
-                vals(a, b);
-                *(volatile eT*)(row + (cS + NFT - 1) * 2) = (eT)a; *(volatile eT*)(row + (cC + NFT - 1) * 2) = (eT)b;
               }
-            } else if (item - BM * N_DIRS < BM) {
-              const int pt = item - BM * N_DIRS;
-              char* row = tb + pt * ROWB;
-              const float4 v = *(const float4*)(auxl + pt * 32 + (Q1 ? 16 : 0));
-              st1(row, 0 - colBase, v.x); st1(row, 1 - colBase, v.y); st1(row, 2 - colBase, v.z);
-              for (int f = L.E; f < L.EP; ++f) st1(row, f - colBase, 0.f);
+            } else if (tid < BM * N_DIRS - 1024 + BM) {
+              char* row = tb + (NFT ? (io >> 16) >> 5 : (io >> 16)) * ROWB;
+              const float4 v = *(const float4*)(ax + (Q1 ? 16 : 0));
+              if constexpr (NFT != 0) {      // aligned order: x' behind the 42 n_freqs sine / cosine columns, then the padding
+                e2 v01, v2z; v01[0] = (eT)v.x; v01[1] = (eT)v.y; v2z[0] = (eT)v.z; v2z[1] = (eT)0.f;
+                *(e2*)(row + 2 * N_DIRS * NFT * 2) = v01; *(e2*)(row + 2 * N_DIRS * NFT * 2 + 4) = v2z;
+                for (int f = 2 * N_DIRS * NFT + 4; f < DW_BLK; f += 2) { e2 z; z[0] = (eT)0.f; z[1] = (eT)0.f; *(e2*)(row + f * 2) = z; }
+              } else {
+                st1(row, 0 - colBase, v.x); st1(row, 1 - colBase, v.y); st1(row, 2 - colBase, v.z);
+                for (int f = L.E; f < L.EP; ++f) st1(row, f - colBase, 0.f);
+              }
             }
-            __builtin_amdgcn_sched_barrier(0);      // one item at a time: interleaved, three items' temporaries do not fit the register file
           }
         };
-        const bool whole6 = nf == 6 && L.EP == DW_BLK;     // replicaCAD.json / scanNet.json
-        if (whole6) { if (q1) fill(std::integral_constant<int, 6>{}, std::true_type{}); else fill(std::integral_constant<int, 6>{}, std::false_type{}); }
+        const bool q1 = st & 1;
+        if (peAligned && nf == 6) { if (q1) fill(std::integral_constant<int, 6>{}, std::true_type{}); else fill(std::integral_constant<int, 6>{}, std::false_type{}); }
         else { if (q1) fill(std::integral_constant<int, 0>{}, std::true_type{}); else fill(std::integral_constant<int, 0>{}, std::false_type{}); }
       }
     };
@@ -366,7 +373,11 @@ __global__ __launch_bounds__(512, 2) void dw_kernel(const DwParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int o = wo * 64 + ob * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-        const int i = wi * 128 + ib * 32 + (lane & 31);
+        int i = wi * 128 + ib * 32 + (lane & 31);
+        if (peAligned) {     // aligned operand order [sin | cos | x' | pad] -> the reference's [x' | sin | cos | pad]
+          const int nsc = 2 * N_DIRS * L.n_freqs;
+          i = i < nsc ? i + 3 : (i < nsc + 3 ? i - nsc : i);
+        }
         __builtin_nontemporal_store(acc[ob][ib][r], slab + o * DW_BLK + i);
       }
 }
@@ -388,8 +399,7 @@ int launch_dw(const DwParams& p, hipStream_t st) {
     if (p.lay.sp8 == 1) return go(dw_kernel<256, true, 1>);
     return p.lay.bwd_f16 ? go(dw_kernel<256, true, 0>) : go(dw_kernel<256, false, 0>);
   }
-  if (p.lay.sp8 == 3) return go(dw_kernel<512, true, 3>);
-  if (p.lay.sp8 == 1) return go(dw_kernel<512, true, 1>);
+  if (p.lay.sp8) return ISDF_EUNSUPPORTED;      // (make_layout: e4m3 spills with the 256-wide tiles only)
   return p.lay.bwd_f16 ? go(dw_kernel<512, true, 0>) : go(dw_kernel<512, false, 0>);
 }
 

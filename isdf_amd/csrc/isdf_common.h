@@ -13,10 +13,13 @@ constexpr int TILE_PTS = 64;   // points per chain-kernel workgroup (two workgro
 constexpr int DW_PTS = 64;     // points per dW-kernel stage
 constexpr int CHAIN_NW = 8;    // waves per chain-kernel workgroup (each owns HD/CHAIN_NW features)
 constexpr int CHAIN_CHUNK_FRAGS = 8;   // weight fragments a wave requests at once (32 VGPRs at the 128-VGPR budget)
-// K-splits per dW unit.  A unit whose input-side operand is embedding-shaped REBUILDS it from six floats per point (dw.hip) instead
-// of reading it: half the bytes per stage, but ~300 VALU instructions per thread and stage next to the MFMAs -- its stages are the
-// longer ones, so it gets more, shorter K-splits.  Default net: 5 x 32 + 2 x 48 = 256 workgroups = one per CU.
-constexpr int DW_SPLIT_REG = 32, DW_SPLIT_PE = 48, DW_SPLIT_MAX = 48;
+// K-splits per dW unit: 5 x 35 + 2 x 40 = 255 workgroups for the default net, one per CU.  A workgroup's time is its number of
+// 64-point stages times ~3.1 us -- measured with the other units switched off: the top layer's 32 workgroups ALONE take as long as all
+// 256 together (profiles/r06_dw_unit_kinds.txt) -- i.e. the kernel is bound by its commit -> transpose-read -> MFMA -> barrier chain,
+// not by bytes, so the split that matters is the one that evens out the stage counts.  A unit that rebuilds its embedding-shaped operand
+// (dw.hip) runs slightly longer stages (~3.25 us) and gets five splits more (same-box A/B of 32/48, 34/43, 35/40, 36/38:
+// profiles/r06_dw_splits.txt).
+constexpr int DW_SPLIT_REG = 35, DW_SPLIT_PE = 40, DW_SPLIT_MAX = 40;
 typedef float slab_t;          // K-split partial slabs (bf16 slabs measured: parity unchanged, -2 us only)
 
 // Vector types for the 16-bit MFMA operands.
@@ -136,9 +139,10 @@ inline int make_layout(const isdf_net_cfg* c, NetLayout* l) {
   if (c->bwd_operand < 0 || c->bwd_operand > 1 || (c->bwd_operand == 1 && !l->fwd_f16)) return ISDF_EINVAL;
   l->bwd_f16 = c->bwd_operand;
   if (c->spill_operand < 0 || c->spill_operand > 3 || (c->spill_operand >= 2 && !l->bwd_f16)) return ISDF_EINVAL;
+  if (c->spill_operand >= 2 && l->HD != 256) return ISDF_EUNSUPPORTED;     // the e4m3 formats are instantiated for the 256-wide tiles
   // auto: e4m3 where it is (nearly) free -- up to six octaves the second-order product P^T GB is a small share of every layer's
   // gradient; the positional encoding amplifies it by 2^(n_freqs - 1), and from nine octaves on e4m3's 2^-4 shows
-  l->sp8 = c->spill_operand == 2 ? 3 : c->spill_operand == 3 ? 1 : (c->spill_operand == 0 && l->bwd_f16 && c->n_freqs <= 6) ? 3 : 0;
+  l->sp8 = c->spill_operand == 2 ? 3 : c->spill_operand == 3 ? 1 : (c->spill_operand == 0 && l->bwd_f16 && c->n_freqs <= 6 && l->HD == 256) ? 3 : 0;
   l->has_transform = c->has_transform;
   l->scale_input = c->scale_input; l->scale_output = c->scale_output;
   for (int i = 0; i < 12; ++i) l->T[i] = c->has_transform ? c->bounds_T[i] : (i % 5 == 0 ? 1.f : 0.f);
