@@ -475,12 +475,20 @@ __global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 && EP == HD && !oper_x2_a
 #pragma unroll
   for (int pb = 0; pb < PB; ++pb) rawp[pb] = 0.f;
 
-  // region 1 <- fp16(v), region 2 <- fp16(v - fp16(v)): the operand pair of a compensated layer (OPER 2)
+  // region 1 <- fp16(v), region 2 <- fp16(v - fp16(v)): the operand pair of a compensated layer (OPER 2).  The residual is formed against
+  // the STORED half (round 6; until then the value was converted twice, once for the store and once for the residual, and the compiler
+  // is free to round the two differently -- one rounding through v_fma_mix*, two through v_mul + v_cvt: a residual against a
+  // differently rounded half is off by an fp16 ulp of the value; fwd_pair.hip has done it this way since round 5)
   auto put_x_hilo = [&](int fb, int pb, int qp, const float (&v)[8]) {
+    f16x4 ha, hb;
     float r[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) r[e] = v[e] - (float)(_Float16)v[e];
-    put_x(true, fb, pb, qp, v, 0);
+    for (int e = 0; e < 4; ++e) { ha[e] = (_Float16)v[e]; hb[e] = (_Float16)v[4 + e]; }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { r[e] = v[e] - (float)ha[e]; r[4 + e] = v[4 + e] - (float)hb[e]; }
+    const int lb = (xw ^ (64 * fb + 32 * qp)) + pb * 32 * ROWB;   // see put_x
+    *(uint2*)(X + lb) = __builtin_bit_cast(uint2, ha);
+    *(uint2*)(X + (lb ^ 16)) = __builtin_bit_cast(uint2, hb);
     put_x(true, fb, pb, qp, r, LO);
   };
   for (int li = 0; li < L.L; ++li) {
