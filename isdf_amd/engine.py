@@ -375,7 +375,7 @@ class Engine:
         # fast path of the step loop: same sampler buffer set, same configuration -> the ctypes structs of the previous
         # call on this set are reused and only the per-step scalars change
         plan_key = None
-        if (smp.get("_slot") is not None and noise is None and not debug and prof_events is None and surf_group is None
+        if (smp.get("_slot") is not None and noise is None and not debug and surf_group is None
                 and lc.bounds_method == "ray"):
             fo = None if optim is None else optim.get("frame_avg_out")
             fi = None if optim is None else optim.get("frame_avg_index")
@@ -393,6 +393,7 @@ class Engine:
                 _, closs, a, o, q, ws, dbg = plan
                 a.noise_std, a.noise_seed, a.noise_offset = float(noise_std), int(noise_seed), int(noise_offset)
                 a.extra_slot, a.extra_value = int(extra_slot), float(extra_value)
+                o.prof_events = prof_events          # (bench.py: four hipEvent_t around the step's kernels on some steps; None otherwise)
                 if q is not None:
                     self.opt_step += 1
                     betas = optim.get("betas", (0.9, 0.999))

@@ -280,6 +280,8 @@ class HotPath:
             kw["surf_group"] = hip.dist_group
         if hip.clock_slots:              # this rank's previous step time rides in the message's tail (one slot per rank)
             kw.update(extra_slot=hip.rank, extra_value=hip.prev_step_ms)
+        if hip.prof_events is not None:  # bench.py: HIP events around this step's kernels (a ctypes array of four hipEvent_t), once
+            kw["prof_events"], hip.prof_events = hip.prof_events, None
         split = hip.dist_group is not None and hip.overlap_allreduce and not fused_optim
         if split:
             if hip.split_event is None:
@@ -662,7 +664,7 @@ def graft(trainer, rng="philox", seed=1, dist_group=None, fix_normal_window=Fals
 
     hip = types.SimpleNamespace(rng=rng, seed=int(seed), dist_group=dist_group, fix_normal_window=bool(fix_normal_window),
                                 fuse_optimiser=bool(fuse_optimiser), device=dev, draw_count=0, noise_count=0,
-                                step_count=0, idx_cache=None, timing_events=None,
+                                step_count=0, idx_cache=None, timing_events=None, prof_events=None,
                                 inline_window=True,      # bench.py flips it for the A/B of the window's transport
                                 overlap_allreduce=bool(overlap_allreduce) and dist_group is not None, split_event=None,
                                 comm_stream=None,
