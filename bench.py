@@ -503,7 +503,7 @@ def main():
     # per-kernel HIP events ride on every PROF_EVERY-th timed step: four event records between the launches cost ~2 us of
     # stream time each (a step with them measured 305 us, without 296 us), and the other steps take the engine's cached call plan
     PROF_EVERY = 4
-    KP = (K + PROF_EVERY - 1) // PROF_EVERY
+    KP = max(K // PROF_EVERY, 1)             # on the LAST step of every group of four (never the first step behind the barrier)
     events = HipEvents(4 * KP)
 
     overlap = group is not None and args.overlap_allreduce
@@ -559,7 +559,7 @@ def main():
     per_step = np.empty(K)
     t0 = time.perf_counter()
     for i in range(K):
-        if i % PROF_EVERY == 0:
+        if (i % PROF_EVERY == PROF_EVERY - 1 or K < PROF_EVERY and i == K - 1) and i // PROF_EVERY < KP:
             tr._hip.prof_events = events.group(i // PROF_EVERY)       # HIP events around this step's kernels, on the launch stream
         t_a = time.perf_counter()
         tr.step()

@@ -16,6 +16,12 @@ tests/test_graft_reference.py); nothing here is needed then.  `step`, `sample_po
 deliberately absent: they exist only as HIP kernels (hot_path.HotPath).
 
     HipTrainer(device, config, ...)  ==  graft(StandinTrainer(device, config, ...), ...)
+
+`add_data`, `add_frame`, `check_keyframe_latest` and `select_keyframes` below follow the reference's methods statement by statement
+(they ARE the reference's driver-side logic, restated because the GPU box has no reference checkout).  The reference is
+Copyright (c) Meta Platforms, Inc. and affiliates, released under the MIT license (iSDF, facebookresearch/iSDF, LICENSE):
+permission is granted, free of charge, to deal in the software without restriction, provided the copyright notice and the
+permission notice are included in all copies or substantial portions of it; the software is provided "as is", without warranty.
 """
 import copy
 import json

@@ -77,9 +77,16 @@ def build(force=False, verbose=True):
     lint_ran = True
     try:
         n_obj, bad = isa_lint.lint_library(staged)
-    except (OSError, subprocess.CalledProcessError, RuntimeError) as e:   # no llvm-objdump on this host, or nothing extracted: the check
-        n_obj, bad, lint_ran = 0, [], False                               # cannot run (tests/test_isa_lint.py then skips too); never a
-        sys.stderr.write("isa_lint could not run (%s)\n" % e)             # reason to ship nothing
+    except (OSError, subprocess.CalledProcessError) as e:   # no llvm-objdump on this host: the check cannot run (tests/test_isa_lint.py
+        n_obj, bad, lint_ran = 0, [], False                 # then skips too) -- never a reason to ship nothing
+        sys.stderr.write("isa_lint could not run (%s)\n" % e)
+    except RuntimeError as e:                               # the tool ran and extracted NO gfx950 code object (a bundler / toolchain
+        if not os.environ.get("ISDF_SKIP_ISA_LINT"):        # format change): the gate fails CLOSED -- an unchecked library is not installed
+            os.remove(staged)
+            raise RuntimeError("isa_lint found nothing to check in the freshly linked library (%s); set ISDF_SKIP_ISA_LINT=1 to install "
+                               "it unchecked" % e)
+        n_obj, bad, lint_ran = 0, [], False
+        sys.stderr.write("isa_lint could not run (%s) -- overridden by ISDF_SKIP_ISA_LINT\n" % e)
     skip = bool(os.environ.get("ISDF_SKIP_ISA_LINT"))
     if bad and not skip:
         os.remove(staged)

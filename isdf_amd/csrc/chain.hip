@@ -20,6 +20,7 @@
 // B = the activation tile in LDS ([point][k], 16-B XOR swizzle, ds_read_b128).
 // In the C layout a lane owns one point and 4 consecutive features per
 // register quad, so epilogues write 8-byte packed pieces back to the LDS tile.
+#include <atomic>
 #include "chain_dev.h"
 
 namespace isdf {
@@ -207,7 +208,7 @@ __global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 && EP == HD && !oper_x2_a
   if (n0 >= P) return;
   const int nf = L.n_freqs;
   const float so = L.scale_output;
-  ChainStamps TS(p.dbg);   // phase time stamps of the -DISDF_DEBUG_HOOKS=1 build; empty inlines in the shipped kernel
+  ChainStamps TS(p.dbg, p.n_cu);   // phase time stamps of the -DISDF_DEBUG_HOOKS=1 build; empty inlines in the shipped kernel
   TS();
   // MODE.FP16_OVFL (hwreg 1, bit 23): float -> e4m3 / fp16 conversions SATURATE instead of producing NaN / inf.  Without it
   // v_cvt_scalef32_pk_fp8_f32 turns anything above 464 into NaN (tools/probes/fp8_cvt.hip); the e4m3 spill of P and GB below is
@@ -1146,23 +1147,29 @@ static int launch_mode(const ChainParams& p, int64_t nTiles, hipStream_t st) {
 bool fwd_pair_supported(const NetLayout& l);                                        // fwd_pair.hip
 int launch_fwd_pair(const ChainParams& p, int64_t nTiles, hipStream_t st);
 
-// compute units of the current device (cached per device ordinal; 256 on an unpartitioned MI355X)
-static int device_cu_count() {
-  static int cached[64] = {};
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
-  if (!cached[dev]) {
-    int n = 0;
-    cached[dev] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+// compute units of the device the launch goes to -- the STREAM's device, not the thread's current one (a caller may hold a stream of
+// another device); cached per ordinal in atomics (concurrent host threads).  256 on an unpartitioned MI355X.  Speed only: the
+// issue-priority heuristic of the chain kernel and the persistent grid of the forward kernel.
+static int device_cu_count(hipStream_t st) {
+  static std::atomic<int> cached[64];
+  int dev = -1;
+  if (st == nullptr || hipStreamGetDevice(st, &dev) != hipSuccess) {     // the null stream belongs to the current device
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
   }
-  return cached[dev];
+  if (dev < 0 || dev >= 64) return 256;
+  int n = cached[dev].load(std::memory_order_relaxed);
+  if (!n) {
+    n = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+    cached[dev].store(n, std::memory_order_relaxed);
+  }
+  return n;
 }
 
 int launch_chain(const ChainParams& p0, int mode, int64_t nTiles, hipStream_t st) {
   if (!layout_supported(p0.lay)) return ISDF_EUNSUPPORTED;
   if (nTiles <= 0) return ISDF_OK;
   ChainParams p = p0;
-  p.n_cu = device_cu_count();
+  p.n_cu = device_cu_count(st);
   switch (mode) {
     case 0:   // forward only: the pair-tile kernel where it exists (<256, 256>), the one-tile kernel elsewhere
       if (fwd_pair_supported(p.lay)) return launch_fwd_pair(p, nTiles, st);

@@ -29,8 +29,8 @@ inline void chain_debug_from_env(ChainDebug& d, void* stamp_area) {
 #if defined(__HIPCC__)
 struct ChainStamps {
   const ChainDebug& d; int n = 0;
-  __device__ explicit ChainStamps(const ChainDebug& dd) : d(dd) {
-    if (d.stagger && ((d.stagger_gen ? (blockIdx.x >> 8) : blockIdx.x) & 1)) {   // de-phase odd tiles / second-round workgroups
+  __device__ explicit ChainStamps(const ChainDebug& dd, int n_cu = 256) : d(dd) {
+    if (d.stagger && ((d.stagger_gen ? ((int)blockIdx.x / n_cu) : blockIdx.x) & 1)) {   // de-phase odd tiles / second-round workgroups (dispatch round = blockIdx / #CUs, as the kernel's genOdd)
       const unsigned long long t0 = __builtin_amdgcn_s_memtime();
       while (__builtin_amdgcn_s_memtime() - t0 < (unsigned long long)d.stagger * 1000ull) __builtin_amdgcn_s_sleep(64);
     }
@@ -45,8 +45,9 @@ struct ChainStamps {
     if (d.times && blockIdx.x == 100 && threadIdx.x == blockDim.x - 64 && n < 128) d.times[384 + n] = __builtin_amdgcn_s_memtime();
     ++n;
   }
-  __device__ void wall(int slot) const {   // wall clock (s_memrealtime, 100 MHz) of every 4th workgroup
-    if (d.times && !d.all_waves && threadIdx.x == 0 && (blockIdx.x & 3) == 0 && blockIdx.x < 4 * 190)
+  __device__ void wall(int slot) const {   // wall clock (s_memrealtime, 100 MHz) of every 4th workgroup: slots 128 .. 383 of the 512-entry
+    // (4 KB) stamp area -- [128 + 2 k + slot] for workgroup 4 k, k < 128 -- below the last-wave stamps at 384..511
+    if (d.times && !d.all_waves && threadIdx.x == 0 && (blockIdx.x & 3) == 0 && blockIdx.x < 4 * 128)
       d.times[128 + slot + blockIdx.x / 2] = __builtin_amdgcn_s_memrealtime();
   }
   __device__ int64_t spill_tile() const { return d.alias ? (int64_t)(blockIdx.x % d.alias) : (int64_t)blockIdx.x; }
@@ -57,7 +58,7 @@ struct ChainDebug {};
 inline void chain_debug_from_env(ChainDebug&, void*) {}
 #if defined(__HIPCC__)
 struct ChainStamps {
-  __device__ explicit ChainStamps(const ChainDebug&) {}
+  __device__ explicit ChainStamps(const ChainDebug&, int = 0) {}
   __device__ void operator()() const {}
   __device__ void wall(int) const {}
   __device__ int64_t spill_tile() const { return (int64_t)blockIdx.x; }

@@ -81,9 +81,12 @@ __global__ __launch_bounds__(256) void normals_kernel(const float* __restrict__ 
   }
 }
 
-// one thread per ray: stable insertion sort of (z, sdf) by z, first negative sdf, reference quirks kept:
-// no negative sample -> sample 0; crossing at the LAST sample -> depth 0 (render.py:19-31)
-template <int MAXS>
+// One thread per ray.  The reference sorts the ray's samples by z (stable) and takes the FIRST one with a negative sdf, with two quirks
+// kept: no negative sample -> sorted sample 0; a crossing at the LAST sorted sample -> depth 0 (render.py:19-31).  No sort is needed for
+// that (round 6; the insertion sort of rounds 1-5 kept two dynamically indexed 64-entry arrays in scratch memory, the only scratch in the
+// library): the first negative sample of the sorted order is the negative sample with the smallest (z, original index), found in one pass
+// -- the smallest over ALL samples if none is negative -- and it is the last sorted sample exactly when S - 1 samples precede it, a second
+// pass over the ray's z values (27 floats, L1-resident).  Same comparisons as the stable sort, so the same sample, bit for bit.
 __global__ void render_depth_kernel(const int32_t* __restrict__ n_valid, int64_t n_host, int S,
                                     const float* __restrict__ z_vals, const float* __restrict__ sdf,
                                     const float* __restrict__ depth_sample, float kf_dist_th,
@@ -92,18 +95,21 @@ __global__ void render_depth_kernel(const int32_t* __restrict__ n_valid, int64_t
   const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   bool below = false;
   if (r < R) {
-    float z[MAXS], s[MAXS];
-    for (int k = 0; k < S; ++k) { z[k] = z_vals[r * S + k]; s[k] = sdf[r * S + k]; }
-    for (int a = 1; a < S; ++a) {
-      const float zk = z[a], sk = s[a];
-      int b = a - 1;
-      while (b >= 0 && z[b] > zk) { z[b + 1] = z[b]; s[b + 1] = s[b]; --b; }
-      z[b + 1] = zk; s[b + 1] = sk;
+    const float* z = z_vals + r * S;
+    const float* s = sdf + r * S;
+    int cn = -1, ca = 0;                 // first-in-sorted-order among the negative samples / among all samples
+    float zn = 0.f, za = z[0];
+    for (int k = 0; k < S; ++k) {
+      const float zk = z[k];
+      if (zk < za) { za = zk; ca = k; }                          // strict: of equal z the earlier sample stays first (stable sort)
+      if (s[k] < 0.f && (cn < 0 || zk < zn)) { zn = zk; cn = k; }
     }
-    int ix = 0;
-    for (int k = S - 1; k >= 0; --k) if (s[k] < 0.f) ix = k;
-    float dpt = __fadd_rn(z[ix], s[ix]);
-    if (ix == S - 1) dpt = 0.f;
+    const int c = cn >= 0 ? cn : ca;
+    const float zc = cn >= 0 ? zn : za, sc = s[c];
+    int before = 0;                      // samples in front of c in the sorted order
+    for (int k = 0; k < S; ++k) before += (z[k] < zc || (z[k] == zc && k < c)) ? 1 : 0;
+    float dpt = __fadd_rn(zc, sc);
+    if (before == S - 1) dpt = 0.f;
     view_depth[r] = dpt;
     if (depth_sample) {
       const float ds = depth_sample[r];
@@ -126,9 +132,8 @@ int launch_normals(const float* depth, int H, int W, float fx, float fy, float c
 int launch_render_depth(const int32_t* n_valid, int64_t n_host, int64_t max_rays, int S, const float* z,
                         const float* sdf, const float* depth_sample, float th, float* view, int32_t* below,
                         hipStream_t st) {
-  if (S > 64) return ISDF_EUNSUPPORTED;
   if (below && hipMemsetAsync(below, 0, 4, st) != hipSuccess) return ISDF_EHIP;
-  hipLaunchKernelGGL(render_depth_kernel<64>, dim3((unsigned)((max_rays + 127) / 128)), dim3(128), 0, st, n_valid,
+  hipLaunchKernelGGL(render_depth_kernel, dim3((unsigned)((max_rays + 127) / 128)), dim3(128), 0, st, n_valid,
                      n_host, S, z, sdf, depth_sample, th, view, below);
   return isdf_launch_status();
 }

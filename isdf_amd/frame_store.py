@@ -39,6 +39,16 @@ class FrameData:
         self._back = {}          # field name -> backing tensor (capacity >= len)
         self.host_losses = bool(host_losses)
 
+    @classmethod
+    def from_reference(cls, other, host_losses=True):
+        """a store holding the keyframes of `other` (the reference's data_util.FrameData, or anything with its attributes): the
+        tensors are shared, the growing buffers are allocated at the next append.  What graft() swaps in for `trainer.frames`."""
+        out = cls(host_losses=host_losses)
+        for k in _FIELDS + ("count",):
+            if hasattr(other, k):
+                setattr(out, k, getattr(other, k))
+        return out
+
     def __len__(self):
         return 0 if self.frame_id is None else len(self.frame_id)
 

@@ -6,6 +6,8 @@ reference `isdf.modules.trainer.Trainer` INSTANCE to the HIP kernels behind the 
     Trainer.sample_points       trainer.py:683-766
     Trainer.sdf_eval_and_loss   trainer.py:768-868   (+ total_loss.backward(), trainer.py:981)
     Trainer.is_keyframe         trainer.py:586-620   (fused sampler -> frozen net -> depth render)
+    Trainer.get_data            trainer.py:530-562   (the reference's own method runs; its two geometry calls -- depth -> point cloud ->
+                                                      8-neighbour normals, transform.py:169-196,215-270 -- are ONE stencil launch)
 
 ONE object owns the state: every attribute the reference's drivers and its own remaining methods read or
 write -- `tot_step_time`, `steps_since_frame`, `optim_frames`, `last_is_keyframe`, `noise_std`, `frames`,
@@ -13,7 +15,9 @@ write -- `tot_step_time`, `steps_since_frame`, `optim_frames`, `last_is_keyframe
 trainer.py:574-650,1011-1014) -- stays on the `Trainer` instance; the methods here only use `self.<name>`
 with the reference's names.  `trainer.sdf_map` becomes an `SDFMapHIP` (a real nn.Module with the
 reference's state_dict keys whose parameters are views of one flat buffer), `trainer.optimiser` a facade
-with the `torch.optim.AdamW` surface.  Everything else (`get_data`, `add_frame`,
+with the `torch.optim.AdamW` surface, `trainer.frames` an `isdf_amd.frame_store.FrameData` (the reference's fields and
+`add_frame_data` contract on geometrically growing buffers instead of one `torch.cat` of the whole keyframe set per frame,
+data_util.py:84-102; the existing keyframes migrate).  Everything else (`add_frame`, `add_data`,
 `check_keyframe_latest`, `select_keyframes`, evaluation, visualisation) keeps running as the
 reference's own code on the same object.
 
@@ -23,13 +27,16 @@ this package) restates the driver-side methods; its `HipTrainer` is `graft()` ap
 There is no CPU fallback: without the HIP library or a HIP device `graft` raises.
 """
 import copy
+import ctypes
+import os
+import sys
 import types
 
 import numpy as np
 import torch
 
-from . import _ffi, dp
-from .engine import LossConfig, SampleConfig
+from . import _ffi, dp, frame_store
+from .engine import LossConfig, NetConfig, SampleConfig
 from .modules import PositionalEncodingHIP, SDFMapHIP
 
 
@@ -490,6 +497,40 @@ class HotPath:
               self.kf_pixel_ratio, " ---> is keyframe:", is_keyframe)
         return is_keyframe
 
+    # ------------------------------------------------------------------ per-frame ingest (trainer.py:530-562)
+    def get_data(self, idxs):
+        """The reference's `get_data` runs unchanged (dataset access, host twins, `T_WC_gt`, its own `FrameData` per frame); for the
+        duration of the call its two geometry functions are answered by the stencil kernel: `pointcloud_from_depth_torch`
+        (transform.py:169-196) hands over the depth image, `estimate_pointcloud_normals` (transform.py:215-270: eight shifted
+        cross products through a 70 MB index tensor, ~10 eager kernels) becomes ONE launch of `isdf_estimate_normals` -- same
+        camera-frame normals, NaN where the reference leaves NaN (fixture `ingest_small`).  With a 0.3 ms step and
+        iters_per_frame = 10 a frame arrives every ~3 ms of stepping: the eager chain was a visible share of that."""
+        geo = self._hip.geometry_transform
+        if not self.do_normal or geo is None:      # (no normals wanted, or not the reference's trainer module)
+            return super().get_data(idxs)
+        eng, hip = self.engine, self._hip
+
+        class _DepthAsPointCloud:          # what the first call hands to the second
+            def __init__(self, depth, fx, fy, cx, cy):
+                self.depth, self.k = depth, (fx, fy, cx, cy)
+
+        def pointcloud_from_depth(depth, fx, fy, cx, cy):
+            return _DepthAsPointCloud(depth, fx, fy, cx, cy)
+
+        def estimate_normals(pc):
+            if not isinstance(pc, _DepthAsPointCloud):      # some other caller's point cloud: the reference's own arithmetic
+                return saved[1](pc)
+            fx, fy, cx, cy = pc.k
+            hip.ingest_launches += 1
+            return eng.estimate_normals(pc.depth, SampleConfig(H=int(pc.depth.shape[0]), W=int(pc.depth.shape[1]),
+                                                               fx=float(fx), fy=float(fy), cx=float(cx), cy=float(cy)))
+        saved = (geo.pointcloud_from_depth_torch, geo.estimate_pointcloud_normals)
+        geo.pointcloud_from_depth_torch, geo.estimate_pointcloud_normals = pointcloud_from_depth, estimate_normals
+        try:
+            return super().get_data(idxs)
+        finally:
+            geo.pointcloud_from_depth_torch, geo.estimate_pointcloud_normals = saved
+
     # ------------------------------------------------------------------ data parallel (SURVEY 8e, C2)
     def check_keyframe_latest(self):
         """The reference's decision logic (trainer.py:622-650) runs unchanged; under data parallelism rank 0's
@@ -591,18 +632,44 @@ UNSUPPORTED_HINT = ("isdf_amd hot path: %s (the reference's own Python path is t
                     "this build ships no second implementation)")
 
 
+def unsupported_reason(trainer):
+    """None, or why the kernels cannot take this trainer's CONFIGURATION (such configs keep running on the reference's
+    own Python path -- `can_graft` says no, nothing raises): `bounds_method="normal"` (loss.py:29), `do_active` (trainer.py:718), a
+    loss_type other than L1 / L2 (loss.py:104), a network shape the tile kernels are not instantiated for (`isdf_check_net`)."""
+    if getattr(trainer, "bounds_method", "ray") not in ("ray", "pc"):
+        return "bounds_method %r (only 'ray' and 'pc' can run upstream, loss.py:29)" % (trainer.bounds_method,)
+    if getattr(trainer, "do_active", False):
+        return "active sampling (rejected by the reference itself, trainer.py:718)"
+    if getattr(trainer, "loss_type", "L1") not in ("L1", "L2"):
+        return "loss_type %r (loss.py:104)" % (trainer.loss_type,)
+    net = getattr(trainer, "sdf_map", None)
+    if net is not None and not isinstance(net, SDFMapHIP) and ENGINE_FACTORY is None and os.path.exists(_ffi.LIB_PATH):
+        try:
+            pe = net.positional_encoding
+            c = NetConfig(hidden=net.out_alpha.in_features, blocks=len(net.mid1), n_freqs=int(pe.n_freqs)).to_c()
+        except AttributeError:
+            return "trainer.sdf_map is not an isdf.modules.fc_map.SDFMap"
+        rc = _ffi.lib().isdf_check_net(ctypes.byref(c))
+        if rc != 0:
+            return "network shape (hidden %d, %d blocks, %d octaves): %s" % (c.hidden, c.blocks, c.n_freqs,
+                                                                              _ffi.lib().isdf_error_string(int(rc)).decode())
+    return None
+
+
 def can_graft(trainer):
-    """True when `graft(trainer)` can bind the kernels: the trainer sits on a HIP device and libisdf_hip.so is built.  The guard
-    INTEGRATION.md puts in front of graft(): on a CPU-only host (BASELINE configs[0]) the reference's own Python path keeps
-    running -- this package ships no second implementation and graft() itself raises there."""
+    """True when `graft(trainer)` can bind the kernels: the trainer sits on a HIP device, libisdf_hip.so is built and the
+    configuration is one the kernels take (`unsupported_reason`).  The guard INTEGRATION.md puts in front of graft(): wherever it says
+    no -- a CPU-only host (BASELINE configs[0]), `bounds_method="normal"`, `do_active`, an uninstantiated network shape -- the
+    reference's own Python path keeps running; this package ships no second implementation, and graft() itself raises there."""
+    if unsupported_reason(trainer) is not None:
+        return False
     if ENGINE_FACTORY is not None:          # host-logic tests with a stand-in engine
         return True
-    import os
     return torch.device(trainer.device).type == "cuda" and torch.cuda.is_available() and os.path.exists(_ffi.LIB_PATH)
 
 
 def graft(trainer, rng="philox", seed=1, dist_group=None, fix_normal_window=False, fwd_operand="fp16x2",
-          fuse_optimiser=True, virtual_step_ms=None, engine_factory=None, overlap_allreduce=False, bwd_operand=None, spill_operand=None):
+          fuse_optimiser=True, virtual_step_ms=None, engine_factory=None, overlap_allreduce=False, bwd_operand=None, spill_operand=None, migrate_frames=True):
     """Re-bind the hot path of `trainer` (an `isdf.modules.trainer.Trainer` or a `StandinTrainer`) to the HIP
     kernels, IN PLACE, and return it.
 
@@ -616,6 +683,8 @@ def graft(trainer, rng="philox", seed=1, dist_group=None, fix_normal_window=Fals
     spill_operand: None (auto) | "16bit" | "e4m3": storage of the spilled P / GB tensors (engine.NetConfig.spill_operand).
     overlap_allreduce: data parallel only -- the closing reduction in two launches and the all-reduce in two parts, the first
          one on a side stream beside the second launch (dp.allreduce_split_); two collectives per step instead of one.
+    migrate_frames: replace `trainer.frames` (the reference's FrameData: one torch.cat of the whole keyframe set per frame,
+         data_util.py:84-102) by an `isdf_amd.frame_store.FrameData` holding the same keyframes (False: keep the caller's store).
     engine_factory: tests only (a stand-in engine for hosts without a GPU)."""
     if isinstance(trainer, HotPath) and getattr(trainer, "_hip", None) is not None:
         return trainer
@@ -628,10 +697,9 @@ def graft(trainer, rng="philox", seed=1, dist_group=None, fix_normal_window=Fals
         dev = torch.device("cuda", torch.cuda.current_device())
     if engine_factory is None and dev.type != "cuda":
         raise _ffi.IsdfError(UNSUPPORTED_HINT % ("device %r is not a HIP device" % (trainer.device,)))
-    if trainer.bounds_method not in ("ray", "pc"):
-        raise _ffi.IsdfError(UNSUPPORTED_HINT % "bounds_method 'normal' cannot run upstream either (loss.py:29)")
-    if getattr(trainer, "do_active", False):
-        raise _ffi.IsdfError(UNSUPPORTED_HINT % "active sampling is rejected by the reference itself (trainer.py:718)")
+    why = unsupported_reason(trainer)
+    if why is not None:                # (can_graft() is the non-raising form: the reference's path then stays in place)
+        raise _ffi.IsdfError(UNSUPPORTED_HINT % why)
     if rng not in ("philox", "torch"):
         raise ValueError("rng must be 'philox' or 'torch'")
 
@@ -671,6 +739,13 @@ def graft(trainer, rng="philox", seed=1, dist_group=None, fix_normal_window=Fals
                                 virtual_step_ms=None if virtual_step_ms is None else float(virtual_step_ms),
                                 loss_host=torch.zeros(8, dtype=torch.float32,
                                                       pin_memory=(dev.type == "cuda")))
+    # the module whose two geometry functions get_data() redirects: `geometry.transform` as the reference's trainer module sees it
+    geo = getattr(getattr(sys.modules.get(trainer.__class__.__module__), "geometry", None), "transform", None)
+    hip.geometry_transform = geo if (geo is not None and hasattr(geo, "pointcloud_from_depth_torch")
+                                     and hasattr(geo, "estimate_pointcloud_normals")) else None
+    hip.ingest_launches = 0
+    if migrate_frames and getattr(trainer, "frames", None) is not None and not isinstance(trainer.frames, frame_store.FrameData):
+        trainer.frames = frame_store.FrameData.from_reference(trainer.frames)     # same fields, the existing keyframes carried over
     trainer._hip = hip
     base = trainer.__class__
     if not issubclass(base, HotPath):

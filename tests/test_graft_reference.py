@@ -228,8 +228,22 @@ def test_reference_driver_loop_on_grafted_reference_trainer(ref_mods):
     _check_schedule(tr, n, ingests, log, 12.0, 30, 3, 0.08, 0.04)
     assert isinstance(tr.frozen_sdf_map, SDFMapHIP) and tr.frozen_sdf_map is not tr.sdf_map   # deepcopy at trainer.py:576
     assert tr.frozen_sdf_map.engine is not tr.sdf_map.engine
-    assert tr.frames.normal_batch.shape[0] == len(tr.frames)         # normals from the reference's get_data
-    assert type(tr.frames) is FrameData
+    assert tr.frames.normal_batch.shape[0] == len(tr.frames)
+    # the ingest is bound (round 6): graft() swapped the keyframe store for the growing one ...
+    from isdf_amd import frame_store
+    assert isinstance(tr.frames, frame_store.FrameData) and not isinstance(tr.frames, FrameData)
+    # ... and the reference's own get_data ran with its two geometry calls answered by the engine: one launch per ingested frame,
+    assert tr._hip.ingest_launches == len(ingests) >= 4
+    geo = mods[5] if hasattr(mods[5], "estimate_pointcloud_normals") else sys.modules["isdf.geometry.transform"]
+    assert geo.estimate_pointcloud_normals.__module__ == "isdf.geometry.transform"      # (the redirect is undone after every call)
+    # with the normals the reference computes for the same depth images (transform.py:169-196,215-270)
+    for k, fid in enumerate(int(i) for i in tr.frames.frame_id):
+        d = torch.from_numpy(depth[fid])
+        ref = geo.estimate_pointcloud_normals(geo.pointcloud_from_depth_torch(d, tr.fx, tr.fy, tr.cx, tr.cy)).numpy()
+        got = tr.frames.normal_batch[k].numpy()
+        assert np.array_equal(np.isnan(ref), np.isnan(got)), fid
+        ok = ~np.isnan(ref)
+        assert np.abs(ref[ok] - got[ok]).max() < 2e-5, (fid, np.abs(ref[ok] - got[ok]).max())
 
 
 def test_reference_driver_loop_on_hiptrainer_standin():

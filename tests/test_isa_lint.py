@@ -50,5 +50,7 @@ def test_hot_kernels_keep_their_register_budgets():
     assert len(hot) >= 40, len(hot)
     for k, v in hot.items():
         assert v["scratch"] == 0 and v["vgpr_spill"] == 0, (k, v)
+    # round 6: NO kernel of the library uses scratch memory (the keyframe test's per-ray sort was the last one: ingest.hip)
+    assert not {k: v for k, v in res.items() if v["scratch"] or v["vgpr_spill"]}
     two_per_cu = [v["vgpr"] for k, v in hot.items() if "chain_kernelILi256ELi256ELi" in k and "ELi256ELi3E" not in k]    # (OPER 3: one per CU)
     assert len(two_per_cu) >= 9 and max(two_per_cu) <= 128, two_per_cu
