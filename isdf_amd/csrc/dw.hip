@@ -15,6 +15,7 @@
 // and written to LDS after the barrier (issue-early / write-late).
 #include "isdf_common.h"
 #include "chain_params.h"
+#include "chain_dev.h"
 
 namespace isdf {
 
@@ -24,11 +25,13 @@ namespace isdf {
 
 template <int HD> struct DwTile {
   static constexpr int BM = DW_PTS;
+  static constexpr int NT = 256;                  // threads: four waves, ONE per SIMD, up to 512 registers each (see dw_kernel)
   static constexpr int ROWB = DW_BLK * 2 + 64;    // padded LDS row (bytes) of a 256-column operand slice
   static constexpr int TEN = BM * ROWB;           // one operand slice in LDS
   static constexpr int AUXB = BM * 32;            // one tile's pe_aux rows (8 floats per point)
-  static constexpr int LDS_BYTES = 4 * TEN + 2 * AUXB;   // two operand slices x two stage buffers + two tiles of pe_aux
-  static constexpr int CH = (BM * DW_BLK * 2) / (512 * 16);  // uint4 per thread per tensor
+  static constexpr int DIRTAB = 4 * TEN + 2 * AUXB;      // the 21 directions / 2 pi, 16 bytes each (PE units)
+  static constexpr int LDS_BYTES = DIRTAB + 512;         // two operand slices x two stage buffers + two tiles of pe_aux + the directions
+  static constexpr int CH = (BM * DW_BLK * 2) / (NT * 16);  // uint4 per thread per 16-bit tensor (8); an e4m3 tensor has half
 };
 
 // Piece c (16 B = 8 elems) of the 64-point half `half`, 256-feature slice `sl` of a chain tile
@@ -46,28 +49,32 @@ __device__ __forceinline__ int frag16_piece(int c, int half, int sl, int& pt, in
   return ((((sl * 8 + blk) * PB + half * HB + pbh) * 2 + qp) * 64 + lane);
 }
 
-// F16: the spilled operands are fp16 (NetLayout::bwd_f16) instead of bf16 -- the same bits through the same transpose reads,
-// v_mfma_f32_32x32x16_f16 instead of _bf16.
+// F16: the spilled 16-bit operands are fp16 (NetLayout::bwd_f16) instead of bf16.  SP8: NetLayout::sp8 (bit 0: GB spilled as e4m3,
+// bit 1: P below the top layer) -- a launch constant, so every stage's format is known at compile time.
 //
-// Units whose input-side operand is embedding-shaped (layer 0, and the embedding columns of the cat layer) do not READ it
-// (round 6): both operands of such a unit's input side -- the embedding of stage q = 0 and Ebar = J_pe gbar of stage q = 1 -- are
-// functions of six floats per point (x' and gbar in x' space, `pe_aux`, written by the chain kernel's loss stage), so the
-// workgroup rebuilds the 64 x 256 slice in LDS: a thread owns two adjacent columns (its direction, octave and phase are
-// fixed for the whole kernel) and walks 16 points.  The arithmetic is the chain kernel's PE / Ebar stage value for value
-// (same expression shapes, `fr` a power of two), so the operand bits equal what that kernel used to spill.  4 of the 28 tensor
-// reads of a step and 2 of the chain kernel's 25 tensor stores are gone (82 MB of 1.245 GB per 27 k-point step).
-// SP8: NetLayout::sp8 (bit 0: GB spilled as e4m3, bit 1: P below the top layer) -- a launch constant, so the format of every stage is
-// known at compile time and the register sets are sized for it (the kernel sits at the 256-register limit).
+// Round 6, second version: FOUR waves, one per SIMD.  The first version (eight waves, two per SIMD, 256 registers each) spent
+// ~3.1 us per 64-point stage whatever the bytes -- the top layer's 32 workgroups alone took as long as all 255 together
+// (profiles/r06_dw_unit_kinds.txt): every wave ran 4 x [12 transpose reads -> wait -> 8 MFMAs] with no read-ahead across k-steps (its
+// 24 operand registers were single-buffered beside a 128-register accumulator), all eight committed the next stage's 64 KB to LDS in
+// front of the first MFMA, and the matrix pipe was 39 % busy.  With one wave per SIMD a wave owns a 128 x 128 quadrant (256 accumulator
+// registers), reads the NEXT k-step's operands while the current one's 16 MFMAs run (2 x 32 registers), feeds every A fragment to four
+// MFMAs instead of two (a third fewer LDS reads), and has the registers to hang the next stage's commit, its reload and -- for the
+// units that rebuild their embedding-shaped operand -- the PE fill behind the MFMAs of the running stage, a slice per k-step.
+//
+// Units whose input-side operand is embedding-shaped (layer 0, and the embedding columns of the cat layer) do not READ it: the
+// embedding of the even stage and Ebar = J_pe gbar of the odd stage are functions of six floats per point (x' and gbar in x' space,
+// `pe_aux`, written by the chain kernel's loss stage), so the workgroup rebuilds the 64 x 256 slice in LDS (see run()).
 template <int HD, bool F16, int SP8>
-__global__ __launch_bounds__(512, 2) void dw_kernel(const DwParams p) {
+__global__ __launch_bounds__(256, 1) void dw_kernel(const DwParams p) {
   typedef DwTile<HD> T;
-  constexpr int BM = T::BM, ROWB = T::ROWB, CH = T::CH;
+  constexpr int BM = T::BM, ROWB = T::ROWB, CH = T::CH, NT = T::NT;
   static_assert(TILE_PTS == DW_PTS, "pe_aux staging below assumes one dW stage pair per chain tile");
+  static_assert(CH == 8 && BM / 16 == 4, "two 16-bit chunks (one e4m3 chunk) ride behind each of the four k-steps");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const NetLayout& L = p.lay;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int wo = w >> 1, wi = w & 1;
-  // block -> (unit, K-split): units have 32 or 48 splits (isdf_common.h)
+  const int wo = w >> 1, wi = w & 1;               // this wave's 128 x 128 quadrant of the unit
+  // block -> (unit, K-split): units have 35 or 40 splits (isdf_common.h)
   int unit = 0, split = blockIdx.x;
   for (int n; split >= (n = dw_unit_splits(L, unit)); ++unit) split -= n;
   const int DW_SPLITK = dw_unit_splits(L, unit);
@@ -81,20 +88,20 @@ __global__ __launch_bounds__(512, 2) void dw_kernel(const DwParams p) {
   const int slA = du.ob;
 
   const int64_t P = p.n_valid ? (int64_t)(*p.n_valid) * p.S : p.n_points_host;
-  constexpr int HALVES = TILE_PTS / DW_PTS;
-  const int nTiles = (int)((P + TILE_PTS - 1) / TILE_PTS) * HALVES;   // 64-point half tiles
+  const int nTiles = (int)((P + TILE_PTS - 1) / TILE_PTS);
 
   // stage q of tile t: q=0 -> (ZB[li], I), q=1 -> (P[li], GB).  Stage parity = q = register set = LDS buffer: the even stages'
-  // operands are 16-bit tiles (4 x 16 B per thread and tensor), the odd stages' are e4m3 (2 x 16 B; SpillLayout), converted to the
-  // 16-bit MFMA operand type on their way into LDS -- P times 2^-10, GB times the point's scale s_G (pe_aux[7]).
+  // operands are 16-bit tiles (8 x 16 B per thread and tensor), the odd stages' are e4m3 where the format says so (4 x 16 B;
+  // SpillLayout), converted to the 16-bit MFMA operand type on their way into LDS -- P times 2^-10, GB times the point's scale s_G
+  // (pe_aux[7]).
   const int64_t offZ = p.sp.ZB[li], offP = p.sp.P[li];
   const int64_t offI = fromEmb ? 0 : p.sp.A[li];
   const int64_t offG = fromEmb ? 0 : p.sp.GB[li];
   constexpr int CH8 = CH / 2;
 
-  f32x16 acc[2][4];
+  f32x16 acc[4][4];
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < 4; ++a)
 #pragma unroll
     for (int b = 0; b < 4; ++b)
 #pragma unroll
@@ -110,79 +117,120 @@ __global__ __launch_bounds__(512, 2) void dw_kernel(const DwParams p) {
   const int s16 = lane & 15, cg = (lane >> 4) & 1, hi = lane >> 5;
   const int trRow = 8 * hi + (s16 >> 2);
   const int trColB = (16 * cg + 4 * (s16 & 3)) * 2;
+  // LDS layout of an operand slice: row-major [point][256 features], rows padded to ROWB, and the 8-byte chunk index of a row XORed
+  // with swz(row) = (row >> 1) & 7.  The padding (16 banks per row) spreads the four rows of a transpose read over the 64 banks; the
+  // XOR does the same for the COMMIT, whose ds_write_b64 serves 16 consecutive lanes = 16 consecutive points at one column per LDS
+  // cycle group: without it those land on two bank pairs of the stores' 32 (8-way: 32 LDS cycles per store instead of 4, ~4 000 of
+  // them per 64-point stage -- what the first version of this kernel was actually bound by).  A transpose read covers whole aligned
+  // groups of eight chunks per row, so the XOR only changes which lane reads which chunk of the same bank set.
+  const int trX = ((trRow >> 1) & 7) << 3;
+  const int trOffA = trRow * ROWB + (trColB ^ trX), trOffB = (trRow + 4) * ROWB + (trColB ^ trX ^ 16);
+  // where this thread's pieces go (chunk 0; see put16 / put8 in run()): a frag16 piece c NT + tid is point pt16, features f16.. and
+  // f16 + 8..; a frag8 piece is points ln & 31 and 32 + (ln & 31), features f8.. and f8 + 8.. (rows pt and pt + 32 share swz)
+  int pt16, f16;
+  const int vo16 = frag16_piece(tid, 0, 0, pt16, f16) * 16, vo8 = tid * 16;      // ... and where they come from (byte offsets in a tile slice)
+  const int wr16A = pt16 * ROWB + ((f16 * 2) ^ (((pt16 >> 1) & 7) << 3)), wr16B = wr16A ^ 16;
+  const int f8 = (w >> 1) * 32 + 16 * (w & 1) + 4 * (lane >> 5);
+  const int wr8A = (lane & 31) * ROWB + ((f8 * 2) ^ ((((lane & 31) >> 1) & 7) << 3)), wr8B = wr8A ^ 16;
   typedef bf16x4 __attribute__((address_space(3))) * lds4;
   auto trload = [&](const char* base, int ptBase, int colElem) -> bf16x8 {
-    const char* a0 = base + (ptBase + trRow) * ROWB + colElem * 2 + trColB;
-    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4)(a0));
-    bf16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4)(a0 + 4 * ROWB));
+    const char* a0 = base + ptBase * ROWB + colElem * 2;      // (ptBase: a multiple of 16, colElem of 32: above the swizzled bits)
+    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4)(a0 + trOffA));
+    bf16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4)(a0 + trOffB));
     bf16x8 r;
     r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
     r[4] = hi4[0]; r[5] = hi4[1]; r[6] = hi4[2]; r[7] = hi4[3];
     return r;
   };
-  auto compute = [&](int buf) {
-    const char* sb = smem + buf * 2 * T::TEN;
+  // One stage = four k-steps of 16 points = eight HALF-steps of 8 MFMAs (two of the wave's four 32-row blocks x its four 32-column
+  // blocks).  Operand fragments are read one half-step ahead -- the two A fragments of the next half-step, and during the second
+  // half of a k-step the four B fragments of the next k-step -- 48 registers instead of the 64 of a whole k-step of read-ahead.
+  // `between(ks, h)` is the slice of the NEXT stage's way into the other LDS buffer (and of its registers' reload) that rides
+  // behind the MFMAs of half-step (ks, h).
+  typedef typename Op<F16>::v8 opv8;
+  auto loadA = [&](const char* sb, int ks, int h, bf16x8 (&a)[2]) {
+    a[0] = trload(sb, ks * 16, wo * 128 + (2 * h) * 32); a[1] = trload(sb, ks * 16, wo * 128 + (2 * h + 1) * 32);
+  };
+  auto loadB = [&](const char* sb, int ks, bf16x8 (&b)[4]) {
 #pragma unroll
-    for (int ks = 0; ks < BM / 16; ++ks) {
-      bf16x8 a[2], b[4];
+    for (int ib = 0; ib < 4; ++ib) b[ib] = trload(sb + T::TEN, ks * 16, wi * 128 + ib * 32);
+  };
+  auto mfmas = [&](auto hTag, const bf16x8 (&a)[2], const bf16x8 (&b)[4]) {
+    constexpr int h = decltype(hTag)::value;
 #pragma unroll
-      for (int ob = 0; ob < 2; ++ob) a[ob] = trload(sb, ks * 16, wo * 64 + ob * 32);
+    for (int o2 = 0; o2 < 2; ++o2)
 #pragma unroll
-      for (int ib = 0; ib < 4; ++ib) b[ib] = trload(sb + T::TEN, ks * 16, wi * 128 + ib * 32);
+      for (int ib = 0; ib < 4; ++ib)
+        acc[2 * h + o2][ib] = Op<F16>::mfma(__builtin_bit_cast(opv8, a[o2]), __builtin_bit_cast(opv8, b[ib]), acc[2 * h + o2][ib]);
+  };
+  // ONE wave per SIMD: nothing but the wave's own instruction order overlaps its MFMAs with anything.  Left to itself the compiler
+  // emits a half-step as [8 MFMAs][everything else] -- each MFMA waits 32 cycles for the pipe behind the previous one, nothing else
+  // issues meanwhile, and the rest then runs beside an idle matrix pipe (PMC: issue + issue-wait = twice the MFMA time).  So every
+  // half-step is its own scheduling region, laid out as 8 x [1 MFMA | <= 2 LDS reads | <= NW LDS writes | <= NV VALU | <= 1 load].
+  auto pipeline = [&](auto nvTag, auto nwTag) {
 #pragma unroll
-      for (int ob = 0; ob < 2; ++ob)
-#pragma unroll
-        for (int ib = 0; ib < 4; ++ib)
-          acc[ob][ib] = Op<F16>::mfma(__builtin_bit_cast(typename Op<F16>::v8, a[ob]), __builtin_bit_cast(typename Op<F16>::v8, b[ib]),
-                                      acc[ob][ib]);
+    for (int i = 0; i < 8; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x200, decltype(nwTag)::value, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, decltype(nvTag)::value, 0);
+      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
     }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto compute = [&](int buf, auto nvTag, auto nwTag, auto&& between0) {
+    auto between = [&](auto ks, auto h) { between0(ks, h); pipeline(nvTag, nwTag); };
+    const char* sb = smem + buf * 2 * T::TEN;
+    typedef std::integral_constant<int, 0> I0; typedef std::integral_constant<int, 1> I1;
+    typedef std::integral_constant<int, 2> I2; typedef std::integral_constant<int, 3> I3;
+    bf16x8 a0[2], a1[2], b0[4], b1[4];
+    loadB(sb, 0, b0); loadA(sb, 0, 0, a0);
+    loadA(sb, 0, 1, a1);                        mfmas(I0{}, a0, b0); between(I0{}, I0{});
+    loadB(sb, 1, b1); loadA(sb, 1, 0, a0);      mfmas(I1{}, a1, b0); between(I0{}, I1{});
+    loadA(sb, 1, 1, a1);                        mfmas(I0{}, a0, b1); between(I1{}, I0{});
+    loadB(sb, 2, b0); loadA(sb, 2, 0, a0);      mfmas(I1{}, a1, b1); between(I1{}, I1{});
+    loadA(sb, 2, 1, a1);                        mfmas(I0{}, a0, b0); between(I2{}, I0{});
+    loadB(sb, 3, b1); loadA(sb, 3, 0, a0);      mfmas(I1{}, a1, b0); between(I2{}, I1{});
+    loadA(sb, 3, 1, a1);                        mfmas(I0{}, a0, b1); between(I3{}, I0{});
+                                                mfmas(I1{}, a1, b1); between(I3{}, I1{});
   };
 
-  // The stage pipeline, once per kind of unit (PE: the input-side operand is rebuilt from pe_aux, not loaded).
+  // The stage pipeline, once per kind of unit (PE: the input-side operand is rebuilt from pe_aux, not loaded; p8: this unit's P is e4m3).
   auto run = [&](auto pe_tag, auto p8_tag) {
     constexpr bool PE = decltype(pe_tag)::value;
     constexpr bool p8 = decltype(p8_tag)::value, g8 = SP8 & 1;     // this unit's P / GB are e4m3 tensors
     constexpr int CHA1 = p8 ? CH8 : CH, CHB1 = g8 ? CH8 : CH;
-    // Two register sets so TWO stages of global loads are in flight while one is computed
-    // (HBM-bound kernel: 64 KB per stage and CU; one stage in flight left ~40 % of the bandwidth unused).
+    // Two register sets so TWO stages of global loads are in flight while one is computed.
     uint4 regA0[CH], regB0[CH], regA1[CHA1], regB1[CHB1];
     float sG1[2] = {1.f, 1.f};        // s_G of this thread's two points (rows lane & 31 and 32 + (lane & 31)) of the odd stage in flight
-    typedef unsigned int u32x4n __attribute__((ext_vector_type(4)));
-    auto ntload = [](const uint4* q) {
-      const u32x4n v = __builtin_nontemporal_load((const u32x4n*)q);
-      return make_uint4(v[0], v[1], v[2], v[3]);
-    };
-    auto issue0 = [&](int st) {        // even stage: ZB and the layer input, 16-bit
+    // Every global load goes through a buffer descriptor (chain_dev.h): address = the TILE's descriptor (SGPRs, rebuilt per slice by
+    // the scalar unit) + ONE per-thread VGPR (vo16 / vo8: the thread's piece of chunk 0) + a scalar offset for slice and chunk.  With
+    // flat addresses the compiler keeps a 64-bit VGPR pair per chunk and tensor alive across the loop -- 48 registers this kernel
+    // does not have.  A 16-bit tile slice: 8 chunks of 4 KB (frag16_piece: chunk c is 32 features = 256 pieces behind chunk 0), slices
+    // 32 KB apart; an e4m3 slice: 4 chunks of 4 KB, slices 16 KB apart.
+    const int tileBytes = (int)p.sp.tileStride * 2;
+    auto tile_rsrc = [&](int64_t off, int t) { return make_rsrc(p.spill + off + (int64_t)t * p.sp.tileStride, (uint32_t)tileBytes); };
+    auto issue0 = [&](int st, auto cTag) {        // even stage: ZB and the layer input, 16-bit
+      constexpr int c = decltype(cTag)::value;
       const int t = split + (st >> 1) * DW_SPLITK;
-      const uint4* ta = (const uint4*)(p.spill + offZ + (int64_t)t * p.sp.tileStride);
-      const uint4* tb = (const uint4*)(p.spill + offI + (int64_t)t * p.sp.tileStride);
-#pragma unroll
-      for (int c = 0; c < CH; ++c) {
-        int pt, f0;
-        regA0[c] = ntload(ta + frag16_piece(c * 512 + tid, 0, slA, pt, f0));
-        if constexpr (!PE) regB0[c] = ntload(tb + frag16_piece(c * 512 + tid, 0, slB, pt, f0));
-      }
+      regA0[c] = bload16<kAuxNT>(tile_rsrc(offZ, t), vo16, slA * 32768 + c * 4096);
+      if constexpr (!PE) regB0[c] = bload16<kAuxNT>(tile_rsrc(offI, t), vo16, slB * 32768 + c * 4096);
     };
-    auto issue1 = [&](int st) {        // odd stage: P and GB -- e4m3 (frag8 pieces: 16 B = a lane's 8 values of both point blocks) or 16-bit
+    auto issue1 = [&](int st, auto ksTag, auto hTag) {       // odd stage, slice (ks, h): P and GB -- e4m3 (frag8 pieces: 16 B = a lane's 8 values of both point blocks; chunk ks, P at h = 0, GB at h = 1) or 16-bit (chunk 2 ks + h)
+      constexpr int ks = decltype(ksTag)::value, h = decltype(hTag)::value, c = 2 * ks + h;
       const int t = split + (st >> 1) * DW_SPLITK;
-      const uint4* ta = (const uint4*)(p.spill + offP + (int64_t)t * p.sp.tileStride);
-      const uint4* tb = (const uint4*)(p.spill + offG + (int64_t)t * p.sp.tileStride);
-      if constexpr (p8) {
-#pragma unroll
-        for (int c = 0; c < CH8; ++c) regA1[c] = ntload(ta + (slA * 16 + ((c * 512 + tid) >> 6)) * 64 + (tid & 63));
-      } else {
-#pragma unroll
-        for (int c = 0; c < CH; ++c) { int pt, f0; regA1[c] = ntload(ta + frag16_piece(c * 512 + tid, 0, slA, pt, f0)); }
-      }
+      if constexpr (p8) { if constexpr (h == 0) regA1[ks] = bload16<kAuxNT>(tile_rsrc(offP, t), vo8, slA * 16384 + ks * 4096); }
+      else regA1[c] = bload16<kAuxNT>(tile_rsrc(offP, t), vo16, slA * 32768 + c * 4096);
       if constexpr (!PE) {
         if constexpr (g8) {
-#pragma unroll
-          for (int c = 0; c < CH8; ++c) regB1[c] = ntload(tb + (slB * 16 + ((c * 512 + tid) >> 6)) * 64 + (tid & 63));
-          const float* aux = p.pe_aux + ((int64_t)t * BM + (tid & 31)) * 8 + 7;
-          sG1[0] = aux[0]; sG1[1] = aux[32 * 8];
+          if constexpr (h == 1) regB1[ks] = bload16<kAuxNT>(tile_rsrc(offG, t), vo8, slB * 16384 + ks * 4096);
+          if constexpr (ks == 3 && h == 1) {       // behind the LAST slice: the commit of the previous odd stage reads the old scales until then
+            const rsrc_t rx = make_rsrc(p.pe_aux + (int64_t)t * BM * 8, BM * 32);
+            sG1[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, (tid & 31) * 32 + 28, 0, 0));
+            sG1[1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, (tid & 31) * 32 + 28, 32 * 32, 0));
+          }
         } else {
-#pragma unroll
-          for (int c = 0; c < CH; ++c) { int pt, f0; regB1[c] = ntload(tb + frag16_piece(c * 512 + tid, 0, slB, pt, f0)); }
+          regB1[c] = bload16<kAuxNT>(tile_rsrc(offG, t), vo16, slB * 32768 + c * 4096);
         }
       }
     };
@@ -191,12 +239,12 @@ __global__ __launch_bounds__(512, 2) void dw_kernel(const DwParams p) {
       if constexpr (F16) return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp8((int)w8, scale, decltype(hiTag)::value));
       else return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8((int)w8, scale, decltype(hiTag)::value));
     };
-    // ---- PE units: a thread owns up to three (point, direction) ITEMS of a 64-point tile -- item = tid + 512 r, point = item / 21,
+    // ---- PE units: a thread owns up to six (point, direction) ITEMS of a 64-point tile -- item = tid + 256 r, point = item / 21,
     // direction = item % 21, the same for every stage -- and writes the direction's 2 n_freqs columns: sin / cos of octave 0 from the
     // hardware (in revolutions: the 1 / 2 pi lives in the direction constants), the higher octaves by angle doubling
     // (s' = 2 s c, c' = 1 - 2 s^2: 4 plain VALU operations per octave and pair instead of two projections and two transcendentals;
-    // <= 3e-6 from the direct value after 11 doublings, against an fp16 ulp of 5e-4).  Threads 320..383 of round r = 2 (which has
-    // only 320 items) write x' / gbar (features 0..2) and the zero padding of their point.
+    // <= 3e-6 from the direct value after 11 doublings, against an fp16 ulp of 5e-4).  Threads 64..127 of round r = 5 (which has
+    // only 64 items) write x' / gbar (features 0..2) and the zero padding of their point.
     //
     // Column order of the rebuilt operand.  ALIGNED (the embedding fits one 256-column slice and n_freqs is even: replicaCAD.json /
     // scanNet.json): [sin groups | cos groups | x' | padding] -- direction d's n_freqs sines start at column d n_freqs, a 4-byte
@@ -204,175 +252,186 @@ __global__ __launch_bounds__(512, 2) void dw_kernel(const DwParams p) {
     // 2 mod 4: twelve 2-byte stores per item and direction).  The dW columns come out in that order too; the slab store below puts
     // column i where the reference's column lives.  Otherwise (EP = 512: nine to eleven octaves) the reference's order, 2-byte stores.
     constexpr float kInv2Pi = 0.15915494309189535f, k2Pi = 6.283185307179586f;
-    float drx[3] = {0.f, 0.f, 0.f}, dry[3] = {0.f, 0.f, 0.f}, drz[3] = {0.f, 0.f, 0.f};
-    int itemOff[3] = {0, 0, 0};       // aligned order: (point * 32) << 16 | byte offset of the item's first column in the operand tile;
-                                      // reference order: point << 16 | (first column relative to the unit's slice) + 1024
+    constexpr int NR = (BM * N_DIRS + BM + NT - 1) / NT;      // rounds (6)
+    // (a round's point, direction and direction constants are re-derived where they are used -- two integer operations and one
+    // 16-byte LDS read of a 21-entry table -- instead of living in 24 registers across the stage loop)
     float4 auxr = make_float4(0.f, 0.f, 0.f, 0.f);
     if constexpr (PE) {
-      const int nf = L.n_freqs;
-#pragma unroll
-      for (int r = 0; r < 3; ++r) {
-        const int item = tid + 512 * r;
-        const bool dirItem = item < BM * N_DIRS;
-        const int pt = dirItem ? item / N_DIRS : (item - BM * N_DIRS) & (BM - 1), d = dirItem ? item - pt * N_DIRS : 0;
-        drx[r] = kDirs[0][d] * kInv2Pi; dry[r] = kDirs[1][d] * kInv2Pi; drz[r] = kDirs[2][d] * kInv2Pi;
-        itemOff[r] = peAligned ? ((pt * 32) << 16) | (pt * ROWB + (dirItem ? d * nf * 2 : 0))
-                               : (pt << 16) | ((dirItem ? 3 + d * nf - slBfull * DW_BLK : 0) + 1024);
-      }
+      if (tid < N_DIRS)
+        *(float4*)(smem + T::DIRTAB + tid * 16) = make_float4(kDirs[0][tid] * kInv2Pi, kDirs[1][tid] * kInv2Pi, kDirs[2][tid] * kInv2Pi, 0.f);
     }
     // pe_aux of the k-th tile of this workgroup: 64 points x 2 float4, one float4 per thread of the first two waves
-    auto load_aux = [&](int k) {
-      if (tid < 128 && 2 * k < nStages)
-        auxr = ((const float4*)p.pe_aux)[((int64_t)(split + k * DW_SPLITK)) * (BM * 2) + tid];
+    auto load_aux = [&](int k) {          // (unconditional, as every load of the pipeline: threads 128.. load a row they do not store)
+      k = min(k, nStages / 2 - 1);
+      const uint4 v = bload16<0>(make_rsrc(p.pe_aux + (int64_t)(split + k * DW_SPLITK) * BM * 8, BM * 32), (tid & 127) * 16, 0);
+      auxr = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
     };
     auto store_aux = [&](int k) {
       if (tid < 128) *(float4*)(smem + 4 * T::TEN + (k & 1) * T::AUXB + tid * 16) = auxr;
     };
-    auto put16 = [&](char* tile, const auto& r) {      // a 16-bit operand slice: frag16 pieces -> row-major LDS tile
-#pragma unroll
-      for (int c = 0; c < CH; ++c) {
-        int pt, f0;
-        frag16_piece(c * 512 + tid, 0, 0, pt, f0);
-        char* pa = tile + pt * ROWB + f0 * 2;
-        *(uint2*)(pa) = make_uint2(r[c].x, r[c].y);
-        *(uint2*)(pa + 16) = make_uint2(r[c].z, r[c].w);
-      }
+    auto put16 = [&](char* tile, const auto& r, auto cTag) {      // chunk c of a 16-bit operand slice: a frag16 piece -> row-major LDS tile
+      constexpr int c = decltype(cTag)::value;       // chunk c sits 32 features = 64 bytes (above the swizzled bits) behind chunk 0
+      *(uint2*)(tile + wr16A + c * 64) = make_uint2(r[c].x, r[c].y);
+      *(uint2*)(tile + wr16B + c * 64) = make_uint2(r[c].z, r[c].w);
     };
-    auto put8 = [&](char* tile, const auto& r, float s0, float s1) {   // an e4m3 slice, converted; s0 / s1: the scales of the lane's two points
-#pragma unroll
-      for (int c = 0; c < CH8; ++c) {
-        const int idx = c * 512 + tid, ln = idx & 63, rr = idx >> 6;
-        const int f0 = (rr >> 1) * 32 + 16 * (rr & 1) + 4 * (ln >> 5);       // elems 0..3 at features f0.., 4..7 at f0 + 8..
-        char* pa = tile + (ln & 31) * ROWB + f0 * 2;
-        const uint4 a = r[c];
-        *(uint2*)(pa) = make_uint2(cvt2(a.x, s0, std::false_type{}), cvt2(a.x, s0, std::true_type{}));
-        *(uint2*)(pa + 16) = make_uint2(cvt2(a.y, s0, std::false_type{}), cvt2(a.y, s0, std::true_type{}));
-        *(uint2*)(pa + 32 * ROWB) = make_uint2(cvt2(a.z, s1, std::false_type{}), cvt2(a.z, s1, std::true_type{}));
-        *(uint2*)(pa + 32 * ROWB + 16) = make_uint2(cvt2(a.w, s1, std::false_type{}), cvt2(a.w, s1, std::true_type{}));
-      }
+    auto put8 = [&](char* tile, const auto& r, float s0, float s1, auto cTag) {   // chunk c of an e4m3 slice, converted; s0 / s1: the scales of the lane's two points
+      constexpr int c = decltype(cTag)::value;       // chunk c: 64 features = 128 bytes behind chunk 0
+      const uint4 a = r[c];
+      *(uint2*)(tile + wr8A + c * 128) = make_uint2(cvt2(a.x, s0, std::false_type{}), cvt2(a.x, s0, std::true_type{}));
+      *(uint2*)(tile + wr8B + c * 128) = make_uint2(cvt2(a.y, s0, std::false_type{}), cvt2(a.y, s0, std::true_type{}));
+      *(uint2*)(tile + wr8A + 32 * ROWB + c * 128) = make_uint2(cvt2(a.z, s1, std::false_type{}), cvt2(a.z, s1, std::true_type{}));
+      *(uint2*)(tile + wr8B + 32 * ROWB + c * 128) = make_uint2(cvt2(a.w, s1, std::false_type{}), cvt2(a.w, s1, std::true_type{}));
     };
-    auto commit = [&](int st, int buf) {
-      char* sb = smem + buf * 2 * T::TEN;
-      if ((st & 1) == 0) {
-        put16(sb, regA0);
-        if constexpr (!PE) put16(sb + T::TEN, regB0);
-      } else {
-        if constexpr (p8) put8(sb, regA1, kSpillPScale, kSpillPScale); else put16(sb, regA1);
-        if constexpr (!PE) { if constexpr (g8) put8(sb + T::TEN, regB1, sG1[0], sG1[1]); else put16(sb + T::TEN, regB1); }
-      }
-      if constexpr (PE) {
-        // q = 0: the embedding (embedding.py:95-111): [x' | sin(xb_df) | cos(xb_df)], xb_df = (x' . dir_d) 2^f
-        // q = 1: Ebar = J_pe gbar (chain.hip's Ebar stage): [gbar | cos(xb_df) k_df | -sin(xb_df) k_df], k_df = (gbar . dir_d) 2^f
-        const char* auxl = smem + 4 * T::TEN + ((st >> 1) & 1) * T::AUXB;
-        char* tb = sb + T::TEN;
-        const int nf = L.n_freqs, halfE = N_DIRS * nf, colBase = slBfull * DW_BLK;
-        typedef typename Op<F16>::e eT;
-        typedef eT e2 __attribute__((ext_vector_type(2)));
-        auto st1 = [&](char* row, int col, float v) {            // one column; `col` relative to this unit's 256-column slice
-          if ((unsigned)col < (unsigned)DW_BLK) *(eT*)(row + col * 2) = (eT)v;
-        };
-        auto fill = [&](auto nfc, auto q1c) {
-          constexpr int NFT = decltype(nfc)::value;               // n_freqs at compile time: the ALIGNED column order (0: run-time loop, 2-byte stores)
-          constexpr bool Q1 = decltype(q1c)::value;
+    // round r of the PE fill of stage st (parity ODD) into its LDS buffer
+    auto fill_round = [&](int st, auto oddTag, auto rTag) {
+      constexpr bool Q1 = decltype(oddTag)::value;
+      constexpr int r = decltype(rTag)::value;
+      // q = 0: the embedding (embedding.py:95-111): [x' | sin(xb_df) | cos(xb_df)], xb_df = (x' . dir_d) 2^f
+      // q = 1: Ebar = J_pe gbar (chain.hip's Ebar stage): [gbar | cos(xb_df) k_df | -sin(xb_df) k_df], k_df = (gbar . dir_d) 2^f
+      const char* auxl = smem + 4 * T::TEN + ((st >> 1) & 1) * T::AUXB;
+      char* tb = smem + (Q1 ? 1 : 0) * 2 * T::TEN + T::TEN;
+      const int nf = L.n_freqs, halfE = N_DIRS * nf, colBase = slBfull * DW_BLK;
+      typedef typename Op<F16>::e eT;
+      typedef eT e2 __attribute__((ext_vector_type(2)));
+      auto st1 = [&](char* row, int xs, int col, float v) {    // one column; `col` relative to this unit's 256-column slice; xs: the row's swizzle
+        if ((unsigned)col < (unsigned)DW_BLK) *(eT*)(row + ((col * 2) ^ xs)) = (eT)v;
+      };
+      constexpr bool lastRound = r == NR - 1;
+      int it = tid + NT * r;                                      // item = (point, direction); the last round's threads 64.. : a point's x' row
+      asm volatile("" : "+v"(it));                                // (opaque: or the compiler hoists point / direction / addresses of all six rounds out of the stage loop and spills them)
+      const int pt = lastRound && it >= BM * N_DIRS ? (it - BM * N_DIRS) & (BM - 1) : it / N_DIRS, d = it - pt * N_DIRS;
+      const int xs = ((pt >> 1) & 7) << 3;                        // the row's swizzle
+      char* row = tb + pt * ROWB;
+      constexpr int lastItems = BM * N_DIRS - NT * (NR - 1);      // direction items of the last round (64)
+      auto item = [&](auto nfc) {
+        constexpr int NFT = decltype(nfc)::value;               // n_freqs at compile time: the ALIGNED column order (0: run-time loop, 2-byte stores)
+        const char* ax = auxl + pt * 32;
+        if (!lastRound || tid < lastItems) {
+          const float4 y = *(const float4*)ax;
+          const float4 dr = *(const float4*)(smem + T::DIRTAB + d * 16);
+          const float r0 = y.x * dr.x + y.y * dr.y + y.z * dr.z;
+          float sn = __builtin_amdgcn_sinf(r0), cs = __builtin_amdgcn_cosf(r0), kf = 0.f;
+          if constexpr (Q1) {
+            const float4 g = *(const float4*)(ax + 16);
+            kf = (g.x * dr.x + g.y * dr.y + g.z * dr.z) * k2Pi;
+          }
+          auto vals = [&](float& a, float& b) {        // this octave's two values, then on to the next octave
+            a = Q1 ? cs * kf : sn; b = Q1 ? -sn * kf : cs;
+            const float t = sn * cs;
+            cs = __builtin_fmaf(-2.f * sn, sn, 1.f); sn = t + t; kf += kf;
+          };
+          if constexpr (NFT == 0) {
+            const int cS = 3 + d * nf - colBase, cC = cS + halfE;      // first column of the sine / cosine group in this slice
+            for (int f = 0; f < nf; ++f) { float a, b; vals(a, b); st1(row, xs, cS + f, a); st1(row, xs, cC + f, b); }
+          } else {
+            static_assert(NFT % 2 == 0, "paired stores assume an even octave count");
+            const int cs0 = d * NFT * 2, cc0 = cs0 + N_DIRS * NFT * 2;    // 4-byte aligned: column d * NFT of row pt
 #pragma unroll
-          for (int r = 0; r < 3; ++r) {
-            // (opaque to the optimiser: derived per-item addresses hoisted out of the stage loop would sit in registers next to the
-            // 128 of the accumulator for the whole kernel -- one packed word per round does)
-            int io = itemOff[r];
-            asm volatile("" : "+v"(io));
-            const char* ax = auxl + (NFT ? (io >> 16) : (io >> 16) * 32);
-            if (r < 2 || tid < BM * N_DIRS - 1024) {
-              const float4 y = *(const float4*)ax;
-              const float r0 = y.x * drx[r] + y.y * dry[r] + y.z * drz[r];
-              float sn = __builtin_amdgcn_sinf(r0), cs = __builtin_amdgcn_cosf(r0), kf = 0.f;
-              if constexpr (Q1) {
-                const float4 g = *(const float4*)(ax + 16);
-                kf = (g.x * drx[r] + g.y * dry[r] + g.z * drz[r]) * k2Pi;
-              }
-              auto vals = [&](float& a, float& b) {        // this octave's two values, then on to the next octave
-                a = Q1 ? cs * kf : sn; b = Q1 ? -sn * kf : cs;
-                const float t = sn * cs;
-                cs = __builtin_fmaf(-2.f * sn, sn, 1.f); sn = t + t; kf += kf;
-              };
-              if constexpr (NFT == 0) {
-                char* row = tb + (io >> 16) * ROWB;
-                const int cS = (io & 0xffff) - 1024, cC = cS + halfE;      // first column of the sine / cosine group in this slice
-                for (int f = 0; f < nf; ++f) { float a, b; vals(a, b); st1(row, cS + f, a); st1(row, cC + f, b); }
-              } else {
-                static_assert(NFT % 2 == 0, "paired stores assume an even octave count");
-                char* ps = tb + (io & 0xffff);                       // 4-byte aligned: column d * NFT of row pt
-                char* pc = ps + N_DIRS * NFT * 2;
-#pragma unroll
-                for (int f = 0; f < NFT; f += 2) {
-                  float a, b, a2, b2;
-                  vals(a, b); vals(a2, b2);
-                  e2 vs, vc; vs[0] = (eT)a; vs[1] = (eT)a2; vc[0] = (eT)b; vc[1] = (eT)b2;
-                  *(e2*)(ps + f * 2) = vs; *(e2*)(pc + f * 2) = vc;
-                }
-              }
-            } else if (tid < BM * N_DIRS - 1024 + BM) {
-              char* row = tb + (NFT ? (io >> 16) >> 5 : (io >> 16)) * ROWB;
-              const float4 v = *(const float4*)(ax + (Q1 ? 16 : 0));
-              if constexpr (NFT != 0) {      // aligned order: x' behind the 42 n_freqs sine / cosine columns, then the padding
-                e2 v01, v2z; v01[0] = (eT)v.x; v01[1] = (eT)v.y; v2z[0] = (eT)v.z; v2z[1] = (eT)0.f;
-                *(e2*)(row + 2 * N_DIRS * NFT * 2) = v01; *(e2*)(row + 2 * N_DIRS * NFT * 2 + 4) = v2z;
-                for (int f = 2 * N_DIRS * NFT + 4; f < DW_BLK; f += 2) { e2 z; z[0] = (eT)0.f; z[1] = (eT)0.f; *(e2*)(row + f * 2) = z; }
-              } else {
-                st1(row, 0 - colBase, v.x); st1(row, 1 - colBase, v.y); st1(row, 2 - colBase, v.z);
-                for (int f = L.E; f < L.EP; ++f) st1(row, f - colBase, 0.f);
-              }
+            for (int f = 0; f < NFT; f += 2) {
+              float a, b, a2, b2;
+              vals(a, b); vals(a2, b2);
+              e2 vs, vc; vs[0] = (eT)a; vs[1] = (eT)a2; vc[0] = (eT)b; vc[1] = (eT)b2;
+              *(e2*)(row + ((cs0 + f * 2) ^ xs)) = vs; *(e2*)(row + ((cc0 + f * 2) ^ xs)) = vc;
             }
           }
-        };
-        const bool q1 = st & 1;
-        if (peAligned && nf == 6) { if (q1) fill(std::integral_constant<int, 6>{}, std::true_type{}); else fill(std::integral_constant<int, 6>{}, std::false_type{}); }
-        else { if (q1) fill(std::integral_constant<int, 0>{}, std::true_type{}); else fill(std::integral_constant<int, 0>{}, std::false_type{}); }
+        } else if (tid < lastItems + BM) {
+          const float4 v = *(const float4*)(ax + (Q1 ? 16 : 0));
+          if constexpr (NFT != 0) {      // aligned order: x' behind the 42 n_freqs sine / cosine columns, then the padding
+            e2 v01, v2z; v01[0] = (eT)v.x; v01[1] = (eT)v.y; v2z[0] = (eT)v.z; v2z[1] = (eT)0.f;
+            *(e2*)(row + ((2 * N_DIRS * NFT * 2) ^ xs)) = v01; *(e2*)(row + ((2 * N_DIRS * NFT * 2 + 4) ^ xs)) = v2z;
+            for (int f = 2 * N_DIRS * NFT + 4; f < DW_BLK; f += 2) { e2 z; z[0] = (eT)0.f; z[1] = (eT)0.f; *(e2*)(row + ((f * 2) ^ xs)) = z; }
+          } else {
+            st1(row, xs, 0 - colBase, v.x); st1(row, xs, 1 - colBase, v.y); st1(row, xs, 2 - colBase, v.z);
+            for (int f = L.E; f < L.EP; ++f) st1(row, xs, f - colBase, 0.f);
+          }
+        }
+      };
+      if (peAligned && nf == 6) item(std::integral_constant<int, 6>{}); else item(std::integral_constant<int, 0>{});
+    };
+    // slice (ks, h) of stage st's way into its LDS buffer: chunk 2 ks + h of every 16-bit tensor, chunk ks of an e4m3 tensor (P at
+    // h = 0, GB at h = 1) and, for a PE unit, its share of the six fill rounds
+    auto commit = [&](int st, auto oddTag, auto ksTag, auto hTag) {
+      constexpr bool ODD = decltype(oddTag)::value;
+      constexpr int ks = decltype(ksTag)::value, h = decltype(hTag)::value;
+      typedef std::integral_constant<int, 2 * ks + h> C; typedef std::integral_constant<int, ks> C8;
+      char* sb = smem + (ODD ? 1 : 0) * 2 * T::TEN;
+      if constexpr (!ODD) {
+        put16(sb, regA0, C{});
+        if constexpr (!PE) put16(sb + T::TEN, regB0, C{});
+      } else {
+        if constexpr (p8) { if constexpr (h == 0) put8(sb, regA1, kSpillPScale, kSpillPScale, C8{}); } else put16(sb, regA1, C{});
+        if constexpr (!PE) {
+          if constexpr (g8) { if constexpr (h == 1) put8(sb + T::TEN, regB1, sG1[0], sG1[1], C8{}); } else put16(sb + T::TEN, regB1, C{});
+        }
       }
+      if constexpr (PE) {
+        static_assert(NR == 6, "fill rounds 0, 1 | 2, 3 | 4 | 5 ride behind k-steps 0..3");
+        constexpr int r = ks < 2 ? 2 * ks + h : (h == 0 ? ks + 2 : -1);
+        if constexpr (r >= 0) fill_round(st, oddTag, std::integral_constant<int, r>{});
+      }
+    };
+    // the reload of the registers slice (ks, h) has just committed, for the stage two ahead.  EVERY load of the pipeline is
+    // unconditional (past the last stage the workgroup re-reads its last tile, an L2 hit): a load under a branch makes the compiler's
+    // s_waitcnt insertion assume the path without it, and every commit would wait for the loads issued a k-step ago instead of two
+    // stages ago.
+    auto issue = [&](int st, auto oddTag, auto ksTag, auto hTag) {
+      constexpr int ks = decltype(ksTag)::value, h = decltype(hTag)::value;
+      constexpr bool ODD = decltype(oddTag)::value;
+      st = min(st, nStages - (ODD ? 1 : 2));
+      if constexpr (ODD) issue1(st, ksTag, hTag);
+      else issue0(st, std::integral_constant<int, 2 * ks + h>{});
+    };
+    auto each_slice = [&](auto&& fn) {
+      typedef std::integral_constant<int, 0> I0; typedef std::integral_constant<int, 1> I1;
+      fn(I0{}, I0{}); fn(I0{}, I1{}); fn(I1{}, I0{}); fn(I1{}, I1{});
+      fn(std::integral_constant<int, 2>{}, I0{}); fn(std::integral_constant<int, 2>{}, I1{});
+      fn(std::integral_constant<int, 3>{}, I0{}); fn(std::integral_constant<int, 3>{}, I1{});
     };
 
     if constexpr (PE) {
       load_aux(0); store_aux(0); load_aux(1);
     }
-    if (nStages > 0) { issue0(0); }
-    if (nStages > 1) { issue1(1); }
+    each_slice([&](auto k, auto h) { issue(0, std::false_type{}, k, h); });
+    each_slice([&](auto k, auto h) { issue(1, std::true_type{}, k, h); });
     if constexpr (PE) __syncthreads();          // tile 0's pe_aux rows are in LDS
-    if (nStages > 0) commit(0, 0);
-    if (nStages > 2) issue0(2);
+    each_slice([&](auto k, auto h) { commit(0, std::false_type{}, k, h); issue(2, std::false_type{}, k, h); });
     __syncthreads();
 
-    // Stage st sits in LDS buffer (st&1).  Each iteration first writes stage st+1 (loads issued two
-    // stages ago) into the OTHER LDS buffer, re-issues that register set for stage st+3, then runs the
-    // MFMAs of stage st: the LDS commit of one wave overlaps the MFMAs of the others, one barrier per stage.
-    // (PE units: the pe_aux rows of the NEXT tile go to LDS in the first half, a barrier ahead of the commit that reads them.)
-    for (int st = 0; st < nStages; st += 2) {
-      if (st + 1 < nStages) {
-        commit(st + 1, 1);
-        if constexpr (PE) { store_aux((st >> 1) + 1); load_aux((st >> 1) + 2); }
-        if (st + 3 < nStages) issue1(st + 3);
-      }
-      compute(0);
+    // Stage st sits in LDS buffer (st & 1).  While its MFMAs run, stage st + 1 (loads issued two stages ago) goes into the OTHER
+    // buffer slice by slice -- one slice behind the MFMAs of each half-step -- and each committed register is re-issued for stage
+    // st + 3 on the spot; one barrier per stage.  (PE units: the pe_aux rows of the NEXT tile go to LDS behind the last half-step of
+    // the even stages, a barrier ahead of the fill that reads them.)  Behind the last stage the commit writes a buffer nobody reads.
+    typedef std::integral_constant<int, PE ? 12 : 4> NV;      // VALU / LDS-store instructions per MFMA slot (the PE fill is ~90 VALU a round)
+    typedef std::integral_constant<int, PE ? 2 : 1> NW;
+    for (int st = 0; st < nStages; st += 2) {       // (nStages is even: two stages per tile)
+      compute(0, NV{}, NW{}, [&](auto ks, auto h) {             // stage st (even) computes; stage st + 1 (odd) goes into buffer 1
+        commit(st + 1, std::true_type{}, ks, h);
+        issue(st + 3, std::true_type{}, ks, h);
+        if constexpr (PE && decltype(ks)::value == 3 && decltype(h)::value == 1) { store_aux((st >> 1) + 1); load_aux((st >> 1) + 2); }
+      });
       __syncthreads();
-      if (st + 1 < nStages) {
-        if (st + 2 < nStages) { commit(st + 2, 0); if (st + 4 < nStages) issue0(st + 4); }
-        compute(1);
-        __syncthreads();
-      }
+      compute(1, NV{}, NW{}, [&](auto ks, auto h) {             // stage st + 1 computes; stage st + 2 (even) goes into buffer 0
+        commit(st + 2, std::false_type{}, ks, h);
+        issue(st + 4, std::false_type{}, ks, h);
+      });
+      __syncthreads();
     }
   };
   typedef std::integral_constant<bool, (SP8 & 2) != 0> P8T;
-  if (fromEmb) run(std::true_type{}, P8T{});
+  if (nStages == 0) {}      // (more K-splits than tiles: a zero slab)
+  else if (fromEmb) run(std::true_type{}, P8T{});
   else if ((SP8 & 2) && li == L.L - 1) run(std::false_type{}, std::false_type{});      // the top layer's P stays 16-bit (SpillLayout)
   else run(std::false_type{}, P8T{});
 
   // partial slab [o][i]
   slab_t* slab = (slab_t*)p.dwPart + ((int64_t)dw_slab_base(L, unit) + split) * DW_BLK * DW_BLK;
 #pragma unroll
-  for (int ob = 0; ob < 2; ++ob)
+  for (int ob = 0; ob < 4; ++ob)
 #pragma unroll
     for (int ib = 0; ib < 4; ++ib)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int o = wo * 64 + ob * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        const int o = wo * 128 + ob * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
         int i = wi * 128 + ib * 32 + (lane & 31);
         if (peAligned) {     // aligned operand order [sin | cos | x' | pad] -> the reference's [x' | sin | cos | pad]
           const int nsc = 2 * N_DIRS * L.n_freqs;
@@ -387,7 +446,7 @@ __global__ __launch_bounds__(512, 2) void dw_kernel(const DwParams p) {
 int launch_dw(const DwParams& p, hipStream_t st) {
   if (!layout_supported(p.lay)) return ISDF_EUNSUPPORTED;
   typedef DwTile<256> T;
-  const dim3 grid(dw_total_slabs(p.lay)), block(512);
+  const dim3 grid(dw_total_slabs(p.lay)), block(T::NT);
   auto go = [&](auto k) {
     if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES) != hipSuccess) return (int)ISDF_EHIP;
     hipLaunchKernelGGL(k, grid, block, T::LDS_BYTES, st, p);

@@ -13,13 +13,13 @@ constexpr int TILE_PTS = 64;   // points per chain-kernel workgroup (two workgro
 constexpr int DW_PTS = 64;     // points per dW-kernel stage
 constexpr int CHAIN_NW = 8;    // waves per chain-kernel workgroup (each owns HD/CHAIN_NW features)
 constexpr int CHAIN_CHUNK_FRAGS = 8;   // weight fragments a wave requests at once (32 VGPRs at the 128-VGPR budget)
-// K-splits per dW unit: 5 x 35 + 2 x 40 = 255 workgroups for the default net, one per CU.  A workgroup's time is its number of
-// 64-point stages times ~3.1 us -- measured with the other units switched off: the top layer's 32 workgroups ALONE take as long as all
-// 256 together (profiles/r06_dw_unit_kinds.txt) -- i.e. the kernel is bound by its commit -> transpose-read -> MFMA -> barrier chain,
-// not by bytes, so the split that matters is the one that evens out the stage counts.  A unit that rebuilds its embedding-shaped operand
-// (dw.hip) runs slightly longer stages (~3.25 us) and gets five splits more (same-box A/B of 32/48, 34/43, 35/40, 36/38:
-// profiles/r06_dw_splits.txt).
-constexpr int DW_SPLIT_REG = 35, DW_SPLIT_PE = 40, DW_SPLIT_MAX = 40;
+// K-splits per dW unit: 5 x 32 + 2 x 48 = 256 workgroups for the default net, one per CU.  With the whole chip at work the kernel
+// runs at the rate its bytes arrive (~4.9 TB/s of operand reads and slab writes), so the split only has to keep every CU busy to the
+// end: the units that REBUILD their embedding-shaped operand (dw.hip) spend ~3 us per 64-point stage on their own (the fill is VALU
+// work of the same four waves that issue the MFMAs), the others ~1.9 us, and the former get half as many stages again fewer.
+// Same-box A/B of 30/53, 32/48, 33/45, 34/43, 35/40: profiles/r06_dw_v2.txt (the first version of the kernel, bound by its LDS
+// commit instead, liked 35/40: profiles/r06_dw_splits.txt).
+constexpr int DW_SPLIT_REG = 32, DW_SPLIT_PE = 48, DW_SPLIT_MAX = 48;
 typedef float slab_t;          // K-split partial slabs (bf16 slabs measured: parity unchanged, -2 us only)
 
 // Vector types for the 16-bit MFMA operands.

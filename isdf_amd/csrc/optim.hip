@@ -314,7 +314,7 @@ __global__ __launch_bounds__(1024) void step_tail_kernel(const TailParams p) {
     else {
       const slab_t* src = (const slab_t*)p.dwPart + (int64_t)dw_slab_base(L, unit) * perUnit + rem;
       // all K-split slabs of this element in flight at once: with 4 at a time the kernel was nine dependent HBM round
-      // trips long (23-26 us for 88 MB).  A unit has 35 slabs, or 40 when the dW kernel rebuilds its input operand (isdf_common.h).
+      // trips long (23-26 us for 88 MB).  A unit has DW_SPLIT_REG slabs, or DW_SPLIT_PE when the dW kernel rebuilds its input operand (isdf_common.h).
 #pragma unroll
       for (int k = 0; k < DW_SPLIT_REG; ++k) s += __builtin_nontemporal_load(src + (int64_t)k * perUnit);
       if (dw_unit_from_emb(L, du)) {

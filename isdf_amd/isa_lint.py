@@ -93,6 +93,100 @@ def kernel_resources(lib):
     return out
 
 
+_ADDR = re.compile(r"//\s*([0-9A-Fa-f]{8,16}):")
+_TARGET = re.compile(r"<[^>]*\+0x([0-9a-fA-F]+)>\s*$")
+
+
+def scratch_in_loops_text(text):
+    """-> [(kernel, instruction)]: scratch (private-segment) accesses that sit INSIDE a loop (a cycle of the kernel's control-flow
+    graph, rebuilt from the disassembly).  A register spilled around a loop costs a store and a load per launch; one reloaded inside
+    the MFMA stream waits behind every global load in flight (scratch shares vmcnt, which retires in order)."""
+    out = []
+
+    def analyse(kernel, base, ins):          # ins: [(addr, text, branch target or None)]
+        if not any(t.startswith("scratch_") for _, t, _ in ins):
+            return
+        addrs = [a for a, _, _ in ins]
+        leaders = {addrs[0]} | {tg for _, _, tg in ins if tg is not None}
+        for k, (a, t, tg) in enumerate(ins[:-1]):
+            if t.startswith(("s_cbranch", "s_branch", "s_endpgm", "s_setpc")):
+                leaders.add(addrs[k + 1])
+        starts = sorted(x for x in leaders if x in set(addrs))
+        import bisect
+        block_of = lambda a: bisect.bisect_right(starts, a) - 1
+        n = len(starts)
+        succ = [set() for _ in range(n)]
+        for k, (a, t, tg) in enumerate(ins):
+            b = block_of(a)
+            last = k + 1 == len(ins) or block_of(addrs[k + 1]) != b
+            if tg is not None and tg in set(starts):
+                succ[b].add(block_of(tg))
+            if last and k + 1 < len(ins) and not t.startswith(("s_branch", "s_endpgm", "s_setpc")):
+                succ[b].add(block_of(addrs[k + 1]))
+        # Tarjan, iterative
+        index, low, on, stack, comp, cnt = [None] * n, [0] * n, [False] * n, [], [None] * n, [0]
+        for root in range(n):
+            if index[root] is not None:
+                continue
+            work = [(root, iter(sorted(succ[root])))]
+            index[root] = low[root] = cnt[0]; cnt[0] += 1; stack.append(root); on[root] = True
+            while work:
+                v, it = work[-1]
+                adv = False
+                for w in it:
+                    if index[w] is None:
+                        index[w] = low[w] = cnt[0]; cnt[0] += 1; stack.append(w); on[w] = True
+                        work.append((w, iter(sorted(succ[w])))); adv = True
+                        break
+                    if on[w]:
+                        low[v] = min(low[v], index[w])
+                if adv:
+                    continue
+                work.pop()
+                if work:
+                    low[work[-1][0]] = min(low[work[-1][0]], low[v])
+                if low[v] == index[v]:
+                    members = []
+                    while True:
+                        w = stack.pop(); on[w] = False; members.append(w)
+                        if w == v:
+                            break
+                    cyc = len(members) > 1 or v in succ[v]
+                    for w in members:
+                        comp[w] = cyc
+        for a, t, _ in ins:
+            if t.startswith("scratch_") and comp[block_of(a)]:
+                out.append((kernel, t))
+
+    kernel, base, ins = None, 0, []
+    for line in text.split("\n"):
+        if line.endswith(">:") and "<" in line:
+            if kernel is not None and ins:
+                analyse(kernel, base, ins)
+            kernel, base, ins = line[line.index("<") + 1:-2], int(line.split()[0], 16), []
+            continue
+        m = _ADDR.search(line)
+        if not m or kernel is None:
+            continue
+        t = line.split("//")[0].strip()
+        tg = None
+        if t.startswith(("s_cbranch", "s_branch")):
+            mt = _TARGET.search(line)
+            tg = base + int(mt.group(1), 16) if mt else None
+        ins.append((int(m.group(1), 16), t, tg))
+    if kernel is not None and ins:
+        analyse(kernel, base, ins)
+    return out
+
+
+def scratch_in_loops(lib):
+    with tempfile.TemporaryDirectory(prefix="isdf_lint_") as wd:
+        bad = []
+        for o in code_objects(lib, wd):
+            bad += scratch_in_loops_text(disassemble(o))
+        return bad
+
+
 def lint_library(lib):
     with tempfile.TemporaryDirectory(prefix="isdf_lint_") as wd:
         objs = code_objects(lib, wd)
