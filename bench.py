@@ -702,7 +702,8 @@ def main():
             "distributed": {"world_size": torch.distributed.get_world_size() if group is not None else 1,
                             "backend": torch.distributed.get_backend() if group is not None else None,
                             "collectives_per_step": 0 if group is None else (2 if overlap else 1),
-                            "overlap_allreduce": bool(overlap), "per_rank_chain_us": per_rank_chain_us,
+                            "overlap_allreduce": bool(overlap), "collective": getattr(tr._hip, "collective", None),
+                            "per_rank_chain_us": per_rank_chain_us,
                             "per_rank_elapsed_s": per_rank_elapsed},
             "dtype": {"fp16x2": "f16 MFMA operands (compensated forward: hi+lo operands past the cat layer), f32 accumulate; ",
                       "fp16x2_full": "f16 MFMA operands (exact-forward instrument: hi+lo operands in every forward layer), f32 accumulate; ",

@@ -22,20 +22,22 @@
 #ifndef ISDF_HIP_H
 #define ISDF_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
 extern "C" {
 #endif
 
-#define ISDF_ABI_VERSION 6
+#define ISDF_ABI_VERSION 7
 
 enum {
   ISDF_OK = 0,
   ISDF_EINVAL = -1,       /* bad argument / null pointer / size mismatch      */
   ISDF_EUNSUPPORTED = -2, /* configuration the kernels are not built for      */
   ISDF_EWORKSPACE = -3,   /* caller workspace too small                       */
-  ISDF_EHIP = -4          /* a HIP runtime call failed (see hipGetLastError)  */
+  ISDF_EHIP = -4,         /* a HIP runtime call failed (see hipGetLastError)  */
+  ISDF_ECOLLECTIVE = -5   /* the caller's collective library refused the call */
 };
 
 /* ---- network description ------------------------------------------------
@@ -312,6 +314,18 @@ int isdf_train_step_adamw(const isdf_net_cfg* net, const isdf_loss_cfg* loss, co
  * (tests/test_dp_gpu.py).                                                                                          */
 int isdf_train_step_finish(const isdf_net_cfg* net, const isdf_optim_args* opt, const float* reduce_buf,
                            int32_t n_frames, int32_t extra_floats, float* host_mailbox, void* stream);
+
+/* THE collective of the data-parallel step, enqueued on the step's OWN stream between isdf_train_step and
+ * isdf_train_step_finish: in-place sum of buf[0..count) over the communicator's ranks.  The library does not link a
+ * collective library: the caller passes the address of RCCL's `ncclAllReduce` (from the RCCL build its communicator was
+ * created with -- torch ships its own) and the communicator (ncclComm_t).  Stream order replaces the two cross-stream
+ * event hand-offs of a framework-issued collective (torch.distributed.all_reduce runs on a side stream: +36 us per step
+ * at world size 1 in round 5, profiles/r05_bench_forced_dp_world1.json).  The caller must not have another collective of
+ * the same communicator in flight on a different stream.  Returns ISDF_ECOLLECTIVE (with the library's code in
+ * isdf_error_string's text) if RCCL refuses the call.  Reference: none (the reference is single-process).  */
+typedef int (*isdf_nccl_allreduce_fn)(const void* sendbuf, void* recvbuf, size_t count, int datatype, int op,
+                                      void* comm, void* stream);
+int isdf_allreduce_sum_f32(isdf_nccl_allreduce_fn nccl_all_reduce, void* comm, float* buf, int64_t count, void* stream);
 /* extra_floats / host_mailbox (optional, pinned host memory of 8 + extra_floats floats): the same launch stores the
  * REDUCED loss_sums[8] followed by the message's caller-owned tail there (isdf_step_args.extra_floats).
  * extra_floats > 0 without a host_mailbox is ISDF_EINVAL (the tail would be dropped silently).                    */

@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # ISDF_HIP_LIB: development override (A/B variants and the instrumented build of tools/build_variants.py)
 LIB_PATH = os.environ.get("ISDF_HIP_LIB") or os.path.join(HERE, "libisdf_hip.so")
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 # every symbol include/isdf_hip.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
@@ -19,7 +19,7 @@ SYMBOLS = [
     "isdf_workspace_bytes", "isdf_reduce_floats", "isdf_reduce_split_floats", "isdf_sample_scan_bytes", "isdf_pack_weights",
     "isdf_sample_rays",
     "isdf_sdf_eval", "isdf_train_step", "isdf_train_step_adamw", "isdf_train_step_finish", "isdf_bounds_pc",
-    "isdf_frame_avg", "isdf_adamw", "isdf_estimate_normals", "isdf_render_depth",
+    "isdf_frame_avg", "isdf_adamw", "isdf_estimate_normals", "isdf_render_depth", "isdf_allreduce_sum_f32",
 ]
 
 LS_SDF, LS_GRAD, LS_EIK, LS_TOTAL, LS_COUNT = 0, 1, 2, 3, 4
@@ -124,6 +124,7 @@ def lib():
     L.isdf_train_step.argtypes = [P(NetCfg), P(LossCfg), vp, vp, P(StepArgs), P(StepOut), vp, i64, vp]
     L.isdf_train_step_adamw.argtypes = [P(NetCfg), P(LossCfg), P(StepArgs), P(StepOut), P(OptimArgs), vp, i64, vp]
     L.isdf_train_step_finish.argtypes = [P(NetCfg), P(OptimArgs), vp, i32, i32, vp, vp]
+    L.isdf_allreduce_sum_f32.argtypes = [vp, vp, vp, C.c_int64, vp]
     L.isdf_bounds_pc.argtypes = [vp, i32, i32, vp, vp, vp, vp, i64, vp, vp, vp]
     L.isdf_frame_avg.argtypes = [vp, i64, i32, vp, vp, vp, vp]
     L.isdf_adamw.argtypes = [P(NetCfg), vp, vp, vp, vp, vp, f32, f32, f32, f32, f32, f32, i32, vp, vp]

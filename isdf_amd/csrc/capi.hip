@@ -45,6 +45,8 @@ extern "C" {
 
 int isdf_abi_version(void) { return ISDF_ABI_VERSION; }
 
+static thread_local int g_isdf_last_collective_error = 0;
+
 const char* isdf_error_string(int code) {
   switch (code) {
     case ISDF_OK: return "ok";
@@ -54,6 +56,11 @@ const char* isdf_error_string(int code) {
     case ISDF_EHIP: {
       static thread_local char buf[160];
       snprintf(buf, sizeof(buf), "HIP runtime error: %s", g_isdf_last_hip_error ? hipGetErrorString((hipError_t)g_isdf_last_hip_error) : "(no launch status recorded)");
+      return buf;
+    }
+    case ISDF_ECOLLECTIVE: {
+      static thread_local char buf[96];
+      snprintf(buf, sizeof(buf), "the collective library refused the all-reduce (ncclResult_t %d)", g_isdf_last_collective_error);
       return buf;
     }
   }
@@ -275,6 +282,14 @@ int isdf_train_step_finish(const isdf_net_cfg* net, const isdf_optim_args* opt, 
                            opt->weight_decay, opt->step, (hipStream_t)stream, F, bl, bl + (int64_t)n_frames * 64,
                            opt->loss_approx, opt->frame_avg, opt->frame_avg_index, lossSums, bl + (int64_t)n_frames * 128,
                            extra_floats, host_mailbox, opt->frame_avg_inline_n, opt->frame_avg_index_inline);
+}
+
+int isdf_allreduce_sum_f32(isdf_nccl_allreduce_fn nccl_all_reduce, void* comm, float* buf, int64_t count, void* stream) {
+  if (!nccl_all_reduce || !comm || !buf || count < 1) return ISDF_EINVAL;
+  constexpr int kNcclFloat32 = 7, kNcclSum = 0;            // ncclDataType_t / ncclRedOp_t (rccl.h)
+  const int rc = nccl_all_reduce(buf, buf, (size_t)count, kNcclFloat32, kNcclSum, comm, stream);
+  if (rc != 0) { g_isdf_last_collective_error = rc; return ISDF_ECOLLECTIVE; }
+  return ISDF_OK;
 }
 
 int isdf_bounds_pc(const int32_t* n_valid, int32_t max_rays, int32_t S, const float* pc, const float* z_vals,

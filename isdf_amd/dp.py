@@ -39,6 +39,31 @@ def allreduce_(buf, group=None):
     return buf
 
 
+def rccl_direct(group, device):
+    """(address of ncclAllReduce, ncclComm_t) of `group`'s RCCL communicator on `device`, or None when the group is not an RCCL
+    group on a HIP device (gloo in the CPU tests; `ISDF_DP_COLLECTIVE=torch` forces None).  With it the step's collective is
+    enqueued on the step's own stream by the C library (isdf_allreduce_sum_f32) instead of going through
+    torch.distributed.all_reduce, which runs it on ProcessGroupNCCL's side stream behind two cross-stream event waits.
+    The communicator stays torch's (created by the group's first collective -- graft() has broadcast the weights by then);
+    torch's RCCL build is the one it belongs to, so ncclAllReduce is taken from that library."""
+    import os
+    if os.environ.get("ISDF_DP_COLLECTIVE", "").lower() == "torch" or torch.device(device).type != "cuda":
+        return None
+    try:
+        if torch.distributed.get_backend(group) != "nccl":
+            return None
+        import ctypes
+        backend = group._get_backend(torch.device(device))
+        comm = int(backend._comm_ptr())
+        lib = ctypes.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"))
+        fn = ctypes.cast(lib.ncclAllReduce, ctypes.c_void_p).value
+        return (fn, comm) if fn and comm else None
+    except Exception as e:      # an older torch without _comm_ptr, a statically linked RCCL ...: the framework's collective still works
+        import warnings
+        warnings.warn("isdf_amd: direct RCCL all-reduce unavailable (%r); using torch.distributed.all_reduce" % (e,))
+        return None
+
+
 def new_split_event(device):
     """an event whose native handle exists (torch creates it at the first record)"""
     ev = torch.cuda.Event()

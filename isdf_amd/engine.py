@@ -517,6 +517,13 @@ class Engine:
             keep += [fa_out, fa_idx]
         return q
 
+    def allreduce_direct(self, rccl):
+        """THE collective of the data-parallel step on the step's own stream (isdf_allreduce_sum_f32): in-place sum of the
+        whole message -- reduce_buf incl. its caller-owned tail -- over the ranks of `rccl` = dp.rccl_direct(group, device)."""
+        fn, comm = rccl
+        _ffi.check(self.lib.isdf_allreduce_sum_f32(fn, comm, _ffi.ptr(self.reduce_buf), int(self.reduce_buf.numel()),
+                                                   _stream(self.device)), "isdf_allreduce_sum_f32")
+
     def train_step_finish(self, n_frames, optim):
         """Second half of the data-parallel step (isdf_train_step_finish): AdamW on the all-reduced gradient sums,
         operand repack and -- with optim["frame_avg_out"] -- loss.frame_avg from the reduced bins, ONE launch."""

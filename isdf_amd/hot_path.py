@@ -298,7 +298,10 @@ class HotPath:
         if split:                        # the message in two parts, the first one beside the closing reduction's second launch
             dp.allreduce_split_(eng.reduce_buf, eng.reduce_split, hip.split_event, hip.comm_stream, hip.dist_group)
         elif hip.dist_group is not None:   # sums over ranks; AdamW divides by the reduced count
-            dp.allreduce_(eng.reduce_buf, hip.dist_group)   # THE collective of the step
+            if hip.rccl is not None:       # THE collective of the step: RCCL on the step's own stream, enqueued by the C library
+                eng.allreduce_direct(hip.rccl)
+            else:                          # (gloo / a torch without the communicator handle: the framework's side-stream form)
+                dp.allreduce_(eng.reduce_buf, hip.dist_group)
         return dbg
 
     def sdf_eval_and_loss(self, sample, do_avg_loss=True):
@@ -750,7 +753,7 @@ def graft(trainer, rng="philox", seed=1, dist_group=None, fix_normal_window=Fals
     base = trainer.__class__
     if not issubclass(base, HotPath):
         trainer.__class__ = type("Hip" + base.__name__, (HotPath, base), {"__module__": HotPath.__module__})
-    hip.clock_slots, hip.prev_step_ms, hip.rank = 0, 0.0, 0
+    hip.clock_slots, hip.prev_step_ms, hip.rank, hip.rccl, hip.collective = 0, 0.0, 0, None, None
     if dist_group is not None:                           # replicated weights / moments
         eng = trainer.sdf_map.engine
         for t in (eng.params, eng.exp_avg, eng.exp_avg_sq):
@@ -760,4 +763,6 @@ def graft(trainer, rng="philox", seed=1, dist_group=None, fix_normal_window=Fals
         hip.window_rng_state = np.random.RandomState(hip.seed + 104729).get_state()   # replicated select_keyframes stream
         if hip.virtual_step_ms is None:                  # per-rank step-time slots in the tail of the all-reduce message
             hip.clock_slots = eng.reduce_extra = hip.world
+        hip.rccl = dp.rccl_direct(dist_group, hip.device) if hasattr(eng, "allreduce_direct") else None
+        hip.collective = "rccl on the step's stream (isdf_allreduce_sum_f32)" if hip.rccl is not None else "torch.distributed.all_reduce"
     return trainer

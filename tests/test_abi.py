@@ -113,3 +113,30 @@ def test_ctypes_structs_match_the_header_layout(tmp_path):
         ct = structs[name]
         assert C.sizeof(ct) == int(size), (name, C.sizeof(ct), size)
         assert getattr(ct, last[name]).offset == int(off), (name, last[name])
+
+
+def test_allreduce_entry_point_checks_its_arguments_and_reports_a_refusing_collective():
+    """isdf_allreduce_sum_f32 (the data-parallel step's collective on the step's own stream): no collective library is linked, the
+    caller passes RCCL's ncclAllReduce -- here a stand-in that refuses, which never touches the buffer, so this runs without a GPU."""
+    import ctypes as C
+    lib = _ffi.lib()
+    buf = (C.c_float * 16)()
+    assert lib.isdf_allreduce_sum_f32(None, 1, C.addressof(buf), 16, None) == -1          # ISDF_EINVAL: no function
+    assert lib.isdf_allreduce_sum_f32(1, None, C.addressof(buf), 16, None) == -1          # ... no communicator
+    assert lib.isdf_allreduce_sum_f32(1, 1, None, 16, None) == -1
+    assert lib.isdf_allreduce_sum_f32(1, 1, C.addressof(buf), 0, None) == -1
+    seen = []
+
+    def refuse(send, recv, count, dtype, op, comm, stream):
+        seen.append((send, recv, count, dtype, op, comm))
+        return 5
+    fn = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p)(refuse)
+    rc = lib.isdf_allreduce_sum_f32(C.cast(fn, C.c_void_p).value, 0x1234, C.addressof(buf), 16, None)
+    assert rc == -5 and b"ncclResult_t 5" in lib.isdf_error_string(rc)                   # ISDF_ECOLLECTIVE
+    # in place, fp32 (ncclFloat32 = 7), sum (ncclSum = 0), the caller's communicator
+    assert seen == [(C.addressof(buf), C.addressof(buf), 16, 7, 0, 0x1234)]
+
+
+def test_rccl_direct_is_off_for_non_rccl_groups():
+    from isdf_amd import dp
+    assert dp.rccl_direct(None, "cpu") is None
