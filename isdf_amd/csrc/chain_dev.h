@@ -29,7 +29,17 @@ typedef __amdgpu_buffer_rsrc_t rsrc_t;
 __device__ __forceinline__ rsrc_t make_rsrc(const void* base, uint32_t bytes) {
   return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, bytes, 0x00020000);
 }
-constexpr int kAuxNT = 2;   // non-temporal: the spill stream must not evict the L2-resident weight copies
+constexpr int kAuxNT = 2;   // the non-temporal hint of a buffer load (aux bit 1)
+// Cache policy of the spill traffic.  Rounds 2 - 5: everything the chain kernel re-reads itself (A, P) went out and came back
+// non-temporal -- the stack (1.0 GB per step then) streamed through the 256 MB Infinity Cache anyway and only evicted the weight
+// copies on its way.  Round 6: with e4m3 P / GB and no stored embedding the stack is 230 MB per step and FITS; stored and re-read
+// with the default policy it is served from the cache: chain kernel 169.5 -> 154.9 us same-box, either hint alone: nothing
+// (profiles/r06_cache_policy.txt).  The dW kernel's operand loads are each tensor's LAST use: they stay non-temporal (dW +2.5 us
+// otherwise in the first A/B, nothing in the second), and so does the step tail's one read of the K-split slabs (chain +5 us
+// with the default policy there); the slabs themselves are STORED with the default policy (tail -1.8 us).
+constexpr bool kSpillStoreNT = false;   // the chain kernel's spill stores
+constexpr int kAuxSpillLoad = 0;        // ... and its re-reads
+constexpr int kAuxDwLoad = kAuxNT;      // the dW kernel's operand loads
 template <int AUX> __device__ __forceinline__ uint4 bload16(rsrc_t r, int voff, int soff) {
   const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, AUX);
   return make_uint4(v[0], v[1], v[2], v[3]);
@@ -55,7 +65,7 @@ __device__ __forceinline__ i32x4 make_srd(const void* base, uint32_t bytes) {
   asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen offset:" #IMM " nt\n\ts_nop 1" ::"v"(v), "v"(voff), "s"(srd), "s"(soff) : "memory")
 #define ISDF_BSTORE16_DF(IMM) \
   asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen offset:" #IMM "\n\ts_nop 1" ::"v"(v), "v"(voff), "s"(srd), "s"(soff) : "memory")
-template <bool NT = true>
+template <bool NT = kSpillStoreNT>
 __device__ __forceinline__ void bstore16_nt(uint4 x, i32x4 srd, int voff, int soff, int c) {
   u32x4 v; v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w;
   soff += (c >> 2) * 4096;

@@ -213,24 +213,24 @@ __global__ __launch_bounds__(256, 1) void dw_kernel(const DwParams p) {
     auto issue0 = [&](int st, auto cTag) {        // even stage: ZB and the layer input, 16-bit
       constexpr int c = decltype(cTag)::value;
       const int t = split + (st >> 1) * DW_SPLITK;
-      regA0[c] = bload16<kAuxNT>(tile_rsrc(offZ, t), vo16, slA * 32768 + c * 4096);
-      if constexpr (!PE) regB0[c] = bload16<kAuxNT>(tile_rsrc(offI, t), vo16, slB * 32768 + c * 4096);
+      regA0[c] = bload16<kAuxDwLoad>(tile_rsrc(offZ, t), vo16, slA * 32768 + c * 4096);
+      if constexpr (!PE) regB0[c] = bload16<kAuxDwLoad>(tile_rsrc(offI, t), vo16, slB * 32768 + c * 4096);
     };
     auto issue1 = [&](int st, auto ksTag, auto hTag) {       // odd stage, slice (ks, h): P and GB -- e4m3 (frag8 pieces: 16 B = a lane's 8 values of both point blocks; chunk ks, P at h = 0, GB at h = 1) or 16-bit (chunk 2 ks + h)
       constexpr int ks = decltype(ksTag)::value, h = decltype(hTag)::value, c = 2 * ks + h;
       const int t = split + (st >> 1) * DW_SPLITK;
-      if constexpr (p8) { if constexpr (h == 0) regA1[ks] = bload16<kAuxNT>(tile_rsrc(offP, t), vo8, slA * 16384 + ks * 4096); }
-      else regA1[c] = bload16<kAuxNT>(tile_rsrc(offP, t), vo16, slA * 32768 + c * 4096);
+      if constexpr (p8) { if constexpr (h == 0) regA1[ks] = bload16<kAuxDwLoad>(tile_rsrc(offP, t), vo8, slA * 16384 + ks * 4096); }
+      else regA1[c] = bload16<kAuxDwLoad>(tile_rsrc(offP, t), vo16, slA * 32768 + c * 4096);
       if constexpr (!PE) {
         if constexpr (g8) {
-          if constexpr (h == 1) regB1[ks] = bload16<kAuxNT>(tile_rsrc(offG, t), vo8, slB * 16384 + ks * 4096);
+          if constexpr (h == 1) regB1[ks] = bload16<kAuxDwLoad>(tile_rsrc(offG, t), vo8, slB * 16384 + ks * 4096);
           if constexpr (ks == 3 && h == 1) {       // behind the LAST slice: the commit of the previous odd stage reads the old scales until then
             const rsrc_t rx = make_rsrc(p.pe_aux + (int64_t)t * BM * 8, BM * 32);
             sG1[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, (tid & 31) * 32 + 28, 0, 0));
             sG1[1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, (tid & 31) * 32 + 28, 32 * 32, 0));
           }
         } else {
-          regB1[c] = bload16<kAuxNT>(tile_rsrc(offG, t), vo16, slB * 32768 + c * 4096);
+          regB1[c] = bload16<kAuxDwLoad>(tile_rsrc(offG, t), vo16, slB * 32768 + c * 4096);
         }
       }
     };
@@ -437,7 +437,7 @@ __global__ __launch_bounds__(256, 1) void dw_kernel(const DwParams p) {
           const int nsc = 2 * N_DIRS * L.n_freqs;
           i = i < nsc ? i + 3 : (i < nsc + 3 ? i - nsc : i);
         }
-        __builtin_nontemporal_store(acc[ob][ib][r], slab + o * DW_BLK + i);
+        slab[o * DW_BLK + i] = acc[ob][ib][r];      // default cache policy: the step tail reads the slabs next (non-temporal stores: tail +1.8 us)
       }
 }
 

@@ -1,10 +1,7 @@
-cd $GRAFT_REPO_ROOT; O=gpurun_out/r06_dp; mkdir -p $O
-timeout 600 python -m pytest tests/test_dp_rccl_direct_gpu.py tests/test_dp_gpu.py tests/test_bench_launch.py -x -q -m gpu 2>&1 | tail -15 > $O/tests.txt; cat $O/tests.txt
-for rep in 1 2; do
-for mode in none direct torch; do
-  if [ $mode = none ]; then export ISDF_BENCH_FORCE_DP=0; else export ISDF_BENCH_FORCE_DP=1; fi
-  if [ $mode = torch ]; then export ISDF_DP_COLLECTIVE=torch; else export ISDF_DP_COLLECTIVE=; fi
-  python bench.py --steps 200 --warmup 30 --no-cpu-baseline --no-accuracy 2>/dev/null | tail -1 | python -c "
+cd $GRAFT_REPO_ROOT; O=gpurun_out/r06_cachepol; mkdir -p $O
+timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | tail -3 > $O/gpu_tests.txt; cat $O/gpu_tests.txt
+for rep in 1 2; do for f in variants/lib_*.so; do
+  ISDF_HIP_LIB=$PWD/$f python bench.py --steps 200 --warmup 30 --no-cpu-baseline --no-accuracy 2>/dev/null | tail -1 | python -c "
 import sys,json
-j=json.loads(sys.stdin.read()); print('%-8s rep$rep  sync %.4f ms  pipelined %.4f ms  collective %s' % ('$mode', j['ms_per_step'], j['pipelined']['ms_per_step'], j['distributed'].get('collective')))"
-done; done > $O/ab.txt 2>&1; cat $O/ab.txt
+j=json.loads(sys.stdin.read()); print('%-10s rep$rep  sync %.4f ms  pipelined %.4f ms  chain %.4f dw %.4f tail %.4f' % ('$f'.split('lib_')[1][:-3], j['ms_per_step'], j['pipelined']['ms_per_step'], *list(j['kernel_ms'].values())[:3]))"
+done; done > $O/ab_final.txt 2>&1; cat $O/ab_final.txt
