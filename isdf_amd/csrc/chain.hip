@@ -380,7 +380,7 @@ __global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 && EP == HD && !oper_x2_a
       for (int qp = 0; qp < 2; ++qp)
 #pragma unroll
         for (int pb = 0; pb < PB; ++pb)
-          pr.v[fb][qp][pb] = bload16<kAuxSpillLoad>(rsS, lane16 + (cidx(fb, pb, qp) & 3) * 1024, sb + (cidx(fb, pb, qp) >> 2) * 4096);
+          pr.v[fb][qp][pb] = bload16<spill_load_aux(HD)>(rsS, lane16 + (cidx(fb, pb, qp) & 3) * 1024, sb + (cidx(fb, pb, qp) >> 2) * 4096);
   };
   auto load_tile8 = [&](const Pre& pr, int fb, int pb, int qp, float (&o)[8]) {
     const uint4 u = pr.v[fb][qp][pb];
@@ -397,10 +397,10 @@ __global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 && EP == HD && !oper_x2_a
   };
   auto store_tile8 = [&](int64_t tensorOff, int fb, int pb, int qp, const float (&v)[8]) {
     const uint2 a = pack4<BW>(v[0], v[1], v[2], v[3]), b = pack4<BW>(v[4], v[5], v[6], v[7]);
-    bstore16_nt<kSpillStoreNT>(make_uint4(a.x, a.y, b.x, b.y), srdS, lane16, sbase(tensorOff), cidx(fb, pb, qp));
+    bstore16_nt<spill_store_nt(HD)>(make_uint4(a.x, a.y, b.x, b.y), srdS, lane16, sbase(tensorOff), cidx(fb, pb, qp));
   };
   // tensors that only the dW kernel re-reads (GB, ZB): default cache policy since round 4 (chain -2.3 %, dW unchanged); A and P,
-  // which the chain kernel itself re-reads, follow kSpillStoreNT (chain_dev.h: default policy too since the stack fits the cache)
+  // which the chain kernel itself re-reads, follow spill_store_nt(HD) (chain_dev.h: default policy too for the 256-wide nets, whose stack fits the cache)
   auto store_tile8_dw = [&](int64_t tensorOff, int fb, int pb, int qp, const float (&v)[8]) {
     const uint2 a = pack4<BW>(v[0], v[1], v[2], v[3]), b = pack4<BW>(v[4], v[5], v[6], v[7]);
     bstore16_nt<false>(make_uint4(a.x, a.y, b.x, b.y), srdS, lane16, sbase(tensorOff), cidx(fb, pb, qp));
@@ -416,7 +416,7 @@ __global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 && EP == HD && !oper_x2_a
     for (int fb = 0; fb < FB; ++fb)
 #pragma unroll
       for (int qp = 0; qp < 2; ++qp)
-        pr.v[fb][qp] = bload16<kAuxSpillLoad>(rsS, lane16 + ((fb * 2 + qp) & 3) * 1024, sb + ((fb * 2 + qp) >> 2) * 4096);
+        pr.v[fb][qp] = bload16<spill_load_aux(HD)>(rsS, lane16 + ((fb * 2 + qp) & 3) * 1024, sb + ((fb * 2 + qp) >> 2) * 4096);
   };
   auto load_f8 = [&](const Pre8& pr, int fb, int pb, int qp, float scale, float (&o)[8]) {
     const uint4 u = pr.v[fb][qp];
@@ -622,7 +622,7 @@ __global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 && EP == HD && !oper_x2_a
       put_x(F16, fb, pb, qp, pv, 0);
       if (toR2) put_x(F16, fb, pb, qp, pv, HD);
       if (MODE == 2) {
-        if constexpr (P8) store_f8(p.sp.P[li - 1], fb, pb, qp, pv, kSpillPScale, std::integral_constant<bool, kSpillStoreNT>{});
+        if constexpr (P8) store_f8(p.sp.P[li - 1], fb, pb, qp, pv, kSpillPScale, std::integral_constant<bool, spill_store_nt(HD)>{});
         else store_tile8(p.sp.P[li - 1], fb, pb, qp, pv);
       }
     });

@@ -37,8 +37,11 @@ constexpr int kAuxNT = 2;   // the non-temporal hint of a buffer load (aux bit 1
 // (profiles/r06_cache_policy.txt).  The dW kernel's operand loads are each tensor's LAST use: they stay non-temporal (dW +2.5 us
 // otherwise in the first A/B, nothing in the second), and so does the step tail's one read of the K-split slabs (chain +5 us
 // with the default policy there); the slabs themselves are STORED with the default policy (tail -1.8 us).
-constexpr bool kSpillStoreNT = false;   // the chain kernel's spill stores
-constexpr int kAuxSpillLoad = 0;        // ... and its re-reads
+// The 512-wide nets keep the non-temporal stream: their packed weight copies (10 MB) do not fit an XCD's L2 and live in the
+// Infinity Cache themselves -- with default-policy spills the chain kernel re-fetches them from HBM (5.4 -> 7.8 ms at the --wide
+// bench workload).  Larger batches of the 256-wide net (54 k .. 729 k points) are neutral to 3 % faster with the default policy.
+constexpr bool spill_store_nt(int hd) { return hd > 256; }            // the chain kernel's spill stores
+constexpr int spill_load_aux(int hd) { return hd > 256 ? kAuxNT : 0; }   // ... and its re-reads
 constexpr int kAuxDwLoad = kAuxNT;      // the dW kernel's operand loads
 template <int AUX> __device__ __forceinline__ uint4 bload16(rsrc_t r, int voff, int soff) {
   const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, AUX);
@@ -65,7 +68,7 @@ __device__ __forceinline__ i32x4 make_srd(const void* base, uint32_t bytes) {
   asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen offset:" #IMM " nt\n\ts_nop 1" ::"v"(v), "v"(voff), "s"(srd), "s"(soff) : "memory")
 #define ISDF_BSTORE16_DF(IMM) \
   asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen offset:" #IMM "\n\ts_nop 1" ::"v"(v), "v"(voff), "s"(srd), "s"(soff) : "memory")
-template <bool NT = kSpillStoreNT>
+template <bool NT>
 __device__ __forceinline__ void bstore16_nt(uint4 x, i32x4 srd, int voff, int soff, int c) {
   u32x4 v; v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w;
   soff += (c >> 2) * 4096;

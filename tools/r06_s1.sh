@@ -1,7 +1,10 @@
 cd $GRAFT_REPO_ROOT; O=gpurun_out/r06_cachepol; mkdir -p $O
-timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | tail -3 > $O/gpu_tests.txt; cat $O/gpu_tests.txt
-for rep in 1 2; do for f in variants/lib_*.so; do
-  ISDF_HIP_LIB=$PWD/$f python bench.py --steps 200 --warmup 30 --no-cpu-baseline --no-accuracy 2>/dev/null | tail -1 | python -c "
+run() { name=$1; shift; for f in variants/lib_prev.so variants/lib_new.so; do
+  ISDF_HIP_LIB=$PWD/$f python bench.py "$@" --no-cpu-baseline --no-accuracy 2>/dev/null | tail -1 | python -c "
 import sys,json
-j=json.loads(sys.stdin.read()); print('%-10s rep$rep  sync %.4f ms  pipelined %.4f ms  chain %.4f dw %.4f tail %.4f' % ('$f'.split('lib_')[1][:-3], j['ms_per_step'], j['pipelined']['ms_per_step'], *list(j['kernel_ms'].values())[:3]))"
-done; done > $O/ab_final.txt 2>&1; cat $O/ab_final.txt
+j=json.loads(sys.stdin.read()); print('%-12s %-6s sync %.4f ms  pipelined %.4f ms  chain %.4f dw %.4f tail %.4f' % ('$name', '$f'.split('lib_')[1][:-3], j['ms_per_step'], j['pipelined']['ms_per_step'], *list(j['kernel_ms'].values())[:3]))"
+done; }
+{ run default --steps 200 --warmup 30
+  run wide --wide --steps 30 --warmup 5
+} > $O/other_workloads2.txt 2>&1; cat $O/other_workloads2.txt
+timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu 2>&1 | tail -2
