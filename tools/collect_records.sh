@@ -12,7 +12,7 @@ done
 cp $O/hbm_traffic.json $P/r${NN}_hbm_traffic.json
 cp $O/pmc_summary.csv $P/r${NN}_pmc_bench.csv
 for s in "" _infer _ingest _sampler; do
-  f=$(find $O/stats$s -name '*kernel_stats.csv' | head -1)
+  f=$(ls -t $(find $O/stats$s -name '*kernel_stats.csv') 2>/dev/null | head -1)      # (a re-run leaves the earlier run's files beside the new ones)
   case "$s" in "") d=$P/r${NN}_kernel_stats.csv;; _infer) d=$P/r${NN}_kernel_stats_inference_8M.csv;; _ingest) d=$P/r${NN}_kernel_stats_ingest.csv;; _sampler) d=$P/r${NN}_kernel_stats_sampler_1M.csv;; esac
   [ -n "$f" ] && cp "$f" "$d"
 done
