@@ -30,7 +30,8 @@ template <int HD> struct DwTile {
   static constexpr int TEN = BM * ROWB;           // one operand slice in LDS
   static constexpr int AUXB = BM * 32;            // one tile's pe_aux rows (8 floats per point)
   static constexpr int DIRTAB = 4 * TEN + 2 * AUXB;      // the 21 directions / 2 pi, 16 bytes each (PE units)
-  static constexpr int LDS_BYTES = DIRTAB + 512;         // two operand slices x two stage buffers + two tiles of pe_aux + the directions
+  static constexpr int DUMMY = DIRTAB + 512;             // a spare row: where the stores of threads without work go (PE fill, last round)
+  static constexpr int LDS_BYTES = DUMMY + ROWB;          // two operand slices x two stage buffers + two tiles of pe_aux + the directions + the spare row
   static constexpr int CH = (BM * DW_BLK * 2) / (NT * 16);  // uint4 per thread per 16-bit tensor (8); an e4m3 tensor has half
 };
 
@@ -178,12 +179,13 @@ __global__ __launch_bounds__(256, 1) void dw_kernel(const DwParams p) {
     }
     __builtin_amdgcn_sched_barrier(0);
   };
-  auto compute = [&](int buf, auto nvTag, auto nwTag, auto&& between0) {
+  auto compute = [&](int buf, auto nvTag, auto nwTag, auto&& pre, auto&& between0) {
     auto between = [&](auto ks, auto h) { between0(ks, h); pipeline(nvTag, nwTag); };
     const char* sb = smem + buf * 2 * T::TEN;
     typedef std::integral_constant<int, 0> I0; typedef std::integral_constant<int, 1> I1;
     typedef std::integral_constant<int, 2> I2; typedef std::integral_constant<int, 3> I3;
     bf16x8 a0[2], a1[2], b0[4], b1[4];
+    pre();                                      // (PE units: the LDS reads of the first fill round, a half-step ahead of their use)
     loadB(sb, 0, b0); loadA(sb, 0, 0, a0);
     loadA(sb, 0, 1, a1);                        mfmas(I0{}, a0, b0); between(I0{}, I0{});
     loadB(sb, 1, b1); loadA(sb, 1, 0, a0);      mfmas(I1{}, a1, b0); between(I0{}, I1{});
@@ -196,8 +198,12 @@ __global__ __launch_bounds__(256, 1) void dw_kernel(const DwParams p) {
   };
 
   // The stage pipeline, once per kind of unit (PE: the input-side operand is rebuilt from pe_aux, not loaded; p8: this unit's P is e4m3).
-  auto run = [&](auto pe_tag, auto p8_tag) {
+  // (NFT: a PE unit's octave count at compile time = the ALIGNED operand order, or 0 = the reference's order with a run-time octave loop.
+  // A launch-uniform choice, but made per run() instantiation and not inside the fill: a branch there would cut every half-step's
+  // scheduling region in two and put the fill BEHIND the MFMAs instead of between them.)
+  auto run = [&](auto pe_tag, auto p8_tag, auto nft_tag) {
     constexpr bool PE = decltype(pe_tag)::value;
+    constexpr int NFT = decltype(nft_tag)::value;
     constexpr bool p8 = decltype(p8_tag)::value, g8 = SP8 & 1;     // this unit's P / GB are e4m3 tensors
     constexpr int CHA1 = p8 ? CH8 : CH, CHB1 = g8 ? CH8 : CH;
     // Two register sets so TWO stages of global loads are in flight while one is computed.
@@ -266,8 +272,8 @@ __global__ __launch_bounds__(256, 1) void dw_kernel(const DwParams p) {
       const uint4 v = bload16<0>(make_rsrc(p.pe_aux + (int64_t)(split + k * DW_SPLITK) * BM * 8, BM * 32), (tid & 127) * 16, 0);
       auxr = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
     };
-    auto store_aux = [&](int k) {
-      if (tid < 128) *(float4*)(smem + 4 * T::TEN + (k & 1) * T::AUXB + tid * 16) = auxr;
+    auto store_aux = [&](int k) {         // (threads 128.. hold and store the same rows again: no branch in the stage loop)
+      *(float4*)(smem + 4 * T::TEN + (k & 1) * T::AUXB + (tid & 127) * 16) = auxr;
     };
     auto put16 = [&](char* tile, const auto& r, auto cTag) {      // chunk c of a 16-bit operand slice: a frag16 piece -> row-major LDS tile
       constexpr int c = decltype(cTag)::value;       // chunk c sits 32 features = 64 bytes (above the swizzled bits) behind chunk 0
@@ -283,12 +289,31 @@ __global__ __launch_bounds__(256, 1) void dw_kernel(const DwParams p) {
       *(uint2*)(tile + wr8B + 32 * ROWB + c * 128) = make_uint2(cvt2(a.w, s1, std::false_type{}), cvt2(a.w, s1, std::true_type{}));
     };
     // round r of the PE fill of stage st (parity ODD) into its LDS buffer
+    // The three LDS reads of a round (the point's x' and gbar rows of pe_aux, the direction) are issued ONE ROUND AHEAD of the VALU work
+    // that consumes them: with one wave per SIMD a wait for an LDS read stalls everything behind it, the MFMAs included.
+    float4 fy = make_float4(0.f, 0.f, 0.f, 0.f), fg = fy, fdr = fy;
+    auto item_of = [&](auto rTag, int& pt, int& d) {
+      constexpr int r = decltype(rTag)::value;
+      int it = tid + NT * r;                                      // item = (point, direction); the last round's threads 64.. : a point's x' row
+      asm volatile("" : "+v"(it));                                // (opaque: or the compiler hoists point / direction / addresses of all six rounds out of the stage loop and spills them)
+      pt = r == NR - 1 && it >= BM * N_DIRS ? (it - BM * N_DIRS) & (BM - 1) : it / N_DIRS;
+      d = r == NR - 1 && it >= BM * N_DIRS ? 0 : it - pt * N_DIRS;
+    };
+    auto fill_fetch = [&](int st, auto oddTag, auto rTag) {
+      int pt, d;
+      item_of(rTag, pt, d);
+      const char* ax = smem + 4 * T::TEN + ((st >> 1) & 1) * T::AUXB + pt * 32;
+      fy = *(const float4*)ax;
+      if constexpr (decltype(oddTag)::value) fg = *(const float4*)(ax + 16);
+      fdr = *(const float4*)(smem + T::DIRTAB + d * 16);
+    };
     auto fill_round = [&](int st, auto oddTag, auto rTag) {
       constexpr bool Q1 = decltype(oddTag)::value;
       constexpr int r = decltype(rTag)::value;
+      const float4 y = fy, g = fg, dr = fdr;                      // this round's rows, fetched a round ago ...
+      if constexpr (r + 1 < NR) fill_fetch(st, oddTag, std::integral_constant<int, r + 1>{});      // ... and the next round's on their way
       // q = 0: the embedding (embedding.py:95-111): [x' | sin(xb_df) | cos(xb_df)], xb_df = (x' . dir_d) 2^f
       // q = 1: Ebar = J_pe gbar (chain.hip's Ebar stage): [gbar | cos(xb_df) k_df | -sin(xb_df) k_df], k_df = (gbar . dir_d) 2^f
-      const char* auxl = smem + 4 * T::TEN + ((st >> 1) & 1) * T::AUXB;
       char* tb = smem + (Q1 ? 1 : 0) * 2 * T::TEN + T::TEN;
       const int nf = L.n_freqs, halfE = N_DIRS * nf, colBase = slBfull * DW_BLK;
       typedef typename Op<F16>::e eT;
@@ -297,56 +322,47 @@ __global__ __launch_bounds__(256, 1) void dw_kernel(const DwParams p) {
         if ((unsigned)col < (unsigned)DW_BLK) *(eT*)(row + ((col * 2) ^ xs)) = (eT)v;
       };
       constexpr bool lastRound = r == NR - 1;
-      int it = tid + NT * r;                                      // item = (point, direction); the last round's threads 64.. : a point's x' row
-      asm volatile("" : "+v"(it));                                // (opaque: or the compiler hoists point / direction / addresses of all six rounds out of the stage loop and spills them)
-      const int pt = lastRound && it >= BM * N_DIRS ? (it - BM * N_DIRS) & (BM - 1) : it / N_DIRS, d = it - pt * N_DIRS;
+      int pt, d;
+      item_of(rTag, pt, d);
       const int xs = ((pt >> 1) & 7) << 3;                        // the row's swizzle
       char* row = tb + pt * ROWB;
       constexpr int lastItems = BM * N_DIRS - NT * (NR - 1);      // direction items of the last round (64)
-      auto item = [&](auto nfc) {
-        constexpr int NFT = decltype(nfc)::value;               // n_freqs at compile time: the ALIGNED column order (0: run-time loop, 2-byte stores)
-        const char* ax = auxl + pt * 32;
-        if (!lastRound || tid < lastItems) {
-          const float4 y = *(const float4*)ax;
-          const float4 dr = *(const float4*)(smem + T::DIRTAB + d * 16);
-          const float r0 = y.x * dr.x + y.y * dr.y + y.z * dr.z;
-          float sn = __builtin_amdgcn_sinf(r0), cs = __builtin_amdgcn_cosf(r0), kf = 0.f;
-          if constexpr (Q1) {
-            const float4 g = *(const float4*)(ax + 16);
-            kf = (g.x * dr.x + g.y * dr.y + g.z * dr.z) * k2Pi;
-          }
-          auto vals = [&](float& a, float& b) {        // this octave's two values, then on to the next octave
-            a = Q1 ? cs * kf : sn; b = Q1 ? -sn * kf : cs;
-            const float t = sn * cs;
-            cs = __builtin_fmaf(-2.f * sn, sn, 1.f); sn = t + t; kf += kf;
-          };
-          if constexpr (NFT == 0) {
-            const int cS = 3 + d * nf - colBase, cC = cS + halfE;      // first column of the sine / cosine group in this slice
-            for (int f = 0; f < nf; ++f) { float a, b; vals(a, b); st1(row, xs, cS + f, a); st1(row, xs, cC + f, b); }
-          } else {
-            static_assert(NFT % 2 == 0, "paired stores assume an even octave count");
-            const int cs0 = d * NFT * 2, cc0 = cs0 + N_DIRS * NFT * 2;    // 4-byte aligned: column d * NFT of row pt
-#pragma unroll
-            for (int f = 0; f < NFT; f += 2) {
-              float a, b, a2, b2;
-              vals(a, b); vals(a2, b2);
-              e2 vs, vc; vs[0] = (eT)a; vs[1] = (eT)a2; vc[0] = (eT)b; vc[1] = (eT)b2;
-              *(e2*)(row + ((cs0 + f * 2) ^ xs)) = vs; *(e2*)(row + ((cc0 + f * 2) ^ xs)) = vc;
-            }
-          }
-        } else if (tid < lastItems + BM) {
-          const float4 v = *(const float4*)(ax + (Q1 ? 16 : 0));
-          if constexpr (NFT != 0) {      // aligned order: x' behind the 42 n_freqs sine / cosine columns, then the padding
-            e2 v01, v2z; v01[0] = (eT)v.x; v01[1] = (eT)v.y; v2z[0] = (eT)v.z; v2z[1] = (eT)0.f;
-            *(e2*)(row + ((2 * N_DIRS * NFT * 2) ^ xs)) = v01; *(e2*)(row + ((2 * N_DIRS * NFT * 2 + 4) ^ xs)) = v2z;
-            for (int f = 2 * N_DIRS * NFT + 4; f < DW_BLK; f += 2) { e2 z; z[0] = (eT)0.f; z[1] = (eT)0.f; *(e2*)(row + ((f * 2) ^ xs)) = z; }
-          } else {
-            st1(row, xs, 0 - colBase, v.x); st1(row, xs, 1 - colBase, v.y); st1(row, xs, 2 - colBase, v.z);
-            for (int f = L.E; f < L.EP; ++f) st1(row, xs, f - colBase, 0.f);
-          }
-        }
+      const float r0 = y.x * dr.x + y.y * dr.y + y.z * dr.z;
+      float sn = __builtin_amdgcn_sinf(r0), cs = __builtin_amdgcn_cosf(r0), kf = 0.f;
+      if constexpr (Q1) kf = (g.x * dr.x + g.y * dr.y + g.z * dr.z) * k2Pi;
+      auto vals = [&](float& a, float& b) {        // this octave's two values, then on to the next octave
+        a = Q1 ? cs * kf : sn; b = Q1 ? -sn * kf : cs;
+        const float t = sn * cs;
+        cs = __builtin_fmaf(-2.f * sn, sn, 1.f); sn = t + t; kf += kf;
       };
-      if (peAligned && nf == 6) item(std::integral_constant<int, 6>{}); else item(std::integral_constant<int, 0>{});
+      if constexpr (NFT != 0) {
+        // STRAIGHT-LINE code: in the last round, which has 64 direction items and 64 x' rows for 256 threads, every thread runs both
+        // store sequences and the ones without work aim at a spare LDS row (a select, not a branch)
+        static_assert(NFT % 2 == 0 && 2 * N_DIRS * NFT + 4 == DW_BLK, "paired stores; x' and one zero fill the slice behind the 42 NFT sine / cosine columns");
+        char* dummy = smem + T::DUMMY;
+        char* irow = !lastRound || tid < lastItems ? row : dummy;
+        const int cs0 = d * NFT * 2, cc0 = cs0 + N_DIRS * NFT * 2;    // 4-byte aligned: column d * NFT of row pt
+#pragma unroll
+        for (int f = 0; f < NFT; f += 2) {
+          float a, b, a2, b2;
+          vals(a, b); vals(a2, b2);
+          e2 vs, vc; vs[0] = (eT)a; vs[1] = (eT)a2; vc[0] = (eT)b; vc[1] = (eT)b2;
+          *(e2*)(irow + ((cs0 + f * 2) ^ xs)) = vs; *(e2*)(irow + ((cc0 + f * 2) ^ xs)) = vc;
+        }
+        if constexpr (lastRound) {      // aligned order: x' behind the sine / cosine columns
+          char* xrow = tid >= lastItems && tid < lastItems + BM ? row : dummy;
+          const float4 v = Q1 ? g : y;
+          e2 v01, v2z; v01[0] = (eT)v.x; v01[1] = (eT)v.y; v2z[0] = (eT)v.z; v2z[1] = (eT)0.f;
+          *(e2*)(xrow + ((2 * N_DIRS * NFT * 2) ^ xs)) = v01; *(e2*)(xrow + ((2 * N_DIRS * NFT * 2 + 4) ^ xs)) = v2z;
+        }
+      } else if (!lastRound || tid < lastItems) {
+        const int cS = 3 + d * nf - colBase, cC = cS + halfE;      // first column of the sine / cosine group in this slice
+        for (int f = 0; f < nf; ++f) { float a, b; vals(a, b); st1(row, xs, cS + f, a); st1(row, xs, cC + f, b); }
+      } else if (tid < lastItems + BM) {
+        const float4 v = Q1 ? g : y;
+        st1(row, xs, 0 - colBase, v.x); st1(row, xs, 1 - colBase, v.y); st1(row, xs, 2 - colBase, v.z);
+        for (int f = L.E; f < L.EP; ++f) st1(row, xs, f - colBase, 0.f);
+      }
     };
     // slice (ks, h) of stage st's way into its LDS buffer: chunk 2 ks + h of every 16-bit tensor, chunk ks of an e4m3 tensor (P at
     // h = 0, GB at h = 1) and, for a PE unit, its share of the six fill rounds
@@ -394,6 +410,7 @@ __global__ __launch_bounds__(256, 1) void dw_kernel(const DwParams p) {
     each_slice([&](auto k, auto h) { issue(0, std::false_type{}, k, h); });
     each_slice([&](auto k, auto h) { issue(1, std::true_type{}, k, h); });
     if constexpr (PE) __syncthreads();          // tile 0's pe_aux rows are in LDS
+    if constexpr (PE) fill_fetch(0, std::false_type{}, std::integral_constant<int, 0>{});
     each_slice([&](auto k, auto h) { commit(0, std::false_type{}, k, h); issue(2, std::false_type{}, k, h); });
     __syncthreads();
 
@@ -404,13 +421,15 @@ __global__ __launch_bounds__(256, 1) void dw_kernel(const DwParams p) {
     typedef std::integral_constant<int, PE ? 12 : 4> NV;      // VALU / LDS-store instructions per MFMA slot (the PE fill is ~90 VALU a round)
     typedef std::integral_constant<int, PE ? 2 : 1> NW;
     for (int st = 0; st < nStages; st += 2) {       // (nStages is even: two stages per tile)
-      compute(0, NV{}, NW{}, [&](auto ks, auto h) {             // stage st (even) computes; stage st + 1 (odd) goes into buffer 1
+      compute(0, NV{}, NW{}, [&] { if constexpr (PE) fill_fetch(st + 1, std::true_type{}, std::integral_constant<int, 0>{}); },
+              [&](auto ks, auto h) {                            // stage st (even) computes; stage st + 1 (odd) goes into buffer 1
         commit(st + 1, std::true_type{}, ks, h);
         issue(st + 3, std::true_type{}, ks, h);
         if constexpr (PE && decltype(ks)::value == 3 && decltype(h)::value == 1) { store_aux((st >> 1) + 1); load_aux((st >> 1) + 2); }
       });
       __syncthreads();
-      compute(1, NV{}, NW{}, [&](auto ks, auto h) {             // stage st + 1 computes; stage st + 2 (even) goes into buffer 0
+      compute(1, NV{}, NW{}, [&] { if constexpr (PE) fill_fetch(st + 2, std::false_type{}, std::integral_constant<int, 0>{}); },
+              [&](auto ks, auto h) {                            // stage st + 1 computes; stage st + 2 (even) goes into buffer 0
         commit(st + 2, std::false_type{}, ks, h);
         issue(st + 4, std::false_type{}, ks, h);
       });
@@ -419,9 +438,10 @@ __global__ __launch_bounds__(256, 1) void dw_kernel(const DwParams p) {
   };
   typedef std::integral_constant<bool, (SP8 & 2) != 0> P8T;
   if (nStages == 0) {}      // (more K-splits than tiles: a zero slab)
-  else if (fromEmb) run(std::true_type{}, P8T{});
-  else if ((SP8 & 2) && li == L.L - 1) run(std::false_type{}, std::false_type{});      // the top layer's P stays 16-bit (SpillLayout)
-  else run(std::false_type{}, P8T{});
+  else if (fromEmb && peAligned) run(std::true_type{}, P8T{}, std::integral_constant<int, 6>{});
+  else if (fromEmb) run(std::true_type{}, P8T{}, std::integral_constant<int, 0>{});
+  else if ((SP8 & 2) && li == L.L - 1) run(std::false_type{}, std::false_type{}, std::integral_constant<int, 0>{});      // the top layer's P stays 16-bit (SpillLayout)
+  else run(std::false_type{}, P8T{}, std::integral_constant<int, 0>{});
 
   // partial slab [o][i]
   slab_t* slab = (slab_t*)p.dwPart + ((int64_t)dw_slab_base(L, unit) + split) * DW_BLK * DW_BLK;
