@@ -126,6 +126,9 @@ __global__ __launch_bounds__(256, 1) void dw_kernel(const DwParams p) {
   // groups of eight chunks per row, so the XOR only changes which lane reads which chunk of the same bank set.
   const int trX = ((trRow >> 1) & 7) << 3;
   const int trOffA = trRow * ROWB + (trColB ^ trX), trOffB = (trRow + 4) * ROWB + (trColB ^ trX ^ 16);
+  // (the operand slice a PE unit REBUILDS is written by its fill, not by the commit: it stays unswizzled -- the fill's 4-byte stores
+  // then take immediate offsets instead of an XOR and an add each)
+  const int trOffA_in = fromEmb ? trRow * ROWB + trColB : trOffA, trOffB_in = fromEmb ? (trRow + 4) * ROWB + trColB : trOffB;
   // where this thread's pieces go (chunk 0; see put16 / put8 in run()): a frag16 piece c NT + tid is point pt16, features f16.. and
   // f16 + 8..; a frag8 piece is points ln & 31 and 32 + (ln & 31), features f8.. and f8 + 8.. (rows pt and pt + 32 share swz)
   int pt16, f16;
@@ -134,10 +137,10 @@ __global__ __launch_bounds__(256, 1) void dw_kernel(const DwParams p) {
   const int f8 = (w >> 1) * 32 + 16 * (w & 1) + 4 * (lane >> 5);
   const int wr8A = (lane & 31) * ROWB + ((f8 * 2) ^ ((((lane & 31) >> 1) & 7) << 3)), wr8B = wr8A ^ 16;
   typedef bf16x4 __attribute__((address_space(3))) * lds4;
-  auto trload = [&](const char* base, int ptBase, int colElem) -> bf16x8 {
+  auto trload = [&](const char* base, int ptBase, int colElem, int offA, int offB) -> bf16x8 {
     const char* a0 = base + ptBase * ROWB + colElem * 2;      // (ptBase: a multiple of 16, colElem of 32: above the swizzled bits)
-    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4)(a0 + trOffA));
-    bf16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4)(a0 + trOffB));
+    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4)(a0 + offA));
+    bf16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4)(a0 + offB));
     bf16x8 r;
     r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
     r[4] = hi4[0]; r[5] = hi4[1]; r[6] = hi4[2]; r[7] = hi4[3];
@@ -150,11 +153,11 @@ __global__ __launch_bounds__(256, 1) void dw_kernel(const DwParams p) {
   // behind the MFMAs of half-step (ks, h).
   typedef typename Op<F16>::v8 opv8;
   auto loadA = [&](const char* sb, int ks, int h, bf16x8 (&a)[2]) {
-    a[0] = trload(sb, ks * 16, wo * 128 + (2 * h) * 32); a[1] = trload(sb, ks * 16, wo * 128 + (2 * h + 1) * 32);
+    a[0] = trload(sb, ks * 16, wo * 128 + (2 * h) * 32, trOffA, trOffB); a[1] = trload(sb, ks * 16, wo * 128 + (2 * h + 1) * 32, trOffA, trOffB);
   };
   auto loadB = [&](const char* sb, int ks, bf16x8 (&b)[4]) {
 #pragma unroll
-    for (int ib = 0; ib < 4; ++ib) b[ib] = trload(sb + T::TEN, ks * 16, wi * 128 + ib * 32);
+    for (int ib = 0; ib < 4; ++ib) b[ib] = trload(sb + T::TEN, ks * 16, wi * 128 + ib * 32, trOffA_in, trOffB_in);
   };
   auto mfmas = [&](auto hTag, const bf16x8 (&a)[2], const bf16x8 (&b)[4]) {
     constexpr int h = decltype(hTag)::value;
@@ -292,25 +295,30 @@ __global__ __launch_bounds__(256, 1) void dw_kernel(const DwParams p) {
     // The three LDS reads of a round (the point's x' and gbar rows of pe_aux, the direction) are issued ONE ROUND AHEAD of the VALU work
     // that consumes them: with one wave per SIMD a wait for an LDS read stalls everything behind it, the MFMAs included.
     float4 fy = make_float4(0.f, 0.f, 0.f, 0.f), fg = fy, fdr = fy;
-    auto item_of = [&](auto rTag, int& pt, int& d) {
-      constexpr int r = decltype(rTag)::value;
-      int it = tid + NT * r;                                      // item = (point, direction); the last round's threads 64.. : a point's x' row
-      asm volatile("" : "+v"(it));                                // (opaque: or the compiler hoists point / direction / addresses of all six rounds out of the stage loop and spills them)
-      pt = r == NR - 1 && it >= BM * N_DIRS ? (it - BM * N_DIRS) & (BM - 1) : it / N_DIRS;
-      d = r == NR - 1 && it >= BM * N_DIRS ? 0 : it - pt * N_DIRS;
-    };
+    // (point, direction) of the round in flight: item = tid + 256 r, 256 = 12 x 21 + 4 -- each round is twelve points and four
+    // directions past the previous one; round 0 starts from the thread's constants behind an opaque copy (or the compiler hoists the
+    // six rounds' points / directions / addresses out of the stage loop and spills them).  Last round: threads 64.. own a point's x' row.
+    int fpt = 0, fd = 0;
+    const int pt0 = tid / N_DIRS, d0 = tid - pt0 * N_DIRS;
+    static_assert(NT == 12 * N_DIRS + 4, "incremental item update");
     auto fill_fetch = [&](int st, auto oddTag, auto rTag) {
-      int pt, d;
-      item_of(rTag, pt, d);
-      const char* ax = smem + 4 * T::TEN + ((st >> 1) & 1) * T::AUXB + pt * 32;
+      constexpr int r = decltype(rTag)::value;
+      if constexpr (r == 0) { fpt = pt0; fd = d0; asm volatile("" : "+v"(fpt), "+v"(fd)); }
+      else {
+        fd += 4; fpt += 12;
+        if (fd >= N_DIRS) { fd -= N_DIRS; fpt += 1; }
+        if constexpr (r == NR - 1) { if (tid >= BM * N_DIRS - NT * (NR - 1)) { fpt = (tid - (BM * N_DIRS - NT * (NR - 1))) & (BM - 1); fd = 0; } }
+      }
+      const char* ax = smem + 4 * T::TEN + ((st >> 1) & 1) * T::AUXB + fpt * 32;
       fy = *(const float4*)ax;
       if constexpr (decltype(oddTag)::value) fg = *(const float4*)(ax + 16);
-      fdr = *(const float4*)(smem + T::DIRTAB + d * 16);
+      fdr = *(const float4*)(smem + T::DIRTAB + fd * 16);
     };
     auto fill_round = [&](int st, auto oddTag, auto rTag) {
       constexpr bool Q1 = decltype(oddTag)::value;
       constexpr int r = decltype(rTag)::value;
       const float4 y = fy, g = fg, dr = fdr;                      // this round's rows, fetched a round ago ...
+      const int pt = fpt, d = fd;
       if constexpr (r + 1 < NR) fill_fetch(st, oddTag, std::integral_constant<int, r + 1>{});      // ... and the next round's on their way
       // q = 0: the embedding (embedding.py:95-111): [x' | sin(xb_df) | cos(xb_df)], xb_df = (x' . dir_d) 2^f
       // q = 1: Ebar = J_pe gbar (chain.hip's Ebar stage): [gbar | cos(xb_df) k_df | -sin(xb_df) k_df], k_df = (gbar . dir_d) 2^f
@@ -318,13 +326,10 @@ __global__ __launch_bounds__(256, 1) void dw_kernel(const DwParams p) {
       const int nf = L.n_freqs, halfE = N_DIRS * nf, colBase = slBfull * DW_BLK;
       typedef typename Op<F16>::e eT;
       typedef eT e2 __attribute__((ext_vector_type(2)));
-      auto st1 = [&](char* row, int xs, int col, float v) {    // one column; `col` relative to this unit's 256-column slice; xs: the row's swizzle
-        if ((unsigned)col < (unsigned)DW_BLK) *(eT*)(row + ((col * 2) ^ xs)) = (eT)v;
+      auto st1 = [&](char* row, int col, float v) {            // one column; `col` relative to this unit's 256-column slice
+        if ((unsigned)col < (unsigned)DW_BLK) *(eT*)(row + col * 2) = (eT)v;
       };
       constexpr bool lastRound = r == NR - 1;
-      int pt, d;
-      item_of(rTag, pt, d);
-      const int xs = ((pt >> 1) & 7) << 3;                        // the row's swizzle
       char* row = tb + pt * ROWB;
       constexpr int lastItems = BM * N_DIRS - NT * (NR - 1);      // direction items of the last round (64)
       const float r0 = y.x * dr.x + y.y * dr.y + y.z * dr.z;
@@ -332,8 +337,9 @@ __global__ __launch_bounds__(256, 1) void dw_kernel(const DwParams p) {
       if constexpr (Q1) kf = (g.x * dr.x + g.y * dr.y + g.z * dr.z) * k2Pi;
       auto vals = [&](float& a, float& b) {        // this octave's two values, then on to the next octave
         a = Q1 ? cs * kf : sn; b = Q1 ? -sn * kf : cs;
-        const float t = sn * cs;
-        cs = __builtin_fmaf(-2.f * sn, sn, 1.f); sn = t + t; kf += kf;
+        const float u = sn + sn;                   // (2 s) c and 1 - (2 s) s: the same values as 2 (s c) and fma(-2 s, s, 1), one operation less
+        const float c2 = __builtin_fmaf(-u, sn, 1.f);
+        sn = u * cs; cs = c2; kf += kf;
       };
       if constexpr (NFT != 0) {
         // STRAIGHT-LINE code: in the last round, which has 64 direction items and 64 x' rows for 256 threads, every thread runs both
@@ -347,21 +353,21 @@ __global__ __launch_bounds__(256, 1) void dw_kernel(const DwParams p) {
           float a, b, a2, b2;
           vals(a, b); vals(a2, b2);
           e2 vs, vc; vs[0] = (eT)a; vs[1] = (eT)a2; vc[0] = (eT)b; vc[1] = (eT)b2;
-          *(e2*)(irow + ((cs0 + f * 2) ^ xs)) = vs; *(e2*)(irow + ((cc0 + f * 2) ^ xs)) = vc;
+          *(e2*)(irow + cs0 + f * 2) = vs; *(e2*)(irow + cc0 + f * 2) = vc;
         }
         if constexpr (lastRound) {      // aligned order: x' behind the sine / cosine columns
           char* xrow = tid >= lastItems && tid < lastItems + BM ? row : dummy;
           const float4 v = Q1 ? g : y;
           e2 v01, v2z; v01[0] = (eT)v.x; v01[1] = (eT)v.y; v2z[0] = (eT)v.z; v2z[1] = (eT)0.f;
-          *(e2*)(xrow + ((2 * N_DIRS * NFT * 2) ^ xs)) = v01; *(e2*)(xrow + ((2 * N_DIRS * NFT * 2 + 4) ^ xs)) = v2z;
+          *(e2*)(xrow + 2 * N_DIRS * NFT * 2) = v01; *(e2*)(xrow + 2 * N_DIRS * NFT * 2 + 4) = v2z;
         }
       } else if (!lastRound || tid < lastItems) {
         const int cS = 3 + d * nf - colBase, cC = cS + halfE;      // first column of the sine / cosine group in this slice
-        for (int f = 0; f < nf; ++f) { float a, b; vals(a, b); st1(row, xs, cS + f, a); st1(row, xs, cC + f, b); }
+        for (int f = 0; f < nf; ++f) { float a, b; vals(a, b); st1(row, cS + f, a); st1(row, cC + f, b); }
       } else if (tid < lastItems + BM) {
         const float4 v = Q1 ? g : y;
-        st1(row, xs, 0 - colBase, v.x); st1(row, xs, 1 - colBase, v.y); st1(row, xs, 2 - colBase, v.z);
-        for (int f = L.E; f < L.EP; ++f) st1(row, xs, f - colBase, 0.f);
+        st1(row, 0 - colBase, v.x); st1(row, 1 - colBase, v.y); st1(row, 2 - colBase, v.z);
+        for (int f = L.E; f < L.EP; ++f) st1(row, f - colBase, 0.f);
       }
     };
     // slice (ks, h) of stage st's way into its LDS buffer: chunk 2 ks + h of every 16-bit tensor, chunk ks of an e4m3 tensor (P at

@@ -1,6 +1,6 @@
 cd $GRAFT_REPO_ROOT; O=gpurun_out/r06_dwv2; mkdir -p $O
 ISDF_HIP_LIB=$PWD/variants/lib_prev.so python tools/train_ab_check.py --dump /tmp/a.npz > $O/ab_check.txt 2>&1
-ISDF_HIP_LIB=$PWD/variants/lib_sl.so python tools/train_ab_check.py --dump /tmp/b.npz >> $O/ab_check.txt 2>&1
+ISDF_HIP_LIB=$PWD/variants/lib_sl2.so python tools/train_ab_check.py --dump /tmp/b.npz >> $O/ab_check.txt 2>&1
 python tools/train_ab_check.py --compare /tmp/a.npz /tmp/b.npz 2>&1 | grep "/grad" >> $O/ab_check.txt
 grep "/grad" $O/ab_check.txt
 for rep in 1 2; do for f in variants/lib_*.so; do
