@@ -145,18 +145,30 @@ def _stream(device=None):
     return C.c_void_p(torch.cuda.current_stream(idx).cuda_stream)
 
 
+_RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)     # hipStream_t of a device's current stream as an int, ~0.2 us
+_STREAM_OBJ = {}  # device index -> (torch.cuda.Stream, c_void_p, raw handle): torch.cuda.current_stream() builds a new object per call (~3 us)
+
+
 class pinned_stream:
     """with pinned_stream(device) as st: every Engine call on that device inside launches on `st` (torch's current
-    stream of the device at entry).  Keyed per device, so trainers on different devices do not overwrite each other."""
+    stream of the device at entry).  Keyed per device, so trainers on different devices do not overwrite each other.
+    The Stream object is cached per device and re-used while the device's current RAW stream is the one it wraps
+    (a caller's `torch.cuda.stream(...)` context changes the raw handle and is honoured)."""
 
     def __init__(self, device=None):
-        self.idx = torch.cuda.current_device() if device is None or torch.device(device).index is None else torch.device(device).index
+        if isinstance(device, int):
+            self.idx = device
+        else:
+            self.idx = torch.cuda.current_device() if device is None or torch.device(device).index is None else torch.device(device).index
 
     def __enter__(self):
         self.prev = _PINNED.get(self.idx)
-        st = torch.cuda.current_stream(self.idx)
-        _PINNED[self.idx] = (st, C.c_void_p(st.cuda_stream))
-        return st
+        c = _STREAM_OBJ.get(self.idx)
+        if c is None or _RAW_STREAM is None or _RAW_STREAM(self.idx) != c[2]:
+            st = torch.cuda.current_stream(self.idx)
+            c = _STREAM_OBJ[self.idx] = (st, C.c_void_p(st.cuda_stream), st.cuda_stream)
+        _PINNED[self.idx] = c
+        return c[0]
 
     def __exit__(self, *exc):
         if self.prev is None:

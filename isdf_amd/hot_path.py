@@ -85,6 +85,9 @@ class FlatAdamW:
                 self.param_groups[0][k] = sd["param_groups"][0][k]
 
 
+_CUDA_GET_DEVICE = getattr(torch._C, "_cuda_getDevice", None)       # the current device index without torch.cuda's Python layers
+
+
 class StepLosses(dict):
     """`losses` of `Trainer.step`: keys sdf_loss / grad_loss / eikonal_loss (floats) and total_loss (0-d tensor;
     callers use '{:.6f}'.format and .item(), train.py:138,215).  Built from ONE 8-float device->host copy that
@@ -351,10 +354,14 @@ class HotPath:
         return (time.perf_counter() - start) * 1000.0
 
     def step(self):
-        if self._hip.device.type != "cuda":
+        dev = self._hip.device
+        if dev.type != "cuda":
             return self._step(None)
         from .engine import pinned_stream
-        with torch.cuda.device(self._hip.device), pinned_stream(self._hip.device) as st:
+        if _CUDA_GET_DEVICE is not None and dev.index is not None and _CUDA_GET_DEVICE() == dev.index:
+            with pinned_stream(dev.index) as st:      # already the current device: no device switch around the step (~3 us of host time)
+                return self._step(st)
+        with torch.cuda.device(dev), pinned_stream(dev) as st:
             return self._step(st)
 
     def _step(self, st):
