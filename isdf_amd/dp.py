@@ -64,6 +64,38 @@ def rccl_direct(group, device):
         return None
 
 
+def rccl_agree(lib, cand, group, device, stream_ptr):
+    """The group's decision on the direct path, identical on every rank (a split decision would deadlock the first step):
+    (1) every rank found its communicator handle (`cand` = rccl_direct(...), agreed with the framework's own collective);
+    (2) ONE small all-reduce through the direct path -- every rank contributes rank + 1 in 64 floats, the sum is known -- came out
+    right on every rank.  Otherwise all ranks use torch.distributed.all_reduce together.  This is where the direct path meets a
+    world size > 1 for the first time on a multi-GPU node (one-GPU boxes can only form an RCCL group of one rank), so it is checked
+    where it runs.  Collective: every rank of an RCCL group on HIP devices must call it (graft() does)."""
+    import os, warnings
+    if torch.device(device).type != "cuda" or torch.distributed.get_backend(group) != "nccl":
+        return None
+    if os.environ.get("ISDF_DP_COLLECTIVE", "").lower() == "torch":      # (an environment switch is the same on every rank of a launch)
+        return None
+    rank, world = torch.distributed.get_rank(group), torch.distributed.get_world_size(group)
+    flag = torch.tensor([1.0 if cand is not None else 0.0], device=device)
+    torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN, group=group)
+    if float(flag.item()) != 1.0:
+        return None
+    fn, comm = cand
+    t = torch.full((64,), float(rank + 1), dtype=torch.float32, device=device)
+    torch.cuda.synchronize(device)
+    rc = lib.isdf_allreduce_sum_f32(fn, comm, t.data_ptr(), 64, stream_ptr)
+    torch.cuda.synchronize(device)
+    ok = rc == 0 and bool((t == world * (world + 1) / 2.0).all().item())
+    flag.fill_(1.0 if ok else 0.0)
+    torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN, group=group)
+    if float(flag.item()) != 1.0:
+        warnings.warn("isdf_amd: the direct RCCL all-reduce failed its self-test (rank %d: rc %d, sums right: %s); "
+                      "every rank uses torch.distributed.all_reduce" % (rank, rc, ok))
+        return None
+    return cand
+
+
 def new_split_event(device):
     """an event whose native handle exists (torch creates it at the first record)"""
     ev = torch.cuda.Event()

@@ -770,6 +770,8 @@ def graft(trainer, rng="philox", seed=1, dist_group=None, fix_normal_window=Fals
         hip.window_rng_state = np.random.RandomState(hip.seed + 104729).get_state()   # replicated select_keyframes stream
         if hip.virtual_step_ms is None:                  # per-rank step-time slots in the tail of the all-reduce message
             hip.clock_slots = eng.reduce_extra = hip.world
-        hip.rccl = dp.rccl_direct(dist_group, hip.device) if hasattr(eng, "allreduce_direct") else None
+        if hasattr(eng, "allreduce_direct") and hip.device.type == "cuda":      # (the CPU tests' stand-in engine has no C library behind it)
+            from .engine import _stream
+            hip.rccl = dp.rccl_agree(eng.lib, dp.rccl_direct(dist_group, hip.device), dist_group, hip.device, _stream(hip.device))
         hip.collective = "rccl on the step's stream (isdf_allreduce_sum_f32)" if hip.rccl is not None else "torch.distributed.all_reduce"
     return trainer

@@ -1,6 +1,5 @@
-cd $GRAFT_REPO_ROOT; O=gpurun_out/r06_host; mkdir -p $O
-python tools/host_timeline.py 2>&1 | grep -v amdgpu.ids > $O/host_timeline2.txt; cat $O/host_timeline2.txt
-timeout 900 python -m pytest tests -x -q -m gpu -k "not parity" 2>&1 | tail -2
-for rep in 1 2; do python bench.py --steps 200 --warmup 30 --no-cpu-baseline --no-accuracy 2>/dev/null | tail -1 | python -c "
+cd $GRAFT_REPO_ROOT; O=gpurun_out/r06_dp; mkdir -p $O
+timeout 600 python -m pytest tests/test_dp_rccl_direct_gpu.py tests/test_dp_gpu.py tests/test_bench_launch.py -x -q -m gpu 2>&1 | tail -3
+ISDF_BENCH_FORCE_DP=1 python bench.py --steps 100 --warmup 30 --no-cpu-baseline --no-accuracy 2>/dev/null | tail -1 | python -c "
 import sys,json
-j=json.loads(sys.stdin.read()); print('rep$rep  sync %.4f ms  pipelined %.4f ms  chain %.4f dw %.4f tail %.4f' % (j['ms_per_step'], j['pipelined']['ms_per_step'], *list(j['kernel_ms'].values())[:3]))"; done
+j=json.loads(sys.stdin.read()); print('forced dp  sync %.4f ms  pipelined %.4f ms  collective %s' % (j['ms_per_step'], j['pipelined']['ms_per_step'], j['distributed'].get('collective')))"
