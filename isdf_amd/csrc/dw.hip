@@ -5,14 +5,15 @@
 // the input-gradient graph.  Operands are the bf16 tiles chain.hip spilled.
 //
 // Mapping: one workgroup = one 256x256 dW "unit" (a layer; the cat layer is two
-// units) x one K-split over point tiles.  8 waves as 4(o) x 2(i), each wave a
-// 64x128 fp32 accumulator (128 VGPRs).  The contraction index is the POINT, but
-// the spilled tiles are [point][feature], so both MFMA operands are fetched
-// with ds_read_b64_tr_b16 (LDS transpose read, gfx950) from row-major LDS
-// tiles; rows are padded by 64 B so the 4-row x 32-B footprints of the two
-// 16-lane groups of a half-wave fall in disjoint bank windows.  Global loads of
-// the next stage are issued into registers before the MFMAs of the current one
-// and written to LDS after the barrier (issue-early / write-late).
+// units) x one K-split over point tiles.  FOUR waves, one per SIMD, as 2(o) x 2(i),
+// each wave a 128x128 fp32 accumulator quadrant (256 of its 512 registers).  The
+// contraction index is the POINT, but the spilled tiles are [point][feature], so
+// both MFMA operands are fetched with ds_read_b64_tr_b16 (LDS transpose read,
+// gfx950) from row-major LDS tiles; rows are padded by 64 B so the four rows of a
+// transpose read fall in disjoint bank windows, and their 8-byte chunks are
+// XOR-swizzled by the row so that the commit's stores do too.  Two stages of global
+// loads are in flight; the next stage's way into LDS rides behind the MFMAs of the
+// running one, slice by slice (dw_kernel's header).
 #include "isdf_common.h"
 #include "chain_params.h"
 #include "chain_dev.h"
@@ -58,9 +59,11 @@ __device__ __forceinline__ int frag16_piece(int c, int half, int sl, int& pt, in
 // (profiles/r06_dw_unit_kinds.txt): every wave ran 4 x [12 transpose reads -> wait -> 8 MFMAs] with no read-ahead across k-steps (its
 // 24 operand registers were single-buffered beside a 128-register accumulator), all eight committed the next stage's 64 KB to LDS in
 // front of the first MFMA, and the matrix pipe was 39 % busy.  With one wave per SIMD a wave owns a 128 x 128 quadrant (256 accumulator
-// registers), reads the NEXT k-step's operands while the current one's 16 MFMAs run (2 x 32 registers), feeds every A fragment to four
+// registers), reads the operands of the next HALF-step while the current one's 8 MFMAs run (48 registers), feeds every A fragment to four
 // MFMAs instead of two (a third fewer LDS reads), and has the registers to hang the next stage's commit, its reload and -- for the
-// units that rebuild their embedding-shaped operand -- the PE fill behind the MFMAs of the running stage, a slice per k-step.
+// units that rebuild their embedding-shaped operand -- the PE fill behind the MFMAs of the running stage, a slice per half-step.
+// What the PMC counters then showed the first version had really been bound by: its LDS commit (8-way bank conflicts, 70 % of its LDS
+// cycles -- see the swizzle below).  76.9 -> 58 us; the kernel now runs at the rate its bytes arrive (330 MB at 5.6 TB/s).
 //
 // Units whose input-side operand is embedding-shaped (layer 0, and the embedding columns of the cat layer) do not READ it: the
 // embedding of the even stage and Ebar = J_pe gbar of the odd stage are functions of six floats per point (x' and gbar in x' space,
@@ -70,7 +73,7 @@ __global__ __launch_bounds__(256, 1) void dw_kernel(const DwParams p) {
   typedef DwTile<HD> T;
   constexpr int BM = T::BM, ROWB = T::ROWB, CH = T::CH, NT = T::NT;
   static_assert(TILE_PTS == DW_PTS, "pe_aux staging below assumes one dW stage pair per chain tile");
-  static_assert(CH == 8 && BM / 16 == 4, "two 16-bit chunks (one e4m3 chunk) ride behind each of the four k-steps");
+  static_assert(CH == 8 && BM / 16 == 4, "one 16-bit chunk rides behind each of the eight half-steps (an e4m3 chunk behind every other)");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const NetLayout& L = p.lay;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;

@@ -14,11 +14,11 @@ constexpr int DW_PTS = 64;     // points per dW-kernel stage
 constexpr int CHAIN_NW = 8;    // waves per chain-kernel workgroup (each owns HD/CHAIN_NW features)
 constexpr int CHAIN_CHUNK_FRAGS = 8;   // weight fragments a wave requests at once (32 VGPRs at the 128-VGPR budget)
 // K-splits per dW unit: 5 x 32 + 2 x 48 = 256 workgroups for the default net, one per CU.  With the whole chip at work the kernel
-// runs at the rate its bytes arrive (~4.9 TB/s of operand reads and slab writes), so the split only has to keep every CU busy to the
-// end: the units that REBUILD their embedding-shaped operand (dw.hip) spend ~3 us per 64-point stage on their own (the fill is VALU
-// work of the same four waves that issue the MFMAs), the others ~1.9 us, and the former get half as many stages again fewer.
-// Same-box A/B of 30/53, 32/48, 33/45, 34/43, 35/40: profiles/r06_dw_v2.txt (the first version of the kernel, bound by its LDS
-// commit instead, liked 35/40: profiles/r06_dw_splits.txt).
+// runs at the rate its bytes arrive (~5.6 TB/s of operand reads and slab writes), so the split only has to keep every CU busy to the
+// end: the units that REBUILD their embedding-shaped operand (dw.hip) do VALU work on top of their MFMAs (55 us on their own at 48
+// splits against 50 us for the others at 32) and get the finer split.  Same-box A/Bs of 30/53 .. 36/38, twice: all within 1 us of each
+// other now (profiles/r06_dw_v2.txt; the first version of the kernel, bound by its LDS commit instead, liked 35/40:
+// profiles/r06_dw_splits.txt).
 constexpr int DW_SPLIT_REG = 32, DW_SPLIT_PE = 48, DW_SPLIT_MAX = 48;
 typedef float slab_t;          // K-split partial slabs (bf16 slabs measured: parity unchanged, -2 us only)
 

@@ -1,5 +1,6 @@
-cd $GRAFT_REPO_ROOT; O=gpurun_out/r06_dp; mkdir -p $O
-timeout 600 python -m pytest tests/test_dp_rccl_direct_gpu.py tests/test_dp_gpu.py tests/test_bench_launch.py -x -q -m gpu 2>&1 | tail -3
-ISDF_BENCH_FORCE_DP=1 python bench.py --steps 100 --warmup 30 --no-cpu-baseline --no-accuracy 2>/dev/null | tail -1 | python -c "
-import sys,json
-j=json.loads(sys.stdin.read()); print('forced dp  sync %.4f ms  pipelined %.4f ms  collective %s' % (j['ms_per_step'], j['pipelined']['ms_per_step'], j['distributed'].get('collective')))"
+cd $GRAFT_REPO_ROOT; O=gpurun_out/r06_acc; mkdir -p $O
+A="--paired-draws --keyframes 24 --steps-per-kf 100"
+timeout 1700 python tests/accuracy_experiment.py $A --backend hip --seeds $(seq 21 120) --out $O/paired_hip_21_120.json > $O/paired_hip_21_120.log 2>&1; echo rc=$?
+tail -n 2 $O/paired_hip_21_120.log
+python tools/accuracy_stats.py profiles/r05_accuracy_paired_draws_control_fp32_gpu_seeds21_120.json $O/paired_hip_21_120.json > $O/stats_vs_control.json 2>&1; head -20 $O/stats_vs_control.json
+python tools/accuracy_stats.py profiles/r05_accuracy_paired_draws_hip_seeds21_120.json $O/paired_hip_21_120.json > $O/stats_vs_r05_hip.json 2>&1; head -20 $O/stats_vs_r05_hip.json
