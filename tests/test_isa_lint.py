@@ -64,3 +64,21 @@ def test_hot_kernels_keep_their_register_budgets():
     assert len(one_wave_per_simd) == 6 and max(one_wave_per_simd) <= 512
     two_per_cu = [v["vgpr"] for k, v in hot.items() if "chain_kernelILi256ELi256ELi" in k and "ELi256ELi3E" not in k]    # (OPER 3: one per CU)
     assert len(two_per_cu) >= 9 and max(two_per_cu) <= 128, two_per_cu
+
+
+def test_scratch_in_loops_is_cfg_based():
+    """isa_lint.scratch_in_loops: a spill AROUND a loop is fine, one INSIDE a cycle of the control-flow graph is flagged -- and a
+    backward branch that merely jumps to an earlier block (code layout) does not make everything in between a loop."""
+    text = "\n".join([
+        "0000000000001000 <k>:",
+        "\tscratch_store_dword off, v1, off offset:4          // 000000001000: DC000000",      # before the loop: parked
+        "\ts_nop 0                                            // 000000001008: BF800000",
+        "\tscratch_load_dword v2, off, off                    // 00000000100C: DC000000",      # loop body (0x100c .. 0x1014): flagged
+        "\ts_cbranch_scc1 65533                               // 000000001014: BF85FFFD <k+0xc>",
+        "\ts_branch 3                                         // 000000001018: BF820003 <k+0x28>",   # forward jump over the next block
+        "\tscratch_load_dword v1, off, off offset:4           // 00000000101C: DC000000",      # reached only by the backward jump below: no cycle
+        "\ts_endpgm                                           // 000000001024: BF810000",
+        "\ts_branch 65532                                     // 000000001028: BF82FFFC <k+0x1c>",
+    ])
+    bad = isa_lint.scratch_in_loops_text(text)
+    assert bad == [("k", "scratch_load_dword v2, off, off")], bad
