@@ -232,8 +232,8 @@ def accuracy_leg(local, seeds=(1, 2), n_kf=24, steps_per_kf=100):
             "band_cm": [3.0, 7.0], "band_source": "BASELINE.md 1: final rays.vis.av_l1 of the authors' 12 sequences x 10 runs (0.031-0.074 m, sd ~0.5 cm)",
             "schedule": "%d keyframes x %d steps, 480x640 synthetic room, 200k evaluation rays, paired draws (same initial network, same torch streams)" % (n_kf, steps_per_kf),
             "seconds": round(time.perf_counter() - t0, 1),
-            "note": "two seeds of a chaotic trajectory have a standard error of ~0.6 cm; the 120-paired-seed control of round 5 "
-                    "(profiles/r05_accuracy_gap.txt) measured HIP - control = +0.09 +- 0.09 cm"}
+            "note": "two seeds of a chaotic trajectory have a standard error of ~0.6 cm; the 100-paired-seed control on round 6's final "
+                    "tree (profiles/r06_accuracy_gap.txt) measured HIP - control = -0.12 +- 0.09 cm (round 5, 120 seeds: +0.09 +- 0.09)"}
 
 
 def sampler_scale(args, tr, eng, cam, rank):
