@@ -2,12 +2,9 @@
 for (the realsense nets: eleven / nine octaves, three hidden layers per block).  usage: python tools/step_kernels_by_config.py"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import ctypes as C
 import numpy as np, torch
 from isdf_amd.engine import Engine, NetConfig, LossConfig, SampleConfig
 from isdf_amd import synthetic
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from bench import HipEvents
 
 cam = dict(synthetic.SCANNET_CAM)
 d, n, T = synthetic.keyframes(5, cam, seed=1)
@@ -22,7 +19,6 @@ for name, kw in (("replicaCAD  6 oct, 2 per block", dict()), ("realsense_franka 
     sc = SampleConfig(n_rays=200, **cam); lc = LossConfig()
     s = eng.sample(d, T, n, idx, idx, sc, seed=1, offset=0)
     opt = dict(lr=0.0013, weight_decay=0.012, betas=(0.9, 0.999), eps=1e-8)
-    ev = HipEvents(eng.lib_hip if hasattr(eng, "lib_hip") else None) if False else None
     for _ in range(20):
         eng.train_step(s, lc, sc, noise_std=0.0, optim=opt)
     torch.cuda.synchronize()
