@@ -405,6 +405,12 @@ __global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 && EP == HD && !oper_x2_a
     const uint2 a = pack4<BW>(v[0], v[1], v[2], v[3]), b = pack4<BW>(v[4], v[5], v[6], v[7]);
     bstore16_nt<false>(make_uint4(a.x, a.y, b.x, b.y), srdS, lane16, sbase(tensorOff), cidx(fb, pb, qp));
   };
+  // ZB is written by the LAST sweep and read only by the dW kernel: for the 256-wide nets it goes out non-temporal, which leaves the
+  // Infinity Cache to the tensors the sweeps re-read (chain -1.7 us, dW +0.9: profiles/r06_cache_policy.txt)
+  auto store_tile8_zb = [&](int64_t tensorOff, int fb, int pb, int qp, const float (&v)[8]) {
+    const uint2 a = pack4<BW>(v[0], v[1], v[2], v[3]), b = pack4<BW>(v[4], v[5], v[6], v[7]);
+    bstore16_nt<spill_zb_nt(HD)>(make_uint4(a.x, a.y, b.x, b.y), srdS, lane16, sbase(tensorOff), cidx(fb, pb, qp));
+  };
   // ---- e4m3 spills of P and GB (SpillLayout): 16 bytes per lane = its 8 values of point block 0, then of point block 1.  Encode
   // divides by `scale`, decode multiplies (v_cvt_scalef32_pk_fp8_f32 / _f32_fp8: one instruction per two values, the scale is free).
   static_assert(PB == 2, "a frag8 piece holds the two point blocks of a tile");
@@ -1032,7 +1038,7 @@ __global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 && EP == HD && !oper_x2_a
         bsum[e] += zb[e];
         wsum[e] += sb * a[e];
       }
-      store_tile8_dw(p.sp.ZB[li], fb, pb, qp, zb);
+      store_tile8_zb(p.sp.ZB[li], fb, pb, qp, zb);
       if (li > 0) put_x(BW, fb, pb, qp, zb, 0);
     }, [&](int fb, int qp) {
 #pragma unroll
@@ -1096,7 +1102,7 @@ __global__ __launch_bounds__(CHAIN_NW * 64, (HD <= 256 && EP == HD && !oper_x2_a
         zb[e] = acc[fb][pb][8 * qp + e] * s1 + inj;
         bsum[e] += zb[e];
       }
-      store_tile8_dw(p.sp.ZB[li], fb, pb, qp, zb);
+      store_tile8_zb(p.sp.ZB[li], fb, pb, qp, zb);
       if (li > 0) put_x(BW, fb, pb, qp, zb, 0);
     }, [&](int fb, int qp) {
       vec_store8(bsum, li * HD + ubase(fb, qp));

@@ -42,6 +42,7 @@ constexpr int kAuxNT = 2;   // the non-temporal hint of a buffer load (aux bit 1
 // bench workload).  Larger batches of the 256-wide net (54 k .. 729 k points) are neutral to 3 % faster with the default policy.
 constexpr bool spill_store_nt(int hd) { return hd > 256; }            // the chain kernel's spill stores
 constexpr int spill_load_aux(int hd) { return hd > 256 ? kAuxNT : 0; }   // ... and its re-reads
+constexpr bool spill_zb_nt(int hd) { return hd <= 256; }               // ZB (last sweep -> dW only): around the cache where the cache holds the stack
 constexpr int kAuxDwLoad = kAuxNT;      // the dW kernel's operand loads
 template <int AUX> __device__ __forceinline__ uint4 bload16(rsrc_t r, int voff, int soff) {
   const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, AUX);

@@ -1,2 +1,6 @@
-cd $GRAFT_REPO_ROOT; O=gpurun_out/r06_timeline; mkdir -p $O
-python tools/timeline.py 2>&1 | grep -v amdgpu.ids > $O/timeline.txt; cat $O/timeline.txt | head -90
+cd $GRAFT_REPO_ROOT; O=gpurun_out/r06_cachepol; mkdir -p $O
+for rep in 1 2 3; do for f in variants/lib_*.so; do
+  ISDF_HIP_LIB=$PWD/$f python bench.py --steps 200 --warmup 30 --no-cpu-baseline --no-accuracy 2>/dev/null | tail -1 | python -c "
+import sys,json
+j=json.loads(sys.stdin.read()); print('%-10s rep$rep  sync %.4f ms  pipelined %.4f ms  chain %.4f dw %.4f tail %.4f' % ('$f'.split('lib_')[1][:-3], j['ms_per_step'], j['pipelined']['ms_per_step'], *list(j['kernel_ms'].values())[:3]))"
+done; done > $O/ab_zbnt.txt 2>&1; cat $O/ab_zbnt.txt
