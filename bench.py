@@ -766,7 +766,9 @@ def main():
                          "kernel": "chain_kernel (fused PE+MLP fwd / input-grad / adjoint / reverse)",
                          "achieved": round(flops_chain / t_chain / 1e12, 3), "peak": MFMA_PEAK / 1e12,
                          "unit": "TFLOP/s", "frac": round(flops_chain / t_chain / MFMA_PEAK, 5), "traffic": traffic,
-                         "traffic_unit": "HBM bytes per launch (rocprofv3 --pmc, separate passes)", "traffic_source": traffic_src,
+                         "traffic_unit": "bytes per launch on the L2's fabric side (rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE, separate passes): requests that "
+                                         "leave an XCD's L2, answered by the Infinity Cache or by HBM -- the counters cannot tell which; with the default cache "
+                                         "policy of round 6 the chain kernel's re-reads are mostly Infinity-Cache hits (DESIGN 6)", "traffic_source": traffic_src,
                          "traffic_commit": traffic_commit,
                          "hbm": None if traffic is None else {"achieved": round(traffic / t_chain / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
                                                               "frac": round(traffic / t_chain / 8e12, 4),
