@@ -1,10 +1,9 @@
-cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r06_chainpmc; mkdir -p $O
-for v in base ldsw base ldsw; do
-  rm -rf /tmp/st_$v; ISDF_HIP_LIB=$R/variants/lib_$v.so timeout 120 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/st_$v -- python $R/tools/train_only.py 200 > /dev/null 2>&1
-  f=$(find /tmp/st_$v -name '*kernel_stats.csv' | head -1)
-  python3 -c "
-import csv,sys
-for r in csv.DictReader(open('$f')):
-    if 'chain_kernel' in r['Name'] or 'dw_kernel' in r['Name']: print('$v', r['Name'][:40], r['Calls'], '%.1f us' % (float(r['AverageNs'])/1e3))"
-done > $O/whatif_lds_write.txt; cat $O/whatif_lds_write.txt
+cd $GRAFT_REPO_ROOT; O=gpurun_out/r06_preload; mkdir -p $O
+ISDF_HIP_LIB=$PWD/variants/lib_prev.so python tools/train_ab_check.py --dump /tmp/a.npz > $O/ab_check.txt 2>&1
+ISDF_HIP_LIB=$PWD/variants/lib_pw1.so python tools/train_ab_check.py --dump /tmp/b.npz >> $O/ab_check.txt 2>&1
+python tools/train_ab_check.py --compare /tmp/a.npz /tmp/b.npz 2>&1 | grep -c "bit-identical"; python tools/train_ab_check.py --compare /tmp/a.npz /tmp/b.npz 2>&1 | grep -v "bit-identical" | head -5
+for rep in 1 2 3; do for f in variants/lib_*.so; do
+  ISDF_HIP_LIB=$PWD/$f python bench.py --steps 200 --warmup 30 --no-cpu-baseline --no-accuracy 2>/dev/null | tail -1 | python -c "
+import sys,json
+j=json.loads(sys.stdin.read()); print('%-10s rep$rep  sync %.4f ms  pipelined %.4f ms  chain %.4f dw %.4f tail %.4f' % ('$f'.split('lib_')[1][:-3], j['ms_per_step'], j['pipelined']['ms_per_step'], *list(j['kernel_ms'].values())[:3]))"
+done; done > $O/ab.txt 2>&1; cat $O/ab.txt
