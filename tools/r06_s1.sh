@@ -1,7 +1,7 @@
-cd $GRAFT_REPO_ROOT; O=gpurun_out/r06_preload; mkdir -p $O
-ISDF_HIP_LIB=$PWD/variants/lib_prev.so python tools/train_ab_check.py --dump /tmp/a.npz > $O/ab_check.txt 2>&1
-ISDF_HIP_LIB=$PWD/variants/lib_pw1.so python tools/train_ab_check.py --dump /tmp/b.npz >> $O/ab_check.txt 2>&1
-python tools/train_ab_check.py --compare /tmp/a.npz /tmp/b.npz 2>&1 | grep -c "bit-identical"; python tools/train_ab_check.py --compare /tmp/a.npz /tmp/b.npz 2>&1 | grep -v "bit-identical" | head -5
+# Round 6's scratch gpurun session (rewritten per experiment during the round; left in its most-used form):
+#   every variants/lib_*.so -- built by tools/build_variants.py / tools/build_rev_lib.sh -- through the same bench, alternating, on ONE box.
+#   /usr/local/graft/bin/gpurun --timeout 900 -- 'timeout 850 bash tools/r06_s1.sh'
+cd $GRAFT_REPO_ROOT; O=gpurun_out/r06_ab; mkdir -p $O
 for rep in 1 2 3; do for f in variants/lib_*.so; do
   ISDF_HIP_LIB=$PWD/$f python bench.py --steps 200 --warmup 30 --no-cpu-baseline --no-accuracy 2>/dev/null | tail -1 | python -c "
 import sys,json
