@@ -90,6 +90,9 @@ __global__ __launch_bounds__(256, 1) void dw_kernel(const DwParams p) {
   const int slBfull = (li == L.cat && fromEmb) ? du.ib - HD / DW_BLK : du.ib;   // 256-column slice of the operand
   const int slB = slBfull % (HD / DW_BLK);
   const int slA = du.ob;
+  // A slice of the padded embedding that lies entirely behind its last feature (the 512-wide net of BASELINE configs[4]: E = 255 in an
+  // EP = 512 operand) is all zeros: no parameter sits behind any of its dW columns and the step tail never reads its slab.
+  if (fromEmb && slBfull * DW_BLK >= L.E) return;
 
   const int64_t P = p.n_valid ? (int64_t)(*p.n_valid) * p.S : p.n_points_host;
   const int nTiles = (int)((P + TILE_PTS - 1) / TILE_PTS);
@@ -113,7 +116,7 @@ __global__ __launch_bounds__(256, 1) void dw_kernel(const DwParams p) {
 
   const int nStages = split < nTiles ? 2 * ((nTiles - split + DW_SPLITK - 1) / DW_SPLITK) : 0;
   // a PE unit of a six-octave net builds its operand in the ALIGNED column order (see run()); others in the reference's order
-  const bool peAligned = fromEmb && L.EP == DW_BLK && L.n_freqs == 6;
+  const bool peAligned = fromEmb && slBfull == 0 && L.E <= DW_BLK && L.n_freqs == 6;
 
   // per-lane transpose-read addressing: in each 16-lane group source lane s
   // supplies row (s>>2), 4-element column chunk (s&3); destination lane i gets
