@@ -210,9 +210,12 @@ __global__ __launch_bounds__(256, 1) void dw_kernel(const DwParams p) {
   // (NFT: a PE unit's octave count at compile time = the ALIGNED operand order, or 0 = the reference's order with a run-time octave loop.
   // A launch-uniform choice, but made per run() instantiation and not inside the fill: a branch there would cut every half-step's
   // scheduling region in two and put the fill BEHIND the MFMAs instead of between them.)
-  auto run = [&](auto pe_tag, auto p8_tag, auto nft_tag) {
+  // (SLT: for the nets whose embedding spans two 256-column slices -- nine / eleven octaves: realsense*.json -- which slice this unit
+  // rebuilds, again per instantiation: slice 0 holds x', every sine and the first cosines, slice 1 the other cosines and the padding.)
+  auto run = [&](auto pe_tag, auto p8_tag, auto nft_tag, auto slice_tag) {
     constexpr bool PE = decltype(pe_tag)::value;
-    constexpr int NFT = decltype(nft_tag)::value;
+    constexpr int NFT = decltype(nft_tag)::value, SLT = decltype(slice_tag)::value;
+    constexpr bool ALIGNED = NFT == 6;          // (the aligned column order exists for the six-octave nets only)
     constexpr bool p8 = decltype(p8_tag)::value, g8 = SP8 & 1;     // this unit's P / GB are e4m3 tensors
     constexpr int CHA1 = p8 ? CH8 : CH, CHB1 = g8 ? CH8 : CH;
     // Two register sets so TWO stages of global loads are in flight while one is computed.
@@ -347,7 +350,7 @@ __global__ __launch_bounds__(256, 1) void dw_kernel(const DwParams p) {
         const float c2 = __builtin_fmaf(-u, sn, 1.f);
         sn = u * cs; cs = c2; kf += kf;
       };
-      if constexpr (NFT != 0) {
+      if constexpr (ALIGNED) {
         // STRAIGHT-LINE code: in the last round, which has 64 direction items and 64 x' rows for 256 threads, every thread runs both
         // store sequences and the ones without work aim at a spare LDS row (a select, not a branch)
         static_assert(NFT % 2 == 0 && 2 * N_DIRS * NFT + 4 == DW_BLK, "paired stores; x' and one zero fill the slice behind the 42 NFT sine / cosine columns");
@@ -366,6 +369,29 @@ __global__ __launch_bounds__(256, 1) void dw_kernel(const DwParams p) {
           const float4 v = Q1 ? g : y;
           e2 v01, v2z; v01[0] = (eT)v.x; v01[1] = (eT)v.y; v2z[0] = (eT)v.z; v2z[1] = (eT)0.f;
           *(e2*)(xrow + 2 * N_DIRS * NFT * 2) = v01; *(e2*)(xrow + 2 * N_DIRS * NFT * 2 + 4) = v2z;
+        }
+      } else if constexpr (NFT != 0) {
+        // The reference's column order [x' | sin | cos | padding] at a compile-time octave count, STRAIGHT-LINE as well: a store whose
+        // column falls outside this unit's slice -- or whose thread has no item in the last round -- aims at the spare row (a select per
+        // store instead of a branch per store: the branchy loop below runs ~10 us per 64-point stage on its own).  2-byte stores: with an
+        // odd octave count the groups start at either parity.  Every sine lives in slice 0 (3 + 21 NFT <= 256 up to twelve octaves).
+        static_assert(3 + N_DIRS * NFT <= DW_BLK && 3 + 2 * N_DIRS * NFT > DW_BLK && 3 + 2 * N_DIRS * NFT <= 2 * DW_BLK, "two slices; the sines in the first");
+        char* dummy = smem + T::DUMMY;
+        char* irow = !lastRound || tid < lastItems ? row : dummy;
+        const int cS = 3 + d * NFT, cC = cS + N_DIRS * NFT - SLT * DW_BLK;      // first sine / cosine column of the direction, relative to this slice
+#pragma unroll
+        for (int f = 0; f < NFT; ++f) {
+          float a, b;
+          vals(a, b);
+          if constexpr (SLT == 0) *(eT*)(irow + (cS + f) * 2) = (eT)a;
+          const int cc = cC + f;
+          char* pc = (unsigned)cc < (unsigned)DW_BLK ? irow : dummy;
+          *(eT*)(pc + (cc & (DW_BLK - 1)) * 2) = (eT)b;
+        }
+        if constexpr (lastRound && SLT == 0) {      // x' in front of the sines; the padding behind the cosines (slice 1) is zeroed once, ahead of the stage loop
+          char* xrow = tid >= lastItems && tid < lastItems + BM ? row : dummy;
+          const float4 v = Q1 ? g : y;
+          *(eT*)(xrow) = (eT)v.x; *(eT*)(xrow + 2) = (eT)v.y; *(eT*)(xrow + 4) = (eT)v.z;
         }
       } else if (!lastRound || tid < lastItems) {
         const int cS = 3 + d * nf - colBase, cC = cS + halfE;      // first column of the sine / cosine group in this slice
@@ -418,6 +444,15 @@ __global__ __launch_bounds__(256, 1) void dw_kernel(const DwParams p) {
 
     if constexpr (PE) {
       load_aux(0); store_aux(0); load_aux(1);
+      if constexpr (NFT != 0 && !ALIGNED && SLT == 1) {      // the zero padding behind the last cosine column: the same in every stage, written once into both buffers
+        constexpr int c0 = 3 + 2 * N_DIRS * NFT - DW_BLK, npad = DW_BLK - c0;
+        typedef typename Op<F16>::e eT0;
+        for (int i = tid; i < BM * npad; i += NT) {
+          const int r = i / npad, c = c0 + i - r * npad;
+          *(eT0*)(smem + T::TEN + r * ROWB + c * 2) = (eT0)0.f;
+          *(eT0*)(smem + 3 * T::TEN + r * ROWB + c * 2) = (eT0)0.f;
+        }
+      }
     }
     each_slice([&](auto k, auto h) { issue(0, std::false_type{}, k, h); });
     each_slice([&](auto k, auto h) { issue(1, std::true_type{}, k, h); });
@@ -449,11 +484,20 @@ __global__ __launch_bounds__(256, 1) void dw_kernel(const DwParams p) {
     }
   };
   typedef std::integral_constant<bool, (SP8 & 2) != 0> P8T;
+  typedef std::integral_constant<int, 0> I0_; typedef std::integral_constant<int, 1> I1_;
+  // the reference-order fill at a compile-time octave count: the nine / eleven-octave nets (16-bit spills: SP8 = 0 instantiations only)
+  const bool straightRef = SP8 == 0 && fromEmb && L.EP == 2 * DW_BLK && (L.n_freqs == 9 || L.n_freqs == 11);
   if (nStages == 0) {}      // (more K-splits than tiles: a zero slab)
-  else if (fromEmb && peAligned) run(std::true_type{}, P8T{}, std::integral_constant<int, 6>{});
-  else if (fromEmb) run(std::true_type{}, P8T{}, std::integral_constant<int, 0>{});
-  else if ((SP8 & 2) && li == L.L - 1) run(std::false_type{}, std::false_type{}, std::integral_constant<int, 0>{});      // the top layer's P stays 16-bit (SpillLayout)
-  else run(std::false_type{}, P8T{}, std::integral_constant<int, 0>{});
+  else if (fromEmb && peAligned) run(std::true_type{}, P8T{}, std::integral_constant<int, 6>{}, I0_{});
+  else if (straightRef) {
+    if constexpr (SP8 == 0) {
+      if (L.n_freqs == 9) { if (slBfull == 0) run(std::true_type{}, P8T{}, std::integral_constant<int, 9>{}, I0_{}); else run(std::true_type{}, P8T{}, std::integral_constant<int, 9>{}, I1_{}); }
+      else { if (slBfull == 0) run(std::true_type{}, P8T{}, std::integral_constant<int, 11>{}, I0_{}); else run(std::true_type{}, P8T{}, std::integral_constant<int, 11>{}, I1_{}); }
+    }
+  }
+  else if (fromEmb) run(std::true_type{}, P8T{}, std::integral_constant<int, 0>{}, I0_{});
+  else if ((SP8 & 2) && li == L.L - 1) run(std::false_type{}, std::false_type{}, std::integral_constant<int, 0>{}, I0_{});      // the top layer's P stays 16-bit (SpillLayout)
+  else run(std::false_type{}, P8T{}, std::integral_constant<int, 0>{}, I0_{});
 
   // partial slab [o][i]
   slab_t* slab = (slab_t*)p.dwPart + ((int64_t)dw_slab_base(L, unit) + split) * DW_BLK * DW_BLK;

@@ -22,7 +22,8 @@ def dump(path):
     dev = lambda a: torch.as_tensor(a).cuda()
     d, n, T = dev(d), dev(n), dev(T)
     cases = [("default", {}), ("fp16", dict(fwd_operand="fp16")), ("bf16", dict(fwd_operand="bf16")),
-             ("wide", dict(hidden=512, blocks=3, n_freqs=10))]
+             ("wide", dict(hidden=512, blocks=3, n_freqs=10)),
+             ("nf11", dict(n_freqs=11)), ("nf9b3", dict(n_freqs=9, blocks=3))]      # the realsense nets' shapes (eleven / nine octaves)
     if "spill_operand" in NetConfig.__dataclass_fields__:      # the spill formats of the default net, side by side
         cases += [("spill16", dict(spill_operand="16bit")), ("spill_e4m3", dict(spill_operand="e4m3")),
                   ("spill_e4m3_gb", dict(spill_operand="e4m3_gb"))]
