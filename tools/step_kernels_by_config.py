@@ -11,8 +11,9 @@ d, n, T = synthetic.keyframes(5, cam, seed=1)
 dev = lambda a: torch.as_tensor(a).cuda()
 d, n, T = dev(d), dev(n), dev(T)
 idx = torch.arange(5, dtype=torch.int32, device="cuda")
-for name, kw in (("replicaCAD  6 oct, 2 per block", dict()), ("realsense_franka 11 oct, 2 per block", dict(n_freqs=11)),
-                 ("realsense 9 oct, 3 per block", dict(n_freqs=9, blocks=3)), ("16-bit spills", dict(spill_operand="16bit")),
+for name, kw in (("replicaCAD / scannet: 6 oct, 2 per block", dict()), ("realsense(_franka): 9 oct, 2 per block", dict(n_freqs=9)),
+                 ("realsense_franka_offline: 11 oct, 3 per block", dict(n_freqs=11, blocks=3)),
+                 ("(11 oct, 2 per block)", dict(n_freqs=11)), ("(9 oct, 3 per block)", dict(n_freqs=9, blocks=3)), ("16-bit spills", dict(spill_operand="16bit")),
                  ("bf16", dict(fwd_operand="bf16"))):
     eng = Engine(NetConfig(transform=synthetic.bounds_transform(), **kw), "cuda")
     torch.manual_seed(0); eng.params.normal_(0, 0.06); eng.pack()
@@ -27,4 +28,4 @@ for name, kw in (("replicaCAD  6 oct, 2 per block", dict()), ("realsense_franka 
     for _ in range(100):
         eng.train_step(s, lc, sc, noise_std=0.0, optim=opt)
     e1.record(); torch.cuda.synchronize()
-    print("%-40s chain + dW + tail %.1f us per step" % (name, e0.elapsed_time(e1) * 10))
+    print("%-46s chain + dW + tail %.1f us per step" % (name, e0.elapsed_time(e1) * 10))
